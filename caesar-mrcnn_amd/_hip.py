@@ -1,0 +1,123 @@
+"""ctypes binding of libmrcnn_hip.so (the C-ABI declared in include/mrcnn_hip.h).
+
+This is the only way the product path reaches the GPU: there is no eager/PyTorch fallback.  If the
+library is missing or a call returns a non-zero status a ``HipPathError`` is raised.
+PyTorch is used by the callers only as the owner of device memory and of the current HIP stream.
+"""
+import ctypes as C
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libmrcnn_hip.so")
+
+
+class HipPathError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad_t", "pad_l", "OH", "OW",
+        "act", "res_mode", "out_mode", "cmod")] + [
+        ("out_n_stride", C.c_int64), ("out_h_stride", C.c_int64), ("out_w_stride", C.c_int64)]
+
+
+class RoiAlignDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("R", C.c_int32), ("P", C.c_int32), ("C", C.c_int32),
+                ("H", C.c_int32 * 4), ("W", C.c_int32 * 4), ("image_area", C.c_float)]
+
+
+class ProposalDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("A", C.c_int32), ("pre_nms_limit", C.c_int32),
+                ("proposal_count", C.c_int32), ("nms_threshold", C.c_float), ("std_dev", C.c_float * 4)]
+
+
+class DetTargetDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "R", "G", "T", "MH", "MW", "mask_h", "mask_w",
+                                          "positive_count")] + [
+        ("negative_ratio_r", C.c_float), ("bbox_std_dev", C.c_float * 4), ("use_mini_mask", C.c_int32)]
+
+
+class DetectionDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("R", C.c_int32), ("C", C.c_int32), ("max_instances", C.c_int32),
+                ("min_confidence", C.c_float), ("nms_threshold", C.c_float), ("bbox_std_dev", C.c_float * 4)]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "A", "T", "C", "mask_h", "mask_w", "max_rpn_pos",
+                                          "mask_loss_dice")] + [("w", C.c_float * 5)]
+
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+RES_NONE, RES_SAME, RES_UP2 = 0, 1, 2
+OUT_NHWC, OUT_DECONV2 = 0, 1
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "mrcnn_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 9),
+    "mrcnn_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, C.c_size_t, C.c_int, _P]),
+    "mrcnn_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
+    "mrcnn_weight_flip_transpose": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mrcnn_bn_fold": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, _P, C.c_int64, _P]),
+    "mrcnn_epilogue_bwd": (C.c_int, [_P] * 11 + [C.c_int64, C.c_int, C.c_int, _P]),
+    "mrcnn_maxpool3x3s2_fwd": (C.c_int, [_P, _P, _P] + [C.c_int] * 8 + [_P]),
+    "mrcnn_maxpool3x3s2_bwd": (C.c_int, [_P, _P, _P] + [C.c_int] * 6 + [_P]),
+    "mrcnn_subsample2_fwd": (C.c_int, [_P, _P] + [C.c_int] * 4 + [_P]),
+    "mrcnn_subsample2_bwd_acc": (C.c_int, [_P, _P] + [C.c_int] * 4 + [_P]),
+    "mrcnn_upsample2_bwd": (C.c_int, [_P, _P] + [C.c_int] * 5 + [_P]),
+    "mrcnn_add_inplace": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "mrcnn_softmax_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    "mrcnn_roialign_fwd": (C.c_int, [C.POINTER(RoiAlignDesc)] + [_P] * 8),
+    "mrcnn_roialign_bwd": (C.c_int, [C.POINTER(RoiAlignDesc)] + [_P] * 7),
+    "mrcnn_proposal_workspace": (C.c_size_t, [C.POINTER(ProposalDesc)]),
+    "mrcnn_proposal_fwd": (C.c_int, [C.POINTER(ProposalDesc)] + [_P] * 8 + [C.c_size_t, _P]),
+    "mrcnn_detection_targets": (C.c_int, [C.POINTER(DetTargetDesc)] + [_P] * 12),
+    "mrcnn_detection_workspace": (C.c_size_t, [C.POINTER(DetectionDesc)]),
+    "mrcnn_detection_fwd": (C.c_int, [C.POINTER(DetectionDesc)] + [_P] * 6 + [C.c_size_t, _P]),
+    "mrcnn_losses_workspace": (C.c_size_t, [C.POINTER(LossDesc)]),
+    "mrcnn_losses_fwd_bwd": (C.c_int, [C.POINTER(LossDesc)] + [_P] * 18 + [C.c_size_t, _P]),
+    "mrcnn_grad_prepare": (C.c_int, [_P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int64, _P]),
+    "mrcnn_sumsq": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "mrcnn_sgd_momentum": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
+                                      _P, _P, _P, C.c_int, C.c_int64, _P]),
+    "mrcnn_hip_version": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names every build of the library must export (mirrors include/mrcnn_hip.h)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load (once) and return the kernel library; never falls back to anything else."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipPathError(
+                "libmrcnn_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'`; there is no CPU fallback for the hot path." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)   # AttributeError here == symbol missing == broken build
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        raise HipPathError("%s failed with status %d" % (what, status))
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor / None."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

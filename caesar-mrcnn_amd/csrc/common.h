@@ -1,0 +1,64 @@
+// Shared device/host helpers for the gfx950 kernels of the Mask R-CNN hot path.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mrcnn_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WAVE 64
+
+static inline int mrcnn_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? MRCNN_OK : MRCNN_ERR_LAUNCH;
+}
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// TF non_max_suppression overlap test [3P]: canonical corners, 0 for empty boxes, IoU > thr.
+__device__ __forceinline__ bool iou_gt(const float* a, const float* bx, float thr) {
+    const float ymin_i = fminf(a[0], a[2]), xmin_i = fminf(a[1], a[3]);
+    const float ymax_i = fmaxf(a[0], a[2]), xmax_i = fmaxf(a[1], a[3]);
+    const float ymin_j = fminf(bx[0], bx[2]), xmin_j = fminf(bx[1], bx[3]);
+    const float ymax_j = fmaxf(bx[0], bx[2]), xmax_j = fmaxf(bx[1], bx[3]);
+    const float area_i = (ymax_i - ymin_i) * (xmax_i - xmin_i);
+    const float area_j = (ymax_j - ymin_j) * (xmax_j - xmin_j);
+    if (area_i <= 0.f || area_j <= 0.f) return false;
+    const float iy0 = fmaxf(ymin_i, ymin_j), ix0 = fmaxf(xmin_i, xmin_j);
+    const float iy1 = fminf(ymax_i, ymax_j), ix1 = fminf(xmax_i, xmax_j);
+    const float inter = fmaxf(iy1 - iy0, 0.f) * fmaxf(ix1 - ix0, 0.f);
+    const float iou = inter / (area_i + area_j - inter);
+    return iou > thr;
+}
+
+
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
+    unsigned lo = (unsigned)__shfl((int)(unsigned)(v & 0xFFFFFFFFull), src, 64);
+    unsigned hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src, 64);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+
+// apply_box_deltas_graph + clip_boxes_graph (mrcnn/model.py:287-326), float32 op by op.
+__device__ __forceinline__ void decode_clip_box(const float* box, float d0, float d1, float d2, float d3,
+                                                float wy1, float wx1, float wy2, float wx2, float* o) {
+    float height = box[2] - box[0], width = box[3] - box[1];
+    float cy = box[0] + 0.5f * height, cx = box[1] + 0.5f * width;
+    cy += d0 * height;
+    cx += d1 * width;
+    height *= expf(d2);
+    width *= expf(d3);
+    float y1 = cy - 0.5f * height, x1 = cx - 0.5f * width;
+    float y2 = y1 + height, x2 = x1 + width;
+    o[0] = fmaxf(fminf(y1, wy2), wy1);
+    o[1] = fmaxf(fminf(x1, wx2), wx1);
+    o[2] = fmaxf(fminf(y2, wy2), wy1);
+    o[3] = fmaxf(fminf(x2, wx2), wx1);
+}

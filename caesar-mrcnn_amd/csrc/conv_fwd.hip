@@ -1,0 +1,263 @@
+// Implicit-GEMM convolution forward for gfx950 on the exact-fp32 matrix cores
+// (v_mfma_f32_32x32x2_f32).  Stands in for KL.Conv2D / Dense / Conv2DTranspose(2x2,s2) + frozen
+// BatchNorm + Add + Activation of the reference graph (mrcnn/model.py:99-210, 916-957, 986-1091,
+// 2005-2022).  GEMM view: M = N*OH*OW pixels, N = Cout, K = KH*KW*Cin; A is gathered on the fly
+// from the NHWC input (never materialised), B is the HWIO weight matrix as stored by Keras.
+//
+// Tiling: BM x BN output tile per workgroup, K-step 32, WM x WN waves, each wave owns
+// (BM/WM) x (BN/WN) as TM x TN MFMA tiles of 32x32.  Within a K-step the two half-waves take
+// k in [0,16) and [16,32) (the MFMA's two k-slices), so a lane reads 16 contiguous k of its A row
+// with four ds_read_b128 and its B column with conflict-free ds_read_b32.  Next K-step's global loads
+// are issued into registers before the MFMAs of the current one (register-staged prefetch).
+#include "common.h"
+
+struct ConvArgs {
+    const float* x; const float* w; const float* bias; const float* scale; const float* shift;
+    const float* res; float* out; float* z;
+    int N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW;
+    int act, res_mode, out_mode, cmod;
+    long long ons, ohs, ows;
+    int M, Ktot, nk, fastA, vecB, dense;
+};
+
+// One 32x32 accumulator tile: lane holds column n, rows mbase + (r&3) + 8*(r>>2).
+__device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& p, const f32x16& acc, int mbase, int n) {
+    if (n >= p.Cout) return;
+    const int c = n % p.cmod;
+    const float bias = p.bias ? p.bias[c] : 0.f;
+    const float sc = p.scale ? p.scale[c] : 1.f;
+    const float sh = p.scale ? p.shift[c] : 0.f;
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        if (m >= p.M) continue;
+        float zv = acc[r] + bias;
+        long long addr, raddr;
+        if (p.dense && p.res_mode != MRCNN_RES_UP2) {
+            addr = (long long)m * p.Cout + n;
+            raddr = addr;
+        } else {
+            int ni = m / ohw, rem = m - ni * ohw;
+            int oh = rem / p.OW, ow = rem - oh * p.OW;
+            if (p.out_mode == MRCNN_OUT_DECONV2) {
+                int ab = n / p.cmod;
+                addr = (long long)ni * p.ons + (long long)(2 * oh + (ab >> 1)) * p.ohs +
+                       (long long)(2 * ow + (ab & 1)) * p.ows + c;
+            } else {
+                addr = (long long)ni * p.ons + (long long)oh * p.ohs + (long long)ow * p.ows + n;
+            }
+            raddr = addr;
+            if (p.res_mode == MRCNN_RES_UP2)
+                raddr = (((long long)ni * (p.OH >> 1) + (oh >> 1)) * (p.OW >> 1) + (ow >> 1)) * p.Cout + n;
+        }
+        if (p.z) p.z[addr] = zv;
+        float y = sc * zv + sh;
+        if (p.res_mode != MRCNN_RES_NONE) y += p.res[raddr];
+        if (p.act == MRCNN_ACT_RELU) y = fmaxf(y, 0.f);
+        else if (p.act == MRCNN_ACT_SIGMOID) y = 1.f / (1.f + expf(-y));
+        p.out[addr] = y;
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArgs p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AST = 36;          // A row stride (floats): 32 + 4 pad -> conflict-free b128 reads
+    constexpr int BST = BN + 4;
+    constexpr int AV = BM * 8 / NT;  // float4 loads of A per thread per K-step
+    constexpr int BV = 8 * BN / NT;  // float4 loads of B per thread per K-step
+    constexpr int AROWSTEP = NT / 8;
+    __shared__ __attribute__((aligned(16))) float lds[BM * AST + 32 * BST];
+    float* As = lds;
+    float* Bs = lds + BM * AST;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntiles = (p.Cout + BN - 1) / BN;
+    const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x % ntiles;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+
+    // ---- per-thread A row bookkeeping -------------------------------------------------------
+    const int a_c4 = tid & 7;
+    int a_ih0[AV], a_iw0[AV];
+    long long a_nb[AV];
+    bool a_ok[AV];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int i = 0; i < AV; ++i) {
+        int m = m0 + (tid >> 3) + i * AROWSTEP;
+        a_ok[i] = m < p.M;
+        int mm = a_ok[i] ? m : 0;
+        int n = mm / ohw, rem = mm - n * ohw;
+        int oh = rem / p.OW, ow = rem - oh * p.OW;
+        a_ih0[i] = oh * p.stride - p.pad_t;
+        a_iw0[i] = ow * p.stride - p.pad_l;
+        a_nb[i] = (long long)n * p.H * p.W * p.Cin;
+    }
+
+    f32x4 ra[AV], rb[BV];
+    int kh = 0, kw = 0, ci0 = 0;   // fast-path K-step position
+
+    auto load_tiles = [&](int ks) {
+        if (p.fastA) {
+#pragma unroll
+            for (int i = 0; i < AV; ++i) {
+                int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                bool v = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const float* ptr = p.x + a_nb[i] + ((long long)ih * p.W + iw) * p.Cin + ci0 + a_c4 * 4;
+                ra[i] = v ? *(const f32x4*)ptr : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            ci0 += 32;
+            if (ci0 >= p.Cin) { ci0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+        } else {
+#pragma unroll
+            for (int i = 0; i < AV; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    int k = ks * 32 + a_c4 * 4 + e;
+                    if (a_ok[i] && k < p.Ktot) {
+                        int tap = k / p.Cin, ci = k - tap * p.Cin;
+                        int tkh = tap / p.KW, tkw = tap - tkh * p.KW;
+                        int ih = a_ih0[i] + tkh, iw = a_iw0[i] + tkw;
+                        if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                            v[e] = p.x[a_nb[i] + ((long long)ih * p.W + iw) * p.Cin + ci];
+                    }
+                }
+                ra[i] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BV; ++i) {
+            int idx = tid + i * NT;
+            int krow = idx / (BN / 4), c4 = idx % (BN / 4);
+            int k = ks * 32 + krow, n = n0 + c4 * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < p.Ktot) {
+                const float* ptr = p.w + (long long)k * p.Cout + n;
+                if (p.vecB) {
+                    if (n < p.Cout) v = *(const f32x4*)ptr;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.Cout) v[e] = ptr[e];
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int i = 0; i < AV; ++i) {
+            int r = (tid >> 3) + i * AROWSTEP;
+            *(f32x4*)&As[r * AST + a_c4 * 4] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BV; ++i) {
+            int idx = tid + i * NT;
+            int krow = idx / (BN / 4), c4 = idx % (BN / 4);
+            *(f32x4*)&Bs[krow * BST + c4 * 4] = rb[i];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    for (int ks = 0; ks < p.nk; ++ks) {
+        if (ks + 1 < p.nk) load_tiles(ks + 1);
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            f32x4 av[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+                av[a] = *(const f32x4*)&As[(wm * TM * 32 + a * 32 + li) * AST + lh * 16 + t4 * 4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float bv[TN];
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    bv[b] = Bs[(lh * 16 + t4 * 4 + e) * BST + wn * TN * 32 + b * 32 + li];
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (ks + 1 < p.nk) {
+            store_tiles();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: bias, frozen-BN affine, residual, activation ---------------------------------
+    const int mw0 = m0 + wm * TM * 32 + 4 * lh, nw0 = n0 + wn * TN * 32 + li;
+    if constexpr (TM >= 1 && TN >= 1) conv_epilogue_tile(p, acc[0][0], mw0, nw0);
+    if constexpr (TM >= 1 && TN >= 2) conv_epilogue_tile(p, acc[0][1], mw0, nw0 + 32);
+    if constexpr (TM >= 2 && TN >= 1) conv_epilogue_tile(p, acc[1][0], mw0 + 32, nw0);
+    if constexpr (TM >= 2 && TN >= 2) conv_epilogue_tile(p, acc[1][1], mw0 + 32, nw0 + 32);
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_conv(const ConvArgs& a, hipStream_t s) {
+    const int mt = (a.M + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN>), dim3((unsigned)(mt * nt)), dim3(WM * WN * 64), 0, s, a);
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc* d, const float* x, const float* w,
+                                const float* bias, const float* scale, const float* shift,
+                                const float* res, float* out, float* z_out, void* stream) {
+    if (!d || !x || !w || !out) return MRCNN_ERR_ARG;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 ||
+        d->stride <= 0 || d->OH <= 0 || d->OW <= 0 || d->cmod <= 0)
+        return MRCNN_ERR_ARG;
+    if (d->res_mode != MRCNN_RES_NONE && !res) return MRCNN_ERR_ARG;
+    if (scale && !shift) return MRCNN_ERR_ARG;
+    if (d->out_mode == MRCNN_OUT_DECONV2 && (d->Cout != 4 * d->cmod || d->res_mode != MRCNN_RES_NONE))
+        return MRCNN_ERR_ARG;
+    if (d->res_mode == MRCNN_RES_UP2 && ((d->OH & 1) || (d->OW & 1))) return MRCNN_ERR_ARG;
+    // the last input row/col touched must exist for at least one tap (host-side shape sanity)
+    if ((long long)(d->OH - 1) * d->stride - d->pad_t >= d->H || (long long)(d->OW - 1) * d->stride - d->pad_l >= d->W)
+        return MRCNN_ERR_ARG;
+    long long M = (long long)d->N * d->OH * d->OW;
+    if (M >= (1LL << 31) || (long long)d->KH * d->KW * d->Cin >= (1LL << 31)) return MRCNN_ERR_ARG;
+
+    ConvArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.scale = scale; a.shift = shift; a.res = res; a.out = out; a.z = z_out;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
+    a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.OH = d->OH; a.OW = d->OW;
+    a.act = d->act; a.res_mode = d->res_mode; a.out_mode = d->out_mode; a.cmod = d->cmod;
+    a.ons = d->out_n_stride; a.ohs = d->out_h_stride; a.ows = d->out_w_stride;
+    a.M = (int)M; a.Ktot = d->KH * d->KW * d->Cin; a.nk = (a.Ktot + 31) / 32;
+    a.fastA = (d->Cin % 32 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    a.vecB = (d->Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
+    a.dense = d->out_mode == MRCNN_OUT_NHWC && d->out_w_stride == d->Cout &&
+              d->out_h_stride == (int64_t)d->OW * d->Cout && d->out_n_stride == (int64_t)d->OH * d->OW * d->Cout;
+    hipStream_t s = (hipStream_t)stream;
+
+    const int Cout = d->Cout;
+    if (Cout <= 32) {
+        long long blocks128 = (M + 127) / 128;
+        return blocks128 >= 256 ? launch_conv<128, 32, 4, 1>(a, s) : launch_conv<64, 32, 2, 1>(a, s);
+    } else if (Cout <= 64) {
+        long long blocks128 = (M + 127) / 128;
+        return blocks128 >= 256 ? launch_conv<128, 64, 2, 2>(a, s) : launch_conv<64, 64, 2, 2>(a, s);
+    } else {
+        long long nt = (Cout + 127) / 128;
+        long long blocks128 = ((M + 127) / 128) * nt;
+        return blocks128 >= 256 ? launch_conv<128, 128, 2, 2>(a, s) : launch_conv<64, 128, 2, 2>(a, s);
+    }
+}

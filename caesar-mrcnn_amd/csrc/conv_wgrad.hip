@@ -1,0 +1,268 @@
+// Weight gradient of the implicit-GEMM convolution on the fp32 matrix cores:
+//   dW[(kh,kw,ci), co] = sum over pixels m of  X[n, oh*s+kh-pt, ow*s+kw-pl, ci] * dY[m, co]
+// (the reference obtains it from TF autodiff of KL.Conv2D; mrcnn/model.py:2487 fit_generator).
+// GEMM view: rows i = (tap, ci) in [0, K), columns co, contraction over the M = N*OH*OW pixels.
+// A workgroup owns a BI x BN tile of dW for one pixel range ("split"); BI divides Cin on the fast path
+// so the tile sits inside one filter tap and its X rows are contiguous channel runs.  Both operands are
+// staged pixel-major in LDS ([32 pixels][channels]) which is already the layout the 32x32x2 MFMA wants
+// (lane = channel, k = pixel): every LDS read is a conflict-free ds_read_b32.  Splits write partial
+// slabs that a second kernel sums in a fixed order, so dW is bitwise reproducible.
+#include "common.h"
+
+struct WgradArgs {
+    const float* x; const float* dy; float* out;   // out: dw (splits==1) or slabs
+    int N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW;
+    int M, Ktot, fast, splits, chunk, acc;
+};
+
+template <int BI, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(const WgradArgs p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BI / WM / 32, TN = BN / WN / 32;
+    constexpr int XST = BI + 4, YST = BN + 4;
+    constexpr int XV = 8 * BI / NT, YV = 8 * BN / NT;     // float4 loads per thread per step
+    __shared__ __attribute__((aligned(16))) float lds[32 * XST + 32 * YST];
+    float* Xs = lds;
+    float* Ys = lds + 32 * XST;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntiles = (p.Cout + BN - 1) / BN;
+    const int itiles = (p.Ktot + BI - 1) / BI;
+    int bid = blockIdx.x;
+    const int ntile = bid % ntiles; bid /= ntiles;
+    const int itile = bid % itiles;
+    const int split = bid / itiles;
+    const int i0 = itile * BI, n0 = ntile * BN;
+    const int m_begin = split * p.chunk;
+    const int m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
+    const int tap = i0 / p.Cin, ci0 = i0 - tap * p.Cin;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int ohw = p.OH * p.OW;
+
+    f32x4 rx[XV], ry[YV];
+    auto load_tiles = [&](int mb) {
+#pragma unroll
+        for (int v = 0; v < XV; ++v) {
+            const int idx = tid + v * NT;
+            const int row = idx / (BI / 4), c4 = idx % (BI / 4);
+            const int m = mb + row;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) {
+                const int n = m / ohw, rem = m - n * ohw;
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                if (p.fast) {
+                    const int ih = oh * p.stride - p.pad_t + kh, iw = ow * p.stride - p.pad_l + kw;
+                    if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                        val = *(const f32x4*)(p.x + (((long long)n * p.H + ih) * p.W + iw) * p.Cin + ci0 + c4 * 4);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = i0 + c4 * 4 + e;
+                        if (i < p.Ktot) {
+                            const int t2 = i / p.Cin, ci = i - t2 * p.Cin;
+                            const int k2 = t2 / p.KW, l2 = t2 - k2 * p.KW;
+                            const int ih = oh * p.stride - p.pad_t + k2, iw = ow * p.stride - p.pad_l + l2;
+                            if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+                                val[e] = p.x[(((long long)n * p.H + ih) * p.W + iw) * p.Cin + ci];
+                        }
+                    }
+                }
+            }
+            rx[v] = val;
+        }
+#pragma unroll
+        for (int v = 0; v < YV; ++v) {
+            const int idx = tid + v * NT;
+            const int row = idx / (BN / 4), c4 = idx % (BN / 4);
+            const int m = mb + row, n = n0 + c4 * 4;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) {
+                const float* ptr = p.dy + (long long)m * p.Cout + n;
+                if ((p.Cout & 3) == 0) {
+                    if (n < p.Cout) val = *(const f32x4*)ptr;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (n + e < p.Cout) val[e] = ptr[e];
+                }
+            }
+            ry[v] = val;
+        }
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int v = 0; v < XV; ++v) {
+            const int idx = tid + v * NT;
+            *(f32x4*)&Xs[(idx / (BI / 4)) * XST + (idx % (BI / 4)) * 4] = rx[v];
+        }
+#pragma unroll
+        for (int v = 0; v < YV; ++v) {
+            const int idx = tid + v * NT;
+            *(f32x4*)&Ys[(idx / (BN / 4)) * YST + (idx % (BN / 4)) * 4] = ry[v];
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    if (m_begin < m_end) {
+        load_tiles(m_begin);
+        store_tiles();
+        __syncthreads();
+        for (int mb = m_begin; mb < m_end; mb += 32) {
+            const bool more = mb + 32 < m_end;
+            if (more) load_tiles(mb + 32);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const int prow = lh * 16 + t;
+                float av[TM], bv[TN];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) av[a] = Xs[prow * XST + wm * TM * 32 + a * 32 + li];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bv[b] = Ys[prow * YST + wn * TN * 32 + b * 32 + li];
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) {
+                store_tiles();
+                __syncthreads();
+            }
+        }
+    }
+
+    float* dst = p.out + (p.splits > 1 ? (long long)split * p.Ktot * p.Cout : 0LL);
+    const bool accumulate = p.splits == 1 && p.acc;
+    auto store_tile = [&](const f32x16& c, int ibase, int n) {
+        if (n >= p.Cout) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = ibase + (r & 3) + 8 * (r >> 2);
+            if (i < p.Ktot) {
+                float* q = dst + (long long)i * p.Cout + n;
+                *q = accumulate ? *q + c[r] : c[r];
+            }
+        }
+    };
+    const int ib = i0 + wm * TM * 32 + 4 * lh, nb = n0 + wn * TN * 32 + li;
+    if constexpr (TM >= 1 && TN >= 1) store_tile(acc[0][0], ib, nb);
+    if constexpr (TM >= 1 && TN >= 2) store_tile(acc[0][1], ib, nb + 32);
+    if constexpr (TM >= 2 && TN >= 1) store_tile(acc[1][0], ib + 32, nb);
+    if constexpr (TM >= 2 && TN >= 2) store_tile(acc[1][1], ib + 32, nb + 32);
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* dw, long long n, int splits, int acc) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = acc ? dw[i] : 0.f;
+    for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
+    dw[i] = s;
+}
+
+struct WgradPlan { int bi, bn, splits, chunk, fast; };
+
+static WgradPlan plan_wgrad(const mrcnn_conv_desc* d) {
+    WgradPlan pl;
+    const long long M = (long long)d->N * d->OH * d->OW;
+    const int Ktot = d->KH * d->KW * d->Cin;
+    pl.fast = 1;
+    if (d->Cin % 128 == 0) pl.bi = 128;
+    else if (d->Cin % 64 == 0) pl.bi = 64;
+    else { pl.bi = 64; pl.fast = 0; }
+    pl.bn = d->Cout >= 128 ? 128 : (d->Cout >= 64 ? 64 : 32);
+    const long long tiles = (long long)((Ktot + pl.bi - 1) / pl.bi) * ((d->Cout + pl.bn - 1) / pl.bn);
+    long long splits = 1024 / (tiles > 0 ? tiles : 1);
+    const long long max_splits = (M + 255) / 256;       // at least 256 pixels (8 steps) per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 64) splits = 64;
+    long long chunk = ((M + splits - 1) / splits + 31) / 32 * 32;
+    splits = (M + chunk - 1) / chunk;
+    pl.splits = (int)splits;
+    pl.chunk = (int)chunk;
+    return pl;
+}
+
+extern "C" size_t mrcnn_conv2d_wgrad_workspace(const mrcnn_conv_desc* d) {
+    if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0) return 0;
+    WgradPlan pl = plan_wgrad(d);
+    if (pl.splits <= 1) return 0;
+    return (size_t)pl.splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
+}
+
+template <int BI, int BN, int WM, int WN>
+static void launch_wgrad(const WgradArgs& a, hipStream_t s) {
+    const int blocks = ((a.Ktot + BI - 1) / BI) * ((a.Cout + BN - 1) / BN) * a.splits;
+    hipLaunchKernelGGL((conv_wgrad_kernel<BI, BN, WM, WN>), dim3((unsigned)blocks), dim3(WM * WN * 64), 0, s, a);
+}
+
+extern "C" int mrcnn_conv2d_wgrad(const mrcnn_conv_desc* d, const float* x, const float* dy, float* dw,
+                                  float* workspace, size_t workspace_bytes, int beta_acc, void* stream) {
+    if (!d || !x || !dy || !dw) return MRCNN_ERR_ARG;
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 ||
+        d->stride <= 0 || d->OH <= 0 || d->OW <= 0)
+        return MRCNN_ERR_ARG;
+    const long long M = (long long)d->N * d->OH * d->OW;
+    if (M >= (1LL << 31)) return MRCNN_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(dy) & 15)) return MRCNN_ERR_ARG;
+    WgradPlan pl = plan_wgrad(d);
+    if (pl.splits > 1 && (!workspace || workspace_bytes < mrcnn_conv2d_wgrad_workspace(d))) return MRCNN_ERR_WORKSPACE;
+    WgradArgs a;
+    a.x = x; a.dy = dy; a.out = pl.splits > 1 ? workspace : dw;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
+    a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.OH = d->OH; a.OW = d->OW;
+    a.M = (int)M; a.Ktot = d->KH * d->KW * d->Cin; a.fast = pl.fast; a.splits = pl.splits; a.chunk = pl.chunk;
+    a.acc = beta_acc;
+    hipStream_t s = (hipStream_t)stream;
+    if (pl.bi == 128) {
+        if (pl.bn == 128) launch_wgrad<128, 128, 2, 2>(a, s);
+        else if (pl.bn == 64) launch_wgrad<128, 64, 2, 2>(a, s);
+        else launch_wgrad<128, 32, 4, 1>(a, s);
+    } else {
+        if (pl.bn == 128) launch_wgrad<64, 128, 2, 2>(a, s);
+        else if (pl.bn == 64) launch_wgrad<64, 64, 2, 2>(a, s);
+        else launch_wgrad<64, 32, 2, 1>(a, s);
+    }
+    if (pl.splits > 1) {
+        const long long n = (long long)a.Ktot * a.Cout;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, workspace, dw, n,
+                           pl.splits, beta_acc);
+    }
+    return mrcnn_launch_status();
+}
+
+// w_t[((KH-1-kh)*KW + (KW-1-kw))*Cout + co][ci] = w[((kh*KW + kw)*Cin + ci)][co]
+__global__ void flip_transpose_kernel(const float* __restrict__ w, float* wt, int KH, int KW, int Cin, int Cout) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int kh = tap / KW, kw = tap % KW;
+    const int tap_t = (KH - 1 - kh) * KW + (KW - 1 - kw);
+    const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;    // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        int ci = ci0 + r, co = co0 + tx;
+        tile[r][tx] = (ci < Cin && co < Cout) ? w[((long long)tap * Cin + ci) * Cout + co] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int co = co0 + r, ci = ci0 + tx;
+        if (co < Cout && ci < Cin) wt[((long long)tap_t * Cout + co) * Cin + ci] = tile[tx][r];
+    }
+}
+
+extern "C" int mrcnn_weight_flip_transpose(const float* w, float* w_t, int KH, int KW, int Cin, int Cout, void* stream) {
+    if (!w || !w_t || KH <= 0 || KW <= 0 || Cin <= 0 || Cout <= 0) return MRCNN_ERR_ARG;
+    dim3 grid((Cout + 31) / 32, (Cin + 31) / 32, KH * KW);
+    hipLaunchKernelGGL(flip_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, w_t, KH, KW, Cin, Cout);
+    return mrcnn_launch_status();
+}

@@ -1,0 +1,255 @@
+// HBM-bound glue kernels of the Mask R-CNN graph: frozen-BN folding, the backward of the conv
+// epilogue (BN affine + residual + activation), 3x3/s2 max pooling (TF SAME), P6 subsampling, the
+// adjoint of nearest 2x upsampling, row softmax.  Reference ops: mrcnn/model.py:57-72, 117-130, 187,
+// 2005-2022, 946, 1028.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------------------
+__global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ mean, const float* __restrict__ var, float eps,
+                               float* scale, float* shift, float* rstd, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 1.0f / sqrtf(var[i] + eps);
+    float s = gamma[i] * r;
+    scale[i] = s;
+    shift[i] = beta[i] - mean[i] * s;
+    if (rstd) rstd[i] = r;
+}
+
+extern "C" int mrcnn_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                             float eps, float* scale, float* shift, float* rstd, int64_t n, void* stream) {
+    if (!gamma || !beta || !mean || !var || !scale || !shift || n <= 0) return MRCNN_ERR_ARG;
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       gamma, beta, mean, var, eps, scale, shift, rstd, n);
+    return mrcnn_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Epilogue backward.  Each workgroup owns a contiguous range of rows of the dense [M, C] tensors and
+// walks it element by element (coalesced); per-channel sums go through LDS atomics, then one global
+// float atomic per channel per workgroup.
+__global__ __launch_bounds__(256) void epilogue_bwd_kernel(
+    const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ z,
+    const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ rstd,
+    float* dy_out, float* dz_out, float* dgamma, float* dbeta, float* dbias, int64_t M, int C, int act,
+    int64_t rows_per_block) {
+    extern __shared__ float sacc[];   // [3][C]
+    float* s_db = sacc;
+    float* s_dg = sacc + C;
+    float* s_dbias = sacc + 2 * C;
+    for (int c = threadIdx.x; c < 3 * C; c += 256) sacc[c] = 0.f;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    const int64_t e0 = r0 * C, e1 = r1 * C;
+    const bool need_stats = dgamma || dbeta;
+    for (int64_t e = e0 + threadIdx.x; e < e1; e += 256) {
+        const int c = (int)(e % C);
+        float g = dout[e];
+        if (act == MRCNN_ACT_RELU) g = out[e] > 0.f ? g : 0.f;
+        else if (act == MRCNN_ACT_SIGMOID) { float o = out[e]; g = g * o * (1.f - o); }
+        if (dy_out) dy_out[e] = g;
+        float dz = scale ? g * scale[c] : g;
+        if (dz_out) dz_out[e] = dz;
+        if (need_stats) {
+            atomicAdd(&s_db[c], g);
+            if (dgamma) atomicAdd(&s_dg[c], g * (z[e] - mean[c]) * rstd[c]);
+        }
+        if (dbias) atomicAdd(&s_dbias[c], dz);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        if (dbeta) atomicAdd(&dbeta[c], s_db[c]);
+        if (dgamma) atomicAdd(&dgamma[c], s_dg[c]);
+        if (dbias) atomicAdd(&dbias[c], s_dbias[c]);
+    }
+}
+
+extern "C" int mrcnn_epilogue_bwd(const float* dout, const float* out, const float* z, const float* scale,
+                                  const float* mean, const float* rstd, float* dy_out, float* dz_out,
+                                  float* dgamma, float* dbeta, float* dbias, int64_t M, int C, int act,
+                                  void* stream) {
+    if (!dout || M <= 0 || C <= 0 || C > 4096) return MRCNN_ERR_ARG;
+    if (act != MRCNN_ACT_NONE && !out) return MRCNN_ERR_ARG;
+    if (dgamma && (!z || !mean || !rstd)) return MRCNN_ERR_ARG;
+    int64_t rows_per_block = cdiv64(M, 2048);
+    // keep at least ~4K elements per workgroup so the per-channel atomics stay negligible
+    int64_t min_rows = cdiv64(4096, C);
+    if (rows_per_block < min_rows) rows_per_block = min_rows;
+    unsigned grid = (unsigned)cdiv64(M, rows_per_block);
+    hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(grid), dim3(256), 3 * C * sizeof(float), (hipStream_t)stream,
+                       dout, out, z, scale, mean, rstd, dy_out, dz_out, dgamma, dbeta, dbias, M, C, act,
+                       rows_per_block);
+    return mrcnn_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* out, int32_t* argmax, int N, int H,
+                                   int W, int C, int OH, int OW, int pad_t, int pad_l) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)N * OH * OW * C;
+    if (i >= total) return;
+    int c = (int)(i % C);
+    int64_t p = i / C;
+    int ow = (int)(p % OW); p /= OW;
+    int oh = (int)(p % OH);
+    int n = (int)(p / OH);
+    float best = -INFINITY;
+    int bi = -1;
+    for (int a = 0; a < 3; ++a) {
+        int ih = oh * 2 - pad_t + a;
+        if ((unsigned)ih >= (unsigned)H) continue;
+        for (int b = 0; b < 3; ++b) {
+            int iw = ow * 2 - pad_l + b;
+            if ((unsigned)iw >= (unsigned)W) continue;
+            float v = x[(((int64_t)n * H + ih) * W + iw) * C + c];
+            if (bi < 0 || v > best) { best = v; bi = ih * W + iw; }
+        }
+    }
+    out[i] = best;
+    if (argmax) argmax[i] = bi;
+}
+
+extern "C" int mrcnn_maxpool3x3s2_fwd(const float* x, float* out, int32_t* argmax, int N, int H, int W, int C,
+                                      int OH, int OW, int pad_t, int pad_l, void* stream) {
+    if (!x || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || OH <= 0 || OW <= 0) return MRCNN_ERR_ARG;
+    if ((OH - 1) * 2 - pad_t >= H || (OW - 1) * 2 - pad_l >= W) return MRCNN_ERR_ARG;
+    int64_t total = (int64_t)N * OH * OW * C;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, out, argmax, N, H, W, C, OH, OW, pad_t, pad_l);
+    return mrcnn_launch_status();
+}
+
+// gather form of the max-pool adjoint: every input pixel looks at the (at most 4) windows covering it
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dout, const int32_t* __restrict__ argmax,
+                                   float* dx, int N, int H, int W, int C, int OH, int OW, int pad_t, int pad_l) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)N * H * W * C;
+    if (i >= total) return;
+    int c = (int)(i % C);
+    int64_t p = i / C;
+    int iw = (int)(p % W); p /= W;
+    int ih = (int)(p % H);
+    int n = (int)(p / H);
+    const int me = ih * W + iw;
+    float acc = 0.f;
+    // windows with 2*oh - pad_t <= ih <= 2*oh - pad_t + 2
+    int oh_lo = (ih + pad_t - 2 + 1) >> 1; if (oh_lo < 0) oh_lo = 0;
+    int oh_hi = (ih + pad_t) >> 1; if (oh_hi > OH - 1) oh_hi = OH - 1;
+    int ow_lo = (iw + pad_l - 2 + 1) >> 1; if (ow_lo < 0) ow_lo = 0;
+    int ow_hi = (iw + pad_l) >> 1; if (ow_hi > OW - 1) ow_hi = OW - 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh)
+        for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+            int64_t o = (((int64_t)n * OH + oh) * OW + ow) * C + c;
+            if (argmax[o] == me) acc += dout[o];
+        }
+    dx[i] = acc;
+}
+
+extern "C" int mrcnn_maxpool3x3s2_bwd(const float* dout, const int32_t* argmax, float* dx, int N, int H, int W,
+                                      int C, int OH, int OW, void* stream) {
+    if (!dout || !argmax || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MRCNN_ERR_ARG;
+    // TF SAME for k=3, s=2: total pad = max((OH-1)*2 + 3 - H, 0), before = total/2
+    int tot_h = (OH - 1) * 2 + 3 - H; if (tot_h < 0) tot_h = 0;
+    int tot_w = (OW - 1) * 2 + 3 - W; if (tot_w < 0) tot_w = 0;
+    int64_t total = (int64_t)N * H * W * C;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dout, argmax, dx, N, H, W, C, OH, OW, tot_h / 2, tot_w / 2);
+    return mrcnn_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void subsample2_kernel(const float* __restrict__ x, float* out, float* dx_acc,
+                                  const float* __restrict__ dout, int N, int H, int W, int C) {
+    const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)N * OH * OW * C;
+    if (i >= total) return;
+    int c = (int)(i % C);
+    int64_t p = i / C;
+    int ow = (int)(p % OW); p /= OW;
+    int oh = (int)(p % OH);
+    int n = (int)(p / OH);
+    int64_t src = (((int64_t)n * H + 2 * oh) * W + 2 * ow) * C + c;
+    if (out) out[i] = x[src];
+    else dx_acc[src] += dout[i];
+}
+
+extern "C" int mrcnn_subsample2_fwd(const float* x, float* out, int N, int H, int W, int C, void* stream) {
+    if (!x || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MRCNN_ERR_ARG;
+    int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C;
+    hipLaunchKernelGGL(subsample2_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       x, out, (float*)nullptr, (const float*)nullptr, N, H, W, C);
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_subsample2_bwd_acc(const float* dout, float* dx, int N, int H, int W, int C, void* stream) {
+    if (!dout || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MRCNN_ERR_ARG;
+    int64_t total = (int64_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C;
+    hipLaunchKernelGGL(subsample2_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)nullptr, (float*)nullptr, dx, dout, N, H, W, C);
+    return mrcnn_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void upsample2_bwd_kernel(const float* __restrict__ dout, float* dsrc, int N, int H, int W, int C,
+                                     int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t total = (int64_t)N * H * W * C;
+    if (i >= total) return;
+    int c = (int)(i % C);
+    int64_t p = i / C;
+    int w = (int)(p % W); p /= W;
+    int h = (int)(p % H);
+    int n = (int)(p / H);
+    const int W2 = 2 * W;
+    int64_t b = (((int64_t)n * 2 * H + 2 * h) * W2 + 2 * w) * C + c;
+    float s = (dout[b] + dout[b + C]) + (dout[b + (int64_t)W2 * C] + dout[b + (int64_t)W2 * C + C]);
+    dsrc[i] = accumulate ? dsrc[i] + s : s;
+}
+
+extern "C" int mrcnn_upsample2_bwd(const float* dout, float* dsrc, int N, int H, int W, int C, int accumulate,
+                                   void* stream) {
+    if (!dout || !dsrc || N <= 0 || H <= 0 || W <= 0 || C <= 0) return MRCNN_ERR_ARG;
+    int64_t total = (int64_t)N * H * W * C;
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       dout, dsrc, N, H, W, C, accumulate);
+    return mrcnn_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ void add_inplace_kernel(float* dst, const float* __restrict__ src, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] += src[i];
+}
+
+extern "C" int mrcnn_add_inplace(float* dst, const float* src, int64_t n, void* stream) {
+    if (!dst || !src || n <= 0) return MRCNN_ERR_ARG;
+    int64_t blocks = cdiv64(n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dst, src, n);
+    return mrcnn_launch_status();
+}
+
+__global__ void softmax_rows_kernel(const float* __restrict__ logits, float* probs, int64_t rows, int C) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const float* l = logits + r * C;
+    float m = l[0];
+    for (int c = 1; c < C; ++c) m = fmaxf(m, l[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(l[c] - m);
+    for (int c = 0; c < C; ++c) probs[r * C + c] = expf(l[c] - m) / s;
+}
+
+extern "C" int mrcnn_softmax_rows(const float* logits, float* probs, int64_t rows, int C, void* stream) {
+    if (!logits || !probs || rows <= 0 || C <= 0) return MRCNN_ERR_ARG;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)cdiv64(rows, 256)), dim3(256), 0, (hipStream_t)stream,
+                       logits, probs, rows, C);
+    return mrcnn_launch_status();
+}
+
+extern "C" const char* mrcnn_hip_version(void) { return "mrcnn_hip 0.1 (gfx950)"; }

@@ -1,0 +1,255 @@
+// ProposalLayer (mrcnn/model.py:329-406): top-k by foreground score, box decode, clip, greedy NMS,
+// zero padding -- per image, index-exact.
+//
+//  K1 select_sort_decode (one 1024-thread workgroup per image)
+//       4-pass MSB-first radix select of the k-th largest score over the A anchors (LDS histograms),
+//       compaction of the k winners (ties at the threshold taken in ascending anchor index, which is
+//       tf.nn.top_k's order), bitonic sort of 64-bit (score desc, index asc) keys in LDS, then
+//       apply_box_deltas_graph + clip_boxes_graph on the sorted winners.
+//  K2 nms_mask: 64x64 tiles of the upper-triangular suppression bit matrix (IoU > threshold).
+//  K3 nms_scan (one wave per image): chunked greedy scan over the bit matrix, gather + zero pad.
+//
+// IoU follows TF's non_max_suppression kernel [3P]: corners canonicalised with min/max, 0 when an area
+// is <= 0, inter / (area_i + area_j - inter), suppress when IoU > threshold.  Compiled with
+// -ffp-contract=off so the float32 operation order is the reference's (no fused multiply-add).
+#include "common.h"
+
+#define SORT_CAP 8192           // bitonic capacity (pre_nms_limit <= SORT_CAP)
+#define K1_THREADS 1024
+
+__device__ __forceinline__ unsigned f2key(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // ascending unsigned == ascending float
+}
+
+struct PropArgs {
+    const float* probs; const float* deltas; const float* anchors;
+    float* rois; int32_t* top_idx; int32_t* keep_idx; int32_t* num_keep;
+    float* boxes_ws;               // [B, K, 4]
+    unsigned long long* mask_ws;   // [B, K, nwords]
+    int B, A, K, proposal_count, nwords;
+    float thr, s0, s1, s2, s3;
+};
+
+__global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const PropArgs p) {
+    __shared__ unsigned long long keys[SORT_CAP];
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_need, s_count, s_wsum[16], s_base;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* sc = p.probs + (int64_t)b * p.A * 2 + 1;     // foreground probability, stride 2
+    const int A = p.A, K = p.K;
+
+    // ---- radix select: largest K keys ------------------------------------------------------------
+    if (tid == 0) { s_prefix = 0; s_need = (unsigned)K; }
+    __syncthreads();
+    unsigned cnt_eq = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int a = tid; a < A; a += K1_THREADS) {
+            unsigned u = f2key(sc[(int64_t)a * 2]);
+            if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned need = s_need, cum = 0;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (cum + hist[d] >= need) break;
+                cum += hist[d];
+            }
+            s_prefix = prefix | ((unsigned)d << shift);
+            s_need = need - cum;
+            s_count = hist[d];
+        }
+        __syncthreads();
+        cnt_eq = s_count;
+    }
+    const unsigned T = s_prefix;       // k-th largest key
+    const unsigned need_eq = s_need;   // how many keys == T belong to the top K (>= 1)
+
+    // ---- compaction into keys[] --------------------------------------------------------------------
+    __syncthreads();                   // everyone has read s_count/s_prefix/s_need
+    for (int i = tid; i < SORT_CAP; i += K1_THREADS) keys[i] = ~0ull;
+    if (tid == 0) { s_count = 0; s_base = 0; }
+    __syncthreads();
+    const bool ordered = cnt_eq > need_eq;      // more ties than slots: lowest anchor index first
+    for (int a0 = 0; a0 < A; a0 += K1_THREADS) {
+        const int a = a0 + tid;
+        unsigned u = 0;
+        bool gt = false, eq = false;
+        if (a < A) {
+            u = f2key(sc[(int64_t)a * 2]);
+            gt = u > T;
+            eq = u == T;
+        }
+        if (gt || (eq && !ordered)) {
+            unsigned slot = atomicAdd(&s_count, 1u);
+            keys[slot] = ((unsigned long long)(~u) << 32) | (unsigned)a;
+        }
+        if (ordered) {
+            // block-wide exclusive rank of `eq` in index order
+            unsigned long long bal = __ballot(eq);
+            unsigned wrank = __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+            if ((tid & 63) == 0) s_wsum[tid >> 6] = (unsigned)__popcll(bal);
+            __syncthreads();
+            unsigned before = s_base;
+            for (int w = 0; w < (tid >> 6); ++w) before += s_wsum[w];
+            if (eq && before + wrank < need_eq) {
+                unsigned slot = atomicAdd(&s_count, 1u);
+                keys[slot] = ((unsigned long long)(~u) << 32) | (unsigned)a;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned tot = 0;
+                for (int w = 0; w < K1_THREADS / 64; ++w) tot += s_wsum[w];
+                s_base += tot;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+
+    // ---- bitonic sort (ascending 64-bit keys == score descending, index ascending) ----------------
+    int n = 1;
+    while (n < K) n <<= 1;
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (n >> 1); t += K1_THREADS) {
+                int lo = ((t / stride) * stride * 2) + (t % stride);
+                int hi = lo + stride;
+                bool up = ((lo & size) == 0);
+                unsigned long long x = keys[lo], y = keys[hi];
+                if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+
+    // ---- decode + clip (apply_box_deltas_graph, clip_boxes_graph with window [0,0,1,1]) ------------
+    for (int i = tid; i < K; i += K1_THREADS) {
+        const unsigned a = (unsigned)(keys[i] & 0xFFFFFFFFull);
+        if (p.top_idx) p.top_idx[(int64_t)b * K + i] = (int)a;
+        const float* an = p.anchors + (int64_t)a * 4;
+        const float* dl = p.deltas + ((int64_t)b * A + a) * 4;
+        float d0 = dl[0] * p.s0, d1 = dl[1] * p.s1, d2 = dl[2] * p.s2, d3 = dl[3] * p.s3;
+        decode_clip_box(an, d0, d1, d2, d3, 0.f, 0.f, 1.f, 1.f, p.boxes_ws + ((int64_t)b * K + i) * 4);
+    }
+}
+
+// grid (nwords, nwords, B); workgroup = 64 threads: row i = 64*blockIdx.y + lane against 64 columns
+__global__ __launch_bounds__(64) void nms_mask_kernel(const PropArgs p) {
+    const int b = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x, lane = threadIdx.x;
+    const int K = p.K;
+    const int i = rb * 64 + lane;
+    unsigned long long* mrow = p.mask_ws + ((int64_t)b * K + i) * p.nwords + cb;
+    if (cb < rb) {                       // strictly lower blocks are never read
+        if (i < K) *mrow = 0ull;
+        return;
+    }
+    __shared__ float cbox[64 * 4];
+    const float* boxes = p.boxes_ws + (int64_t)b * K * 4;
+    const int j0 = cb * 64;
+    if (j0 + lane < K) {
+        const float* s = boxes + (int64_t)(j0 + lane) * 4;
+        cbox[lane * 4 + 0] = s[0]; cbox[lane * 4 + 1] = s[1]; cbox[lane * 4 + 2] = s[2]; cbox[lane * 4 + 3] = s[3];
+    }
+    __syncthreads();
+    if (i >= K) return;
+    float me[4] = {boxes[(int64_t)i * 4], boxes[(int64_t)i * 4 + 1], boxes[(int64_t)i * 4 + 2], boxes[(int64_t)i * 4 + 3]};
+    unsigned long long bits = 0ull;
+    const int jn = (K - j0) < 64 ? (K - j0) : 64;
+    for (int j = 0; j < jn; ++j) {
+        if (j0 + j > i && iou_gt(me, &cbox[j * 4], p.thr)) bits |= 1ull << j;
+    }
+    *mrow = bits;
+}
+
+// one wave per image
+__global__ __launch_bounds__(64) void nms_scan_kernel(const PropArgs p) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int K = p.K, nw = p.nwords, maxk = p.proposal_count;
+    const unsigned long long* mask = p.mask_ws + (int64_t)b * K * nw;
+    const float* boxes = p.boxes_ws + (int64_t)b * K * 4;
+    __shared__ int keep[SORT_CAP];
+    unsigned long long rem0 = 0ull, rem1 = 0ull;     // removed bits: words lane and lane+64
+    int total = 0;
+    for (int c = 0; c < nw && total < maxk; ++c) {
+        const int i = c * 64 + lane;
+        unsigned long long diag = (i < K) ? mask[(int64_t)i * nw + c] : 0ull;
+        unsigned long long remc = shfl64(c < 64 ? rem0 : rem1, c & 63);
+        const int valid_n = (K - c * 64) < 64 ? (K - c * 64) : 64;
+        unsigned long long alive = ~remc;
+        if (valid_n < 64) alive &= (1ull << valid_n) - 1ull;
+        unsigned long long kept = 0ull;
+        for (int t = 0; t < 64; ++t) {
+            unsigned long long d = shfl64(diag, t);
+            if (((alive >> t) & 1ull) && total < maxk) {
+                kept |= 1ull << t;
+                ++total;
+                alive &= ~d;
+            }
+        }
+        // record kept boxes of this chunk
+        if ((kept >> lane) & 1ull) {
+            int pos = total - __popcll(kept) + __popcll(kept & ((1ull << lane) - 1ull));
+            keep[pos] = i;
+        }
+        // OR the rows of the kept boxes into the removed bitmap (only words > c matter)
+        unsigned long long k2 = kept;
+        while (k2) {
+            int t = __ffsll((long long)k2) - 1;
+            k2 &= k2 - 1ull;
+            const unsigned long long* row = mask + (int64_t)(c * 64 + t) * nw;
+            if (lane > c && lane < nw) rem0 |= row[lane];
+            if (lane + 64 > c && lane + 64 < nw) rem1 |= row[lane + 64];
+        }
+    }
+    __syncthreads();
+    if (p.num_keep && lane == 0) p.num_keep[b] = total;
+    for (int q = lane; q < maxk; q += 64) {
+        float* o = p.rois + ((int64_t)b * maxk + q) * 4;
+        if (q < total) {
+            const float* s = boxes + (int64_t)keep[q] * 4;
+            o[0] = s[0]; o[1] = s[1]; o[2] = s[2]; o[3] = s[3];
+            if (p.keep_idx) p.keep_idx[(int64_t)b * maxk + q] = keep[q];
+        } else {
+            o[0] = 0.f; o[1] = 0.f; o[2] = 0.f; o[3] = 0.f;
+            if (p.keep_idx) p.keep_idx[(int64_t)b * maxk + q] = -1;
+        }
+    }
+}
+
+static inline int prop_k(const mrcnn_proposal_desc* d) { return d->pre_nms_limit < d->A ? d->pre_nms_limit : d->A; }
+
+extern "C" size_t mrcnn_proposal_workspace(const mrcnn_proposal_desc* d) {
+    if (!d || d->B <= 0 || d->A <= 0) return 0;
+    size_t K = (size_t)prop_k(d), nw = (K + 63) / 64;
+    return (size_t)d->B * (K * 4 * sizeof(float) + K * nw * sizeof(unsigned long long)) + 256;
+}
+
+extern "C" int mrcnn_proposal_fwd(const mrcnn_proposal_desc* d, const float* rpn_probs, const float* rpn_bbox,
+                                  const float* anchors, float* rois, int32_t* top_idx, int32_t* keep_idx,
+                                  int32_t* num_keep, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!d || !rpn_probs || !rpn_bbox || !anchors || !rois || !workspace) return MRCNN_ERR_ARG;
+    if (d->B <= 0 || d->A <= 0 || d->pre_nms_limit <= 0 || d->proposal_count <= 0) return MRCNN_ERR_ARG;
+    const int K = prop_k(d);
+    if (K > SORT_CAP || d->proposal_count > SORT_CAP) return MRCNN_ERR_ARG;
+    if (workspace_bytes < mrcnn_proposal_workspace(d)) return MRCNN_ERR_WORKSPACE;
+    PropArgs a;
+    a.probs = rpn_probs; a.deltas = rpn_bbox; a.anchors = anchors; a.rois = rois; a.top_idx = top_idx;
+    a.keep_idx = keep_idx; a.num_keep = num_keep;
+    a.B = d->B; a.A = d->A; a.K = K; a.proposal_count = d->proposal_count; a.nwords = (K + 63) / 64;
+    a.thr = d->nms_threshold; a.s0 = d->std_dev[0]; a.s1 = d->std_dev[1]; a.s2 = d->std_dev[2]; a.s3 = d->std_dev[3];
+    uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
+    a.boxes_ws = reinterpret_cast<float*>(base);
+    a.mask_ws = reinterpret_cast<unsigned long long*>(base + (size_t)d->B * K * 4 * sizeof(float));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(select_sort_decode_kernel, dim3(d->B), dim3(K1_THREADS), 0, s, a);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(a.nwords, a.nwords, d->B), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(d->B), dim3(64), 0, s, a);
+    return mrcnn_launch_status();
+}

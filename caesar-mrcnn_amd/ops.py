@@ -1,0 +1,349 @@
+"""Thin host-side operator layer over the C-ABI (one function per kernel group).
+
+Every function takes/returns torch CUDA tensors that only serve as device-memory handles; the
+arithmetic happens in libmrcnn_hip.so.  Shapes follow the reference graph (NHWC float32).
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _hip
+from ._hip import (ACT_NONE, ACT_RELU, ACT_SIGMOID, OUT_DECONV2, OUT_NHWC, RES_NONE, RES_SAME, RES_UP2,
+                   check, current_stream, ptr)
+
+BN_EPS = 1e-3  # Keras BatchNormalization default epsilon [3P]
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _hip.HipPathError("hot-path operators need device tensors (got a CPU tensor)")
+        if t is not None and not t.is_contiguous():
+            raise _hip.HipPathError("hot-path operators need contiguous tensors")
+
+
+def same_padding(size, k, stride):
+    """TF 'SAME': out = ceil(size/stride); pad_before = total//2 (asymmetric when total is odd)."""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k - size, 0)
+    return out, total // 2
+
+
+def conv_desc(x_shape, w_shape, stride=1, padding="same", act=ACT_NONE, res_mode=RES_NONE):
+    N, H, W, Cin = x_shape
+    KH, KW, wcin, Cout = w_shape
+    assert wcin == Cin, (x_shape, w_shape)
+    d = _hip.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride = N, H, W, Cin, Cout, KH, KW, stride
+    if padding == "same":
+        d.OH, d.pad_t = same_padding(H, KH, stride)
+        d.OW, d.pad_l = same_padding(W, KW, stride)
+    elif padding == "valid":
+        d.OH, d.OW = (H - KH) // stride + 1, (W - KW) // stride + 1
+        d.pad_t = d.pad_l = 0
+    else:  # explicit symmetric zero padding (ZeroPadding2D + valid conv)
+        ph, pw = padding
+        d.OH, d.OW = (H + 2 * ph - KH) // stride + 1, (W + 2 * pw - KW) // stride + 1
+        d.pad_t, d.pad_l = ph, pw
+    d.act, d.res_mode, d.out_mode, d.cmod = act, res_mode, OUT_NHWC, Cout
+    d.out_w_stride = Cout
+    d.out_h_stride = d.OW * Cout
+    d.out_n_stride = d.OH * d.OW * Cout
+    return d
+
+
+def conv2d(x, w, bias=None, scale=None, shift=None, res=None, stride=1, padding="same", act=ACT_NONE,
+           res_mode=RES_NONE, out=None, z_out=None, desc=None):
+    """out = act(bn(conv(x, w) + bias) + res).  w is HWIO.  Returns out [N, OH, OW, Cout]."""
+    _need_cuda(x, w, bias, scale, shift, res, out, z_out)
+    d = desc or conv_desc(tuple(x.shape), tuple(w.shape), stride, padding, act, res_mode)
+    if out is None:
+        out = torch.empty((d.N, d.OH, d.OW, d.Cout), dtype=torch.float32, device=x.device)
+    check(_hip.lib().mrcnn_conv2d_fwd(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(scale), ptr(shift), ptr(res),
+                                      ptr(out), ptr(z_out), current_stream()), "mrcnn_conv2d_fwd")
+    return out
+
+
+def conv2d_into(x, w, bias, out_view_ptr, n_stride, h_stride, w_stride, stride=1, padding="same", act=ACT_NONE):
+    """Conv whose output rows land inside a larger buffer (e.g. one pyramid level of the concatenated
+    RPN outputs).  out_view_ptr is the device address of element (0,0,0,0)."""
+    _need_cuda(x, w, bias)
+    d = conv_desc(tuple(x.shape), tuple(w.shape), stride, padding, act)
+    d.out_n_stride, d.out_h_stride, d.out_w_stride = n_stride, h_stride, w_stride
+    check(_hip.lib().mrcnn_conv2d_fwd(C.byref(d), ptr(x), ptr(w), ptr(bias), None, None, None, out_view_ptr, None,
+                                      current_stream()), "mrcnn_conv2d_fwd(into)")
+
+
+def deconv2x2(x, w_gemm, bias, act=ACT_RELU, out=None):
+    """Conv2DTranspose(2x2, stride 2): x [N,H,W,Cin], w_gemm [Cin, 4*Cd] with column (a*2+b)*Cd+co."""
+    _need_cuda(x, w_gemm, bias, out)
+    N, H, W, Cin = x.shape
+    Cd = w_gemm.shape[1] // 4
+    d = _hip.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad_t, d.pad_l = N, H, W, Cin, 4 * Cd, 1, 1, 1, 0, 0
+    d.OH, d.OW, d.act, d.res_mode, d.out_mode, d.cmod = H, W, act, RES_NONE, OUT_DECONV2, Cd
+    d.out_w_stride = Cd
+    d.out_h_stride = 2 * W * Cd
+    d.out_n_stride = 4 * H * W * Cd
+    if out is None:
+        out = torch.empty((N, 2 * H, 2 * W, Cd), dtype=torch.float32, device=x.device)
+    check(_hip.lib().mrcnn_conv2d_fwd(C.byref(d), ptr(x), ptr(w_gemm), ptr(bias), None, None, None, ptr(out), None,
+                                      current_stream()), "mrcnn_conv2d_fwd(deconv)")
+    return out
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """Grow-only scratch buffer per (device, tag) -- nothing is allocated inside the C-ABI calls."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def conv2d_wgrad(x, dy, w_shape, stride=1, padding="same", dw=None, accumulate=False, desc=None):
+    _need_cuda(x, dy, dw)
+    d = desc or conv_desc(tuple(x.shape), tuple(w_shape), stride, padding)
+    if dw is None:
+        dw = torch.empty(tuple(w_shape), dtype=torch.float32, device=x.device)
+    nbytes = _hip.lib().mrcnn_conv2d_wgrad_workspace(C.byref(d))
+    ws = workspace(nbytes, x.device, "wgrad")
+    check(_hip.lib().mrcnn_conv2d_wgrad(C.byref(d), ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(),
+                                        1 if accumulate else 0, current_stream()), "mrcnn_conv2d_wgrad")
+    return dw
+
+
+def weight_flip_transpose(w, out=None):
+    _need_cuda(w, out)
+    KH, KW, Cin, Cout = w.shape
+    if out is None:
+        out = torch.empty((KH, KW, Cout, Cin), dtype=torch.float32, device=w.device)
+    check(_hip.lib().mrcnn_weight_flip_transpose(ptr(w), ptr(out), KH, KW, Cin, Cout, current_stream()),
+          "mrcnn_weight_flip_transpose")
+    return out
+
+
+def bn_fold(gamma, beta, mean, var, scale, shift, rstd=None, eps=BN_EPS):
+    _need_cuda(gamma, beta, mean, var, scale, shift, rstd)
+    check(_hip.lib().mrcnn_bn_fold(ptr(gamma), ptr(beta), ptr(mean), ptr(var), eps, ptr(scale), ptr(shift),
+                                   ptr(rstd), gamma.numel(), current_stream()), "mrcnn_bn_fold")
+
+
+def epilogue_bwd(dout, out=None, z=None, scale=None, mean=None, rstd=None, dy_out=None, dz_out=None,
+                 dgamma=None, dbeta=None, dbias=None, act=ACT_NONE):
+    _need_cuda(dout, out, z, scale, mean, rstd, dy_out, dz_out, dgamma, dbeta, dbias)
+    C_ = dout.shape[-1]
+    M = dout.numel() // C_
+    check(_hip.lib().mrcnn_epilogue_bwd(ptr(dout), ptr(out), ptr(z), ptr(scale), ptr(mean), ptr(rstd), ptr(dy_out),
+                                        ptr(dz_out), ptr(dgamma), ptr(dbeta), ptr(dbias), M, C_, act,
+                                        current_stream()), "mrcnn_epilogue_bwd")
+
+
+def maxpool3x3s2(x, want_argmax=False):
+    _need_cuda(x)
+    N, H, W, C_ = x.shape
+    OH, pt = same_padding(H, 3, 2)
+    OW, pl = same_padding(W, 3, 2)
+    out = torch.empty((N, OH, OW, C_), dtype=torch.float32, device=x.device)
+    am = torch.empty((N, OH, OW, C_), dtype=torch.int32, device=x.device) if want_argmax else None
+    check(_hip.lib().mrcnn_maxpool3x3s2_fwd(ptr(x), ptr(out), ptr(am), N, H, W, C_, OH, OW, pt, pl,
+                                            current_stream()), "mrcnn_maxpool3x3s2_fwd")
+    return (out, am) if want_argmax else out
+
+
+def maxpool3x3s2_bwd(dout, argmax, in_shape):
+    _need_cuda(dout, argmax)
+    N, H, W, C_ = in_shape
+    dx = torch.empty(in_shape, dtype=torch.float32, device=dout.device)
+    check(_hip.lib().mrcnn_maxpool3x3s2_bwd(ptr(dout), ptr(argmax), ptr(dx), N, H, W, C_, dout.shape[1],
+                                            dout.shape[2], current_stream()), "mrcnn_maxpool3x3s2_bwd")
+    return dx
+
+
+def subsample2(x):
+    _need_cuda(x)
+    N, H, W, C_ = x.shape
+    out = torch.empty((N, (H + 1) // 2, (W + 1) // 2, C_), dtype=torch.float32, device=x.device)
+    check(_hip.lib().mrcnn_subsample2_fwd(ptr(x), ptr(out), N, H, W, C_, current_stream()), "mrcnn_subsample2_fwd")
+    return out
+
+
+def subsample2_bwd_acc(dout, dx):
+    _need_cuda(dout, dx)
+    N, H, W, C_ = dx.shape
+    check(_hip.lib().mrcnn_subsample2_bwd_acc(ptr(dout), ptr(dx), N, H, W, C_, current_stream()),
+          "mrcnn_subsample2_bwd_acc")
+
+
+def upsample2_bwd(dout, dsrc, accumulate):
+    _need_cuda(dout, dsrc)
+    N, H, W, C_ = dsrc.shape
+    check(_hip.lib().mrcnn_upsample2_bwd(ptr(dout), ptr(dsrc), N, H, W, C_, 1 if accumulate else 0,
+                                         current_stream()), "mrcnn_upsample2_bwd")
+
+
+def add_inplace(dst, src):
+    _need_cuda(dst, src)
+    assert dst.numel() == src.numel()
+    check(_hip.lib().mrcnn_add_inplace(ptr(dst), ptr(src), dst.numel(), current_stream()), "mrcnn_add_inplace")
+
+
+def softmax_rows(logits, out=None):
+    _need_cuda(logits, out)
+    C_ = logits.shape[-1]
+    if out is None:
+        out = torch.empty_like(logits)
+    check(_hip.lib().mrcnn_softmax_rows(ptr(logits), ptr(out), logits.numel() // C_, C_, current_stream()),
+          "mrcnn_softmax_rows")
+    return out
+
+
+def _roi_desc(boxes, fms, pool, image_area):
+    d = _hip.RoiAlignDesc()
+    d.B, d.R, d.P, d.C = boxes.shape[0], boxes.shape[1], pool, fms[0].shape[3]
+    for i, f in enumerate(fms):
+        d.H[i], d.W[i] = f.shape[1], f.shape[2]
+    d.image_area = float(image_area)
+    return d
+
+
+def roialign(boxes, fms, pool, image_area, want_levels=False):
+    """PyramidROIAlign: boxes [B,R,4], fms = [P2,P3,P4,P5] -> [B,R,pool,pool,C]."""
+    _need_cuda(boxes, *fms)
+    d = _roi_desc(boxes, fms, pool, image_area)
+    out = torch.empty((d.B, d.R, pool, pool, d.C), dtype=torch.float32, device=boxes.device)
+    lv = torch.empty((d.B, d.R), dtype=torch.int32, device=boxes.device) if want_levels else None
+    check(_hip.lib().mrcnn_roialign_fwd(C.byref(d), ptr(boxes), ptr(fms[0]), ptr(fms[1]), ptr(fms[2]), ptr(fms[3]),
+                                        ptr(out), ptr(lv), current_stream()), "mrcnn_roialign_fwd")
+    return (out, lv) if want_levels else out
+
+
+def roialign_bwd(boxes, dout, dfms, pool, image_area):
+    """Scatter-add dout [B,R,pool,pool,C] into the (already initialised) gradient maps dfms."""
+    _need_cuda(boxes, dout, *dfms)
+    d = _roi_desc(boxes, dfms, pool, image_area)
+    check(_hip.lib().mrcnn_roialign_bwd(C.byref(d), ptr(boxes), ptr(dout), ptr(dfms[0]), ptr(dfms[1]), ptr(dfms[2]),
+                                        ptr(dfms[3]), current_stream()), "mrcnn_roialign_bwd")
+
+
+def proposals(rpn_probs, rpn_bbox, anchors, pre_nms_limit, proposal_count, nms_threshold, std_dev, debug=False):
+    """ProposalLayer. rpn_probs [B,A,2], rpn_bbox [B,A,4], anchors [A,4] (normalised) -> rois [B,count,4]."""
+    _need_cuda(rpn_probs, rpn_bbox, anchors)
+    B, A = rpn_probs.shape[0], rpn_probs.shape[1]
+    d = _hip.ProposalDesc()
+    d.B, d.A, d.pre_nms_limit, d.proposal_count, d.nms_threshold = B, A, pre_nms_limit, proposal_count, nms_threshold
+    for i in range(4):
+        d.std_dev[i] = float(std_dev[i])
+    K = min(pre_nms_limit, A)
+    rois = torch.empty((B, proposal_count, 4), dtype=torch.float32, device=rpn_probs.device)
+    top_idx = keep_idx = num_keep = None
+    if debug:
+        top_idx = torch.empty((B, K), dtype=torch.int32, device=rois.device)
+        keep_idx = torch.empty((B, proposal_count), dtype=torch.int32, device=rois.device)
+        num_keep = torch.empty((B,), dtype=torch.int32, device=rois.device)
+    nbytes = _hip.lib().mrcnn_proposal_workspace(C.byref(d))
+    ws = workspace(nbytes, rois.device, "proposal")
+    check(_hip.lib().mrcnn_proposal_fwd(C.byref(d), ptr(rpn_probs), ptr(rpn_bbox), ptr(anchors), ptr(rois),
+                                        ptr(top_idx), ptr(keep_idx), ptr(num_keep), ptr(ws), ws.numel(),
+                                        current_stream()), "mrcnn_proposal_fwd")
+    if debug:
+        # sorted, decoded, clipped boxes live at the head of the workspace: [B, K, 4]
+        base = (ws.data_ptr() + 255) // 256 * 256 - ws.data_ptr()
+        boxes = ws[base: base + B * K * 16].view(torch.float32).view(B, K, 4).clone()
+        return rois, top_idx, keep_idx, num_keep, boxes
+    return rois
+
+
+def detection_targets(proposals_, gt_class_ids, gt_boxes, gt_masks, rand_keys, train_rois, positive_ratio,
+                      bbox_std_dev, mask_shape, use_mini_mask=False):
+    _need_cuda(proposals_, gt_class_ids, gt_boxes, gt_masks, rand_keys)
+    B, R = proposals_.shape[0], proposals_.shape[1]
+    G = gt_boxes.shape[1]
+    d = _hip.DetTargetDesc()
+    d.B, d.R, d.G, d.T = B, R, G, train_rois
+    d.MH, d.MW = gt_masks.shape[1], gt_masks.shape[2]
+    d.mask_h, d.mask_w = mask_shape
+    d.positive_count = int(train_rois * positive_ratio)
+    import numpy as np
+    d.negative_ratio_r = float(np.float32(1.0 / positive_ratio))
+    for i in range(4):
+        d.bbox_std_dev[i] = float(np.float32(bbox_std_dev[i]))
+    d.use_mini_mask = 1 if use_mini_mask else 0
+    dev = proposals_.device
+    rois = torch.empty((B, train_rois, 4), dtype=torch.float32, device=dev)
+    tcls = torch.empty((B, train_rois), dtype=torch.int32, device=dev)
+    tbbox = torch.empty((B, train_rois, 4), dtype=torch.float32, device=dev)
+    tmask = torch.empty((B, train_rois, mask_shape[0], mask_shape[1]), dtype=torch.float32, device=dev)
+    assign = torch.empty((B, train_rois), dtype=torch.int32, device=dev)
+    counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+    check(_hip.lib().mrcnn_detection_targets(C.byref(d), ptr(proposals_), ptr(gt_class_ids), ptr(gt_boxes),
+                                             ptr(gt_masks), ptr(rand_keys), ptr(rois), ptr(tcls), ptr(tbbox),
+                                             ptr(tmask), ptr(assign), ptr(counts), current_stream()),
+          "mrcnn_detection_targets")
+    return rois, tcls, tbbox, tmask, assign, counts
+
+
+def detections(rois, probs, deltas, windows, max_instances, min_confidence, nms_threshold, bbox_std_dev):
+    _need_cuda(rois, probs, deltas, windows)
+    B, R, C_ = probs.shape
+    d = _hip.DetectionDesc()
+    d.B, d.R, d.C, d.max_instances = B, R, C_, max_instances
+    d.min_confidence, d.nms_threshold = float(min_confidence), float(nms_threshold)
+    for i in range(4):
+        d.bbox_std_dev[i] = float(bbox_std_dev[i])
+    out = torch.empty((B, max_instances, 6), dtype=torch.float32, device=rois.device)
+    nbytes = _hip.lib().mrcnn_detection_workspace(C.byref(d))
+    ws = workspace(nbytes, rois.device, "detection")
+    check(_hip.lib().mrcnn_detection_fwd(C.byref(d), ptr(rois), ptr(probs), ptr(deltas), ptr(windows), ptr(out),
+                                         ptr(ws), ws.numel(), current_stream()), "mrcnn_detection_fwd")
+    return out
+
+
+def losses_fwd_bwd(rpn_match, rpn_bbox_t, rpn_logits, rpn_bbox, tcls, tbbox, tmask, active_class_ids, cls_logits,
+                   mbbox, mmask, weights, dice=False):
+    """Returns (losses[5], d_rpn_logits, d_rpn_bbox, d_cls_logits, d_mbbox, d_mmask)."""
+    _need_cuda(rpn_match, rpn_bbox_t, rpn_logits, rpn_bbox, tcls, tbbox, tmask, active_class_ids, cls_logits, mbbox,
+               mmask)
+    d = _hip.LossDesc()
+    d.B, d.A = rpn_logits.shape[0], rpn_logits.shape[1]
+    d.T, d.C = cls_logits.shape[1], cls_logits.shape[2]
+    d.mask_h, d.mask_w = tmask.shape[2], tmask.shape[3]
+    d.max_rpn_pos = rpn_bbox_t.shape[1]
+    d.mask_loss_dice = 1 if dice else 0
+    for i in range(5):
+        d.w[i] = float(weights[i])
+    dev = rpn_logits.device
+    losses = torch.empty((5,), dtype=torch.float32, device=dev)
+    g = [torch.empty_like(t) for t in (rpn_logits, rpn_bbox, cls_logits, mbbox, mmask)]
+    nbytes = _hip.lib().mrcnn_losses_workspace(C.byref(d))
+    ws = workspace(nbytes, dev, "losses")
+    check(_hip.lib().mrcnn_losses_fwd_bwd(C.byref(d), ptr(rpn_match), ptr(rpn_bbox_t), ptr(rpn_logits), ptr(rpn_bbox),
+                                          ptr(tcls), ptr(tbbox), ptr(tmask), ptr(active_class_ids), ptr(cls_logits),
+                                          ptr(mbbox), ptr(mmask), ptr(losses), ptr(g[0]), ptr(g[1]), ptr(g[2]),
+                                          ptr(g[3]), ptr(g[4]), ptr(ws), ws.numel(), current_stream()),
+          "mrcnn_losses_fwd_bwd")
+    return (losses,) + tuple(g)
+
+
+def grad_prepare(grads, params, grad_scale, trainable, seg_offset, seg_numel, seg_l2):
+    _need_cuda(grads, params, trainable, seg_offset, seg_numel, seg_l2)
+    check(_hip.lib().mrcnn_grad_prepare(ptr(grads), ptr(params), float(grad_scale), ptr(trainable), ptr(seg_offset),
+                                        ptr(seg_numel), ptr(seg_l2), seg_offset.numel(), grads.numel(),
+                                        current_stream()), "mrcnn_grad_prepare")
+
+
+def sumsq(g, out):
+    _need_cuda(g, out)
+    check(_hip.lib().mrcnn_sumsq(ptr(g), g.numel(), ptr(out), current_stream()), "mrcnn_sumsq")
+
+
+def sgd_momentum(params, mom, grads, sumsq_t, clipnorm, lr, momentum, trainable, seg_offset, seg_numel):
+    _need_cuda(params, mom, grads, sumsq_t, trainable, seg_offset, seg_numel)
+    check(_hip.lib().mrcnn_sgd_momentum(ptr(params), ptr(mom), ptr(grads), ptr(sumsq_t), float(clipnorm), float(lr),
+                                        float(momentum), 1.0, ptr(trainable), ptr(seg_offset), ptr(seg_numel),
+                                        seg_offset.numel(), params.numel(), current_stream()), "mrcnn_sgd_momentum")

@@ -1,0 +1,204 @@
+/*
+ * mrcnn_hip.h -- C-ABI of the MI355X (gfx950) Mask R-CNN hot path.
+ *
+ * The reference (SKA-INAF/caesar-mrcnn) has no FFI: its hot path is the Keras/TF1 graph wired by
+ * MaskRCNN.build (mrcnn/model.py:1935-2166).  Each entry point below replaces one group of TF/Keras ops
+ * of that graph; the reference call site it stands in for is cited next to it.  All pointers are DEVICE
+ * pointers (allocated by the caller, e.g. PyTorch-ROCm), all tensors are float32 NHWC unless stated,
+ * `stream` is a hipStream_t passed as void*, and every function returns 0 on success or a negative
+ * status (mirroring the reference's 0 / -1 convention, scripts/run.py:1747-1757).  No function
+ * allocates, frees or synchronises; all are re-entrant per stream.
+ */
+#ifndef MRCNN_HIP_H
+#define MRCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRCNN_OK 0
+#define MRCNN_ERR_ARG (-1)
+#define MRCNN_ERR_LAUNCH (-2)
+#define MRCNN_ERR_WORKSPACE (-3)
+
+#define MRCNN_ACT_NONE 0
+#define MRCNN_ACT_RELU 1
+#define MRCNN_ACT_SIGMOID 2
+
+#define MRCNN_RES_NONE 0
+#define MRCNN_RES_SAME 1     /* res has the shape/strides of out                            */
+#define MRCNN_RES_UP2 2      /* res is [N, OH/2, OW/2, Cout]; nearest 2x upsample then add   */
+
+#define MRCNN_OUT_NHWC 0     /* out[n*out_n_stride + oh*out_h_stride + ow*out_w_stride + co] */
+#define MRCNN_OUT_DECONV2 1  /* GEMM column = (a*2+b)*cmod + co -> pixel (2oh+a, 2ow+b), channel co */
+
+/* Convolution as implicit GEMM: M = N*OH*OW pixels, N = Cout, K = KH*KW*Cin.
+ * Replaces KL.Conv2D / TimeDistributed(Conv2D) / Dense / Conv2DTranspose(2x2,s2) with the following
+ * BatchNorm(training=False) + Add + Activation folded into the epilogue
+ * (mrcnn/model.py:99-210, 916-957, 986-1091, 2005-2022).
+ * Weights are HWIO ([KH,KW,Cin,Cout] row-major == the GEMM B matrix [K, Cout]), i.e. the Keras layout.
+ * Epilogue:  z = acc + bias[c];  (z_out gets z);  y = scale ? scale[c]*z + shift[c] : z;
+ *            y += res (res_mode);  y = act(y);  out gets y.        c = column % cmod.          */
+typedef struct mrcnn_conv_desc {
+    int32_t N, H, W, Cin;
+    int32_t Cout;            /* GEMM N (for DECONV2: 4*cmod) */
+    int32_t KH, KW, stride, pad_t, pad_l;
+    int32_t OH, OW;
+    int32_t act, res_mode, out_mode;
+    int32_t cmod;            /* channel modulus for bias/scale/shift (== Cout except DECONV2) */
+    int64_t out_n_stride, out_h_stride, out_w_stride;   /* element strides of out / z_out / res(SAME) */
+} mrcnn_conv_desc;
+
+int mrcnn_conv2d_fwd(const mrcnn_conv_desc* d, const float* x, const float* w, const float* bias,
+                     const float* scale, const float* shift, const float* res, float* out,
+                     float* z_out, void* stream);
+
+/* dW[K, Cout] = sum over pixels of im2col(x)^T . dy   (gradient of KL.Conv2D kernels, taken by TF
+ * autodiff in the reference: keras fit_generator, mrcnn/model.py:2487).  dy is dense [N,OH,OW,Cout].
+ * Partial sums over `splits` pixel ranges go to `workspace` (splits*K*Cout floats) and are reduced in
+ * a fixed order (bitwise reproducible); beta_acc != 0 accumulates into dw instead of overwriting.   */
+int mrcnn_conv2d_wgrad(const mrcnn_conv_desc* d, const float* x, const float* dy, float* dw,
+                       float* workspace, size_t workspace_bytes, int beta_acc, void* stream);
+size_t mrcnn_conv2d_wgrad_workspace(const mrcnn_conv_desc* d);
+
+/* w_t[(KH-1-kh, KW-1-kw, co), ci] = w[(kh,kw,ci), co]: the weights of the data-gradient convolution. */
+int mrcnn_weight_flip_transpose(const float* w, float* w_t, int KH, int KW, int Cin, int Cout,
+                                void* stream);
+
+/* Frozen BatchNorm (KL.BatchNormalization with training=False, mrcnn/model.py:57-72; eps = Keras
+ * default 1e-3):  scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, for n channels.          */
+int mrcnn_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                  float eps, float* scale, float* shift, float* rstd, int64_t n, void* stream);
+
+/* Backward of the conv epilogue over a dense [M, C] tensor:
+ *   dy = dout * act'(out)  (relu: out > 0; sigmoid: out*(1-out));  dy_out (optional) gets dy;  dz_out gets dy*scale (or dy);
+ *   dbeta[c] += sum dy;  dgamma[c] += sum dy*(z-mean)*rstd;  dbias[c] += sum dz.
+ * (reference: TF autodiff through BatchNorm/Add/Activation).  dbeta/dgamma/dbias accumulate (atomics);
+ * any of scale/z/mean/rstd/dgamma/dbeta may be NULL for layers without BatchNorm.                     */
+int mrcnn_epilogue_bwd(const float* dout, const float* out, const float* z, const float* scale,
+                       const float* mean, const float* rstd, float* dy_out, float* dz_out,
+                       float* dgamma, float* dbeta, float* dbias, int64_t M, int C, int act,
+                       void* stream);
+
+/* KL.MaxPooling2D((3,3), strides=(2,2), padding="same") (mrcnn/model.py:187); TF SAME padding:
+ * pad_before = total/2 (0 at even input sizes), window clipped at the borders.  argmax index kept
+ * for the backward pass (first maximum in window scan order, as TF's MaxPoolGrad... see DESIGN.md). */
+int mrcnn_maxpool3x3s2_fwd(const float* x, float* out, int32_t* argmax, int N, int H, int W, int C,
+                           int OH, int OW, int pad_t, int pad_l, void* stream);
+int mrcnn_maxpool3x3s2_bwd(const float* dout, const int32_t* argmax, float* dx, int N, int H, int W,
+                           int C, int OH, int OW, void* stream);
+
+/* out[n, oh, ow, c] = x[n, 2oh, 2ow, c]  (KL.MaxPooling2D(pool_size=(1,1), strides=2) "fpn_p6",
+ * mrcnn/model.py:2022) and its adjoint (accumulating scatter).                                       */
+int mrcnn_subsample2_fwd(const float* x, float* out, int N, int H, int W, int C, void* stream);
+int mrcnn_subsample2_bwd_acc(const float* dout, float* dx, int N, int H, int W, int C, void* stream);
+
+/* dsrc[n, h, w, c] (+)= sum of the 2x2 block of dout: adjoint of KL.UpSampling2D(2,2)
+ * (mrcnn/model.py:2007-2013).                                                                       */
+int mrcnn_upsample2_bwd(const float* dout, float* dsrc, int N, int H, int W, int C, int accumulate,
+                        void* stream);
+
+/* Elementwise helpers on flat buffers. */
+int mrcnn_add_inplace(float* dst, const float* src, int64_t n, void* stream);
+int mrcnn_softmax_rows(const float* logits, float* probs, int64_t rows, int C, void* stream);
+
+/* PyramidROIAlign (mrcnn/model.py:428-534): level = clamp(4 + round(log2(sqrt(h*w)/(224/sqrt(area)))),
+ * 2, 5); tf.image.crop_and_resize(bilinear, extrapolation 0), one sample per bin, output in the
+ * original ROI order.  boxes [B, R, 4] normalised (y1,x1,y2,x2); fm[l] = P(2+l) as [B, Hl, Wl, C].
+ * out [B, R, P, P, C].  C must be a multiple of 64*4 = 256 lanes-of-float4 ... any multiple of 4.   */
+typedef struct mrcnn_roialign_desc {
+    int32_t B, R, P, C;
+    int32_t H[4], W[4];
+    float image_area;        /* IMAGE_SHAPE[0]*IMAGE_SHAPE[1] as float32 */
+} mrcnn_roialign_desc;
+int mrcnn_roialign_fwd(const mrcnn_roialign_desc* d, const float* boxes, const float* fm2,
+                       const float* fm3, const float* fm4, const float* fm5, float* out,
+                       int32_t* level_out, void* stream);
+/* Adjoint: scatter-add (float atomics) of dout into the four pre-zeroed/accumulating maps. */
+int mrcnn_roialign_bwd(const mrcnn_roialign_desc* d, const float* boxes, const float* dout,
+                       float* dfm2, float* dfm3, float* dfm4, float* dfm5, void* stream);
+
+/* ProposalLayer (mrcnn/model.py:329-406): per image, scores = rpn_probs[:, 1]; top-k(min(pre_nms, A),
+ * sorted, ties -> lower index); decode with deltas*std; clip to [0,1]; greedy NMS (IoU > thr
+ * suppresses, TF non_max_suppression semantics); gather; zero-pad to proposal_count.
+ * Outputs: rois [B, proposal_count, 4]; optional debug outputs top_idx [B, K] (int32 anchor ids in
+ * sorted order), keep_idx [B, proposal_count] (positions into the sorted list, -1 padded),
+ * num_keep [B].  workspace from mrcnn_proposal_workspace().                                        */
+typedef struct mrcnn_proposal_desc {
+    int32_t B, A, pre_nms_limit, proposal_count;
+    float nms_threshold;
+    float std_dev[4];
+} mrcnn_proposal_desc;
+size_t mrcnn_proposal_workspace(const mrcnn_proposal_desc* d);
+int mrcnn_proposal_fwd(const mrcnn_proposal_desc* d, const float* rpn_probs, const float* rpn_bbox,
+                       const float* anchors, float* rois, int32_t* top_idx, int32_t* keep_idx,
+                       int32_t* num_keep, void* workspace, size_t workspace_bytes, void* stream);
+
+/* DetectionTargetLayer (mrcnn/model.py:570-763) for one batch.  rand_keys [B, R] uniform floats
+ * replace tf.random.shuffle: candidates are taken in increasing key order (ties -> lower index).
+ * gt_masks is the reference layout [B, MH, MW, G] (uint8 0/1).  Outputs are zero padded to T.       */
+typedef struct mrcnn_dettarget_desc {
+    int32_t B, R, G, T, MH, MW, mask_h, mask_w;
+    int32_t positive_count;      /* int(TRAIN_ROIS_PER_IMAGE * ROI_POSITIVE_RATIO), model.py:635 */
+    float negative_ratio_r;      /* float32(1.0 / ROI_POSITIVE_RATIO), model.py:641-642 */
+    float bbox_std_dev[4];
+    int32_t use_mini_mask;
+} mrcnn_dettarget_desc;
+int mrcnn_detection_targets(const mrcnn_dettarget_desc* d, const float* proposals,
+                            const int32_t* gt_class_ids, const float* gt_boxes,
+                            const uint8_t* gt_masks, const float* rand_keys, float* rois,
+                            int32_t* target_class_ids, float* target_bbox, float* target_mask,
+                            int32_t* roi_gt_assignment, int32_t* counts, void* stream);
+
+/* DetectionLayer / refine_detections_graph (mrcnn/model.py:770-909): detections [B, max_inst, 6]. */
+typedef struct mrcnn_detection_desc {
+    int32_t B, R, C, max_instances;
+    float min_confidence, nms_threshold;
+    float bbox_std_dev[4];
+} mrcnn_detection_desc;
+size_t mrcnn_detection_workspace(const mrcnn_detection_desc* d);
+int mrcnn_detection_fwd(const mrcnn_detection_desc* d, const float* rois, const float* probs,
+                        const float* deltas, const float* windows, float* detections,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/* The five losses and their gradients w.r.t. the network outputs (mrcnn/model.py:1098-1270).
+ * losses[5] = rpn_class, rpn_bbox, mrcnn_class, mrcnn_bbox, mrcnn_mask (each already the batch mean).
+ * loss_weights scale the gradients (LOSS_WEIGHTS * USE_LOSSES).  Gradients are written dense.        */
+typedef struct mrcnn_loss_desc {
+    int32_t B, A, T, C, mask_h, mask_w, max_rpn_pos;   /* max_rpn_pos = rows of input_rpn_bbox */
+    int32_t mask_loss_dice;
+    float w[5];
+} mrcnn_loss_desc;
+size_t mrcnn_losses_workspace(const mrcnn_loss_desc* d);
+int mrcnn_losses_fwd_bwd(const mrcnn_loss_desc* d, const int32_t* rpn_match, const float* rpn_bbox_t,
+                         const float* rpn_class_logits, const float* rpn_bbox,
+                         const int32_t* target_class_ids, const float* target_bbox,
+                         const float* target_mask, const int32_t* active_class_ids,
+                         const float* mrcnn_class_logits, const float* mrcnn_bbox,
+                         const float* mrcnn_mask, float* losses, float* d_rpn_class_logits,
+                         float* d_rpn_bbox, float* d_mrcnn_class_logits, float* d_mrcnn_bbox,
+                         float* d_mrcnn_mask, void* workspace, size_t workspace_bytes, void* stream);
+
+/* keras.optimizers.SGD(lr, momentum, clipnorm) + L2/numel regulariser (mrcnn/model.py:2255-2291) on
+ * flat buffers.  seg_* describe the parameter tensors inside the flat buffer: offset, numel and the
+ * per-tensor L2 coefficient (2*WEIGHT_DECAY/numel, or 0 for gamma/beta).                             */
+/* grads = (trainable ? grads*grad_scale + seg_l2*params : 0): averages the data-parallel gradient
+ * sum (grad_scale = 1/world) and adds the regulariser term before the global norm is taken. */
+int mrcnn_grad_prepare(float* grads, const float* params, float grad_scale,
+                       const uint8_t* trainable_mask_per_seg, const int64_t* seg_offset,
+                       const int64_t* seg_numel, const float* seg_l2, int num_seg, int64_t n, void* stream);
+int mrcnn_sumsq(const float* g, int64_t n, float* out_scalar, void* stream);
+int mrcnn_sgd_momentum(float* params, float* momentum_buf, const float* grads,
+                       const float* sumsq, float clipnorm, float lr, float momentum, float grad_scale,
+                       const uint8_t* trainable_mask_per_seg, const int64_t* seg_offset,
+                       const int64_t* seg_numel, int num_seg, int64_t n, void* stream);
+
+const char* mrcnn_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRCNN_HIP_H */
