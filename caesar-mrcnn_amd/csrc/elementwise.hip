@@ -252,4 +252,44 @@ extern "C" int mrcnn_softmax_rows(const float* logits, float* probs, int64_t row
     return mrcnn_launch_status();
 }
 
+
+// dst[n, h, w, (a*2+b)*C + c] = src[n, 2h+a, 2w+b, c]: regroups the gradient of the 2x2/s2 transposed
+// convolution (mrcnn_mask_deconv, mrcnn/model.py:1087) into the column order of its GEMM.
+__global__ void pixel_unshuffle2_kernel(const float* __restrict__ src, float* dst, int N, int H, int W, int C) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // over float4 of dst
+    const int c4n = C >> 2;
+    int64_t total = (int64_t)N * H * W * 4 * c4n;
+    if (i >= total) return;
+    int c4 = (int)(i % c4n);
+    int64_t p = i / c4n;
+    int ab = (int)(p & 3); p >>= 2;
+    int w = (int)(p % W); p /= W;
+    int h = (int)(p % H);
+    int n = (int)(p / H);
+    const f32x4* s = (const f32x4*)(src + ((((int64_t)n * 2 * H + 2 * h + (ab >> 1)) * 2 * W) + 2 * w + (ab & 1)) * C);
+    ((f32x4*)dst)[i] = s[c4];
+}
+
+extern "C" int mrcnn_pixel_unshuffle2(const float* src, float* dst, int N, int H, int W, int C, void* stream) {
+    if (!src || !dst || N <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3)) return MRCNN_ERR_ARG;
+    int64_t total = (int64_t)N * H * W * C;
+    hipLaunchKernelGGL(pixel_unshuffle2_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       src, dst, N, H, W, C);
+    return mrcnn_launch_status();
+}
+
+// Strided row copy on the DMA path (no kernel): `rows` rows of `row_bytes` bytes.
+extern "C" int mrcnn_copy2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t row_bytes,
+                            size_t rows, void* stream) {
+    if (!dst || !src || row_bytes == 0 || rows == 0 || dst_pitch < row_bytes || src_pitch < row_bytes) return MRCNN_ERR_ARG;
+    hipError_t e = hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, row_bytes, rows, hipMemcpyDeviceToDevice,
+                                    (hipStream_t)stream);
+    return e == hipSuccess ? MRCNN_OK : MRCNN_ERR_LAUNCH;
+}
+
+extern "C" int mrcnn_fill_zero(void* dst, size_t bytes, void* stream) {
+    if (!dst || bytes == 0) return MRCNN_ERR_ARG;
+    return hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream) == hipSuccess ? MRCNN_OK : MRCNN_ERR_LAUNCH;
+}
+
 extern "C" const char* mrcnn_hip_version(void) { return "mrcnn_hip 0.1 (gfx950)"; }

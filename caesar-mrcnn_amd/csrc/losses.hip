@@ -217,7 +217,13 @@ __global__ __launch_bounds__(256) void heads_loss_grad_kernel(const LossArgs p) 
             if (p.dice) {
                 g = -(2.f * y * D - I2) / (D * D) * p.w4;
             } else if (q >= eps && q <= 1.f - eps) {
-                g = (q - y) / (q * (1.f - q)) * (p.w4 / (npos * (float)npix));
+                // TF autodiff of max(x,0) - x*y + log1p(exp(-|x|)) with x = log(q/(1-q)):
+                // relu'(0) = 0 and sign(0) = 0, so the value at x == 0 is -y (not sigmoid(0) - y)
+                const float x = logf(q / (1.f - q));
+                const float e = expf(-fabsf(x));
+                const float sg = x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f);
+                const float gx = (x > 0.f ? 1.f : 0.f) - y - sg * e / (1.f + e);
+                g = gx / (q * (1.f - q)) * (p.w4 / (npos * (float)npix));
             }
         }
         p.d_mmask[row * npix * C + i] = g;

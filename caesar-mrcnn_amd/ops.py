@@ -347,3 +347,24 @@ def sgd_momentum(params, mom, grads, sumsq_t, clipnorm, lr, momentum, trainable,
     check(_hip.lib().mrcnn_sgd_momentum(ptr(params), ptr(mom), ptr(grads), ptr(sumsq_t), float(clipnorm), float(lr),
                                         float(momentum), 1.0, ptr(trainable), ptr(seg_offset), ptr(seg_numel),
                                         seg_offset.numel(), params.numel(), current_stream()), "mrcnn_sgd_momentum")
+
+
+def pixel_unshuffle2(src, out=None):
+    """[N,2H,2W,C] -> [N,H,W,4C] with column (a*2+b)*C + c."""
+    _need_cuda(src, out)
+    N, H2, W2, C_ = src.shape
+    if out is None:
+        out = torch.empty((N, H2 // 2, W2 // 2, 4 * C_), dtype=torch.float32, device=src.device)
+    check(_hip.lib().mrcnn_pixel_unshuffle2(ptr(src), ptr(out), N, H2 // 2, W2 // 2, C_, current_stream()),
+          "mrcnn_pixel_unshuffle2")
+    return out
+
+
+def copy2d(dst_ptr, dst_pitch, src_ptr, src_pitch, row_bytes, rows):
+    check(_hip.lib().mrcnn_copy2d(dst_ptr, dst_pitch, src_ptr, src_pitch, row_bytes, rows, current_stream()),
+          "mrcnn_copy2d")
+
+
+def fill_zero(t):
+    _need_cuda(t)
+    check(_hip.lib().mrcnn_fill_zero(ptr(t), t.numel() * t.element_size(), current_stream()), "mrcnn_fill_zero")

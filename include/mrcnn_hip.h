@@ -101,6 +101,13 @@ int mrcnn_subsample2_bwd_acc(const float* dout, float* dx, int N, int H, int W, 
 int mrcnn_upsample2_bwd(const float* dout, float* dsrc, int N, int H, int W, int C, int accumulate,
                         void* stream);
 
+/* dst[n,h,w,(a*2+b)*C+c] = src[n,2h+a,2w+b,c] (gradient regrouping for Conv2DTranspose 2x2/s2). */
+int mrcnn_pixel_unshuffle2(const float* src, float* dst, int N, int H, int W, int C, void* stream);
+/* DMA helpers (hipMemcpy2DAsync / hipMemsetAsync on `stream`), device to device. */
+int mrcnn_copy2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t row_bytes,
+                 size_t rows, void* stream);
+int mrcnn_fill_zero(void* dst, size_t bytes, void* stream);
+
 /* Elementwise helpers on flat buffers. */
 int mrcnn_add_inplace(float* dst, const float* src, int64_t n, void* stream);
 int mrcnn_softmax_rows(const float* logits, float* probs, int64_t rows, int C, void* stream);

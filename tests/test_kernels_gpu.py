@@ -1,0 +1,429 @@
+"""Kernel-level parity: every C-ABI entry point against the CPU oracle on seeded inputs (sizes the
+oracle finishes in seconds).  Float tolerances are written next to each check; index outputs are
+compared exactly."""
+import numpy as np
+import pytest
+import torch
+
+import mrcnn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+F32 = dict(rtol=2e-4, atol=2e-4)     # fp32 contractions with a different summation order
+
+
+def _ops():
+    from caesar_mrcnn_amd import ops
+    return ops
+
+
+def _rand(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+def _cfg(**kw):
+    from caesar_mrcnn_amd.config import run_py_config
+    return run_py_config(**kw)
+
+
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, padding, act, bn, res
+    (2, 16, 16, 64, 256, 1, 1, "valid", 1, True, 0),
+    (3, 14, 14, 256, 256, 3, 1, "same", 1, True, 0),
+    (2, 16, 16, 256, 128, 1, 2, "valid", 1, True, 0),
+    (2, 64, 64, 3, 64, 7, 2, (3, 3), 1, True, 0),        # stem: generic gather path, K = 147
+    (2, 16, 16, 64, 256, 1, 1, "valid", 1, True, 1),     # residual add + relu
+    (2, 16, 16, 512, 256, 1, 1, "valid", 0, False, 2),   # FPN lateral + nearest-up2 add
+    (5, 7, 7, 256, 1024, 7, 1, "valid", 1, True, 0),     # class head FC as 7x7 VALID conv, K = 12544
+    (1, 33, 17, 64, 64, 3, 1, "same", 0, False, 0),      # ragged M, 64x64 tile
+    (8, 64, 64, 64, 256, 1, 1, "valid", 1, True, 0),     # 128x128 tiles
+    (8, 64, 64, 64, 64, 3, 1, "same", 1, True, 0),       # 128x64 tiles
+    (16, 64, 64, 256, 12, 1, 1, "valid", 0, False, 0),   # 128x32 tiles, ragged Cout
+    (1, 8, 8, 512, 6, 1, 1, "valid", 0, False, 0),       # 64x32 tiles, scalar B loads
+    (4, 28, 28, 256, 4, 1, 1, "valid", 2, False, 0),     # mask logits + sigmoid
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd(dev, case):
+    ops = _ops()
+    N, H, W, Cin, Cout, k, stride, padding, act, bn, res = case
+    rng = np.random.default_rng(1000 + sum(int(v) if isinstance(v, int) else 7 for v in case))
+    x = _rand(rng, N, H, W, Cin)
+    w = _rand(rng, k, k, Cin, Cout, scale=1.0 / np.sqrt(k * k * Cin))
+    b = _rand(rng, Cout, scale=0.1)
+    xt, wt, bt = (torch.tensor(a, device=dev) for a in (x, w, b))
+    y = orc.conv2d_nhwc(torch.tensor(x), torch.tensor(w), torch.tensor(b), stride, padding)
+    z_ref = y.clone()
+    scale = shift = None
+    if bn:
+        g, be, mu, var = rng.uniform(.5, 1.5, Cout), rng.uniform(-.2, .2, Cout), rng.uniform(-.2, .2, Cout), rng.uniform(.5, 1.5, Cout)
+        g, be, mu, var = (torch.tensor(a.astype(np.float32)) for a in (g, be, mu, var))
+        y = orc.batchnorm_frozen(y, g, be, mu, var)
+        scale = torch.empty(Cout, device=dev); shift = torch.empty(Cout, device=dev); rstd = torch.empty(Cout, device=dev)
+        ops.bn_fold(g.to(dev), be.to(dev), mu.to(dev), var.to(dev), scale, shift, rstd)
+        torch.testing.assert_close(rstd.cpu(), 1.0 / torch.sqrt(var + orc.BN_EPS), rtol=1e-6, atol=1e-6)
+    rt = None
+    if res == 1:
+        r = _rand(rng, *y.shape)
+        y = y + torch.tensor(r)
+        rt = torch.tensor(r, device=dev)
+    elif res == 2:
+        r = _rand(rng, N, y.shape[1] // 2, y.shape[2] // 2, Cout)
+        y = y + torch.tensor(r).repeat_interleave(2, 1).repeat_interleave(2, 2)
+        rt = torch.tensor(r, device=dev)
+    if act == 1:
+        y = torch.relu(y)
+    elif act == 2:
+        y = torch.sigmoid(y)
+    z = torch.empty(tuple(y.shape), device=dev)
+    out = ops.conv2d(xt, wt, bt, scale, shift, rt, stride, padding, act, res, z_out=z)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu(), y, **F32)
+    torch.testing.assert_close(z.cpu(), z_ref, **F32)
+
+
+def test_conv_into_concat_buffer(dev):
+    """RPN heads write each pyramid level straight into the concatenated [B, A, 2] buffer."""
+    ops = _ops()
+    rng = np.random.default_rng(5)
+    B = 2
+    shapes = [(8, 8), (4, 4)]
+    A = sum(h * w * 3 for h, w in shapes)
+    buf = torch.full((B, A, 2), -7.0, device=dev)
+    w = _rand(rng, 1, 1, 512, 6, scale=0.05)
+    b = _rand(rng, 6, scale=0.1)
+    off = 0
+    refs = []
+    for h, wd in shapes:
+        x = _rand(rng, B, h, wd, 512)
+        refs.append(orc.conv2d_nhwc(torch.tensor(x), torch.tensor(w), torch.tensor(b), 1, "valid").reshape(B, -1, 2))
+        ops.conv2d_into(torch.tensor(x, device=dev), torch.tensor(w, device=dev), torch.tensor(b, device=dev),
+                        buf.data_ptr() + off * 2 * 4, A * 2, wd * 6, 6, 1, "valid")
+        off += h * wd * 3
+    torch.cuda.synchronize()
+    torch.testing.assert_close(buf.cpu(), torch.cat(refs, 1), **F32)
+
+
+def test_deconv2x2(dev):
+    ops = _ops()
+    from caesar_mrcnn_amd.params import deconv_keras_to_gemm
+    rng = np.random.default_rng(6)
+    x = _rand(rng, 3, 14, 14, 256)
+    k = _rand(rng, 2, 2, 256, 256, scale=0.05)      # Keras (2,2,out,in)
+    b = _rand(rng, 256, scale=0.1)
+    ref = torch.relu(orc.conv2d_transpose_2x2(torch.tensor(x), torch.tensor(k), torch.tensor(b)))
+    wg = torch.tensor(deconv_keras_to_gemm(k).reshape(256, 1024), device=dev)
+    out = ops.deconv2x2(torch.tensor(x, device=dev), wg, torch.tensor(b, device=dev))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.cpu(), ref, **F32)
+
+
+WGRAD_CASES = [
+    (2, 14, 14, 256, 256, 3, 1, "same"),
+    (2, 16, 16, 64, 256, 1, 1, "valid"),
+    (2, 16, 16, 256, 128, 1, 2, "valid"),
+    (2, 32, 32, 3, 64, 7, 2, (3, 3)),
+    (6, 7, 7, 256, 1024, 7, 1, "valid"),
+    (40, 14, 14, 256, 256, 3, 1, "same"),       # several pixel splits
+    (2, 16, 16, 512, 6, 1, 1, "valid"),
+    (2, 16, 16, 64, 64, 3, 1, "same"),
+    (3, 9, 9, 128, 64, 1, 1, "valid"),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad_and_dgrad(dev, case):
+    ops = _ops()
+    N, H, W, Cin, Cout, k, stride, padding = case
+    rng = np.random.default_rng(1000 + sum(int(v) if isinstance(v, int) else 7 for v in case))
+    x = torch.tensor(_rand(rng, N, H, W, Cin), requires_grad=True)
+    w = torch.tensor(_rand(rng, k, k, Cin, Cout, scale=1.0 / np.sqrt(k * k * Cin)), requires_grad=True)
+    y = orc.conv2d_nhwc(x, w, None, stride, padding)
+    dy = torch.tensor(_rand(rng, *y.shape))
+    y.backward(dy)
+    xt, dyt = x.detach().to(dev), dy.to(dev)
+    dw = ops.conv2d_wgrad(xt, dyt, tuple(w.shape), stride, padding)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dw.cpu(), w.grad, rtol=5e-4, atol=5e-4 * float(w.grad.abs().max()))
+    # accumulate mode
+    dw2 = ops.conv2d_wgrad(xt, dyt, tuple(w.shape), stride, padding, dw=dw.clone(), accumulate=True)
+    torch.testing.assert_close(dw2.cpu(), 2 * w.grad, rtol=5e-4, atol=1e-3 * float(w.grad.abs().max()))
+    # data gradient = conv of dy with the flipped/transposed weights (stride 1) or strided scatter (1x1 s2)
+    wt = ops.weight_flip_transpose(w.detach().to(dev))
+    if stride == 1 and k > 1 and padding == "same":
+        dx = ops.conv2d(dyt, wt, None, None, None, None, 1, ((k - 1) // 2, (k - 1) // 2))
+        torch.testing.assert_close(dx.cpu(), x.grad, **F32)
+    elif k == 1 and stride == 1:
+        dx = ops.conv2d(dyt, wt, None, None, None, None, 1, "valid")
+        torch.testing.assert_close(dx.cpu(), x.grad, **F32)
+    elif k == 1 and stride == 2:
+        dx = torch.zeros((N, H, W, Cin), device=dev)
+        d = ops.conv_desc(tuple(dyt.shape), tuple(wt.shape), 1, "valid")
+        d.out_w_stride, d.out_h_stride, d.out_n_stride = 2 * Cin, 2 * W * Cin, H * W * Cin
+        ops.conv2d(dyt, wt, out=dx, desc=d)
+        torch.testing.assert_close(dx.cpu(), x.grad, **F32)
+
+
+@pytest.mark.parametrize("M,C,act,bn", [(500, 256, 1, True), (1000, 6, 0, False), (3000, 4, 2, False),
+                                         (77, 2048, 1, True), (4096, 64, 1, True)])
+def test_epilogue_bwd(dev, M, C, act, bn):
+    ops = _ops()
+    rng = np.random.default_rng(M + C)
+    z = torch.tensor(_rand(rng, M, C), requires_grad=True)
+    g, be, mu, var = (torch.tensor(rng.uniform(.5, 1.5, C).astype(np.float32), requires_grad=True),
+                      torch.tensor(rng.uniform(-.2, .2, C).astype(np.float32), requires_grad=True),
+                      torch.tensor(rng.uniform(-.2, .2, C).astype(np.float32)),
+                      torch.tensor(rng.uniform(.5, 1.5, C).astype(np.float32)))
+    y = orc.batchnorm_frozen(z, g, be, mu, var) if bn else z
+    out = torch.relu(y) if act == 1 else (torch.sigmoid(y) if act == 2 else y)
+    dout = torch.tensor(_rand(rng, M, C))
+    out.backward(dout)
+    rstd = 1.0 / torch.sqrt(var + orc.BN_EPS)
+    scale = (g * rstd).detach()
+    D = lambda t: None if t is None else t.detach().to(dev).contiguous()
+    dy_o, dz_o = torch.empty(M, C, device=dev), torch.empty(M, C, device=dev)
+    dgam, dbet, dbias = (torch.zeros(C, device=dev) for _ in range(3))
+    ops.epilogue_bwd(D(dout), D(out), D(z) if bn else None, D(scale) if bn else None, D(mu) if bn else None,
+                     D(rstd) if bn else None, dy_o, dz_o, dgam if bn else None, dbet if bn else None, dbias, act)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(dz_o.cpu(), z.grad, rtol=1e-5, atol=1e-6)
+    tol = dict(rtol=1e-3, atol=1e-3 * max(1.0, float(z.grad.abs().sum(0).max())))
+    torch.testing.assert_close(dbias.cpu(), z.grad.sum(0), **tol)
+    if bn:
+        torch.testing.assert_close(dgam.cpu(), g.grad, **tol)
+        torch.testing.assert_close(dbet.cpu(), be.grad, **tol)
+
+
+def test_pool_and_resample(dev):
+    ops = _ops()
+    rng = np.random.default_rng(11)
+    for (N, H, W, C) in [(2, 32, 32, 64), (1, 17, 23, 8)]:
+        x = torch.tensor(_rand(rng, N, H, W, C), requires_grad=True)
+        ref = orc.maxpool3x3s2_same(x)
+        dy = torch.tensor(_rand(rng, *ref.shape))
+        ref.backward(dy)
+        out, am = ops.maxpool3x3s2(x.detach().to(dev), want_argmax=True)
+        dx = ops.maxpool3x3s2_bwd(dy.to(dev), am, tuple(x.shape))
+        torch.cuda.synchronize()
+        assert torch.equal(out.cpu(), ref.detach())
+        torch.testing.assert_close(dx.cpu(), x.grad, rtol=1e-6, atol=1e-6)
+    x = torch.tensor(_rand(rng, 2, 8, 8, 256))
+    assert torch.equal(ops.subsample2(x.to(dev)).cpu(), x[:, ::2, ::2, :])
+    dx = torch.ones(2, 8, 8, 256, device=dev)
+    d6 = torch.tensor(_rand(rng, 2, 4, 4, 256))
+    ops.subsample2_bwd_acc(d6.to(dev), dx)
+    ref = torch.ones(2, 8, 8, 256); ref[:, ::2, ::2, :] += d6
+    assert torch.equal(dx.cpu(), ref)
+    dup = torch.tensor(_rand(rng, 2, 16, 16, 32))
+    dsrc = torch.ones(2, 8, 8, 32, device=dev)
+    ops.upsample2_bwd(dup.to(dev), dsrc, True)
+    ref = 1 + dup.reshape(2, 8, 2, 8, 2, 32).sum((2, 4))
+    torch.testing.assert_close(dsrc.cpu(), ref, rtol=1e-6, atol=1e-6)
+    lg = torch.tensor(_rand(rng, 1000, 4, scale=3))
+    torch.testing.assert_close(ops.softmax_rows(lg.to(dev)).cpu(), torch.softmax(lg, -1), rtol=1e-6, atol=1e-7)
+    a = torch.tensor(_rand(rng, 100000)); b = torch.tensor(_rand(rng, 100000))
+    ad = a.to(dev); ops.add_inplace(ad, b.to(dev))
+    assert torch.equal(ad.cpu(), a + b)
+
+
+def _random_rois(rng, B, R, zero_tail=0):
+    """log-uniform sizes covering all four pyramid levels, some ROIs touching the border."""
+    size = np.exp(rng.uniform(np.log(0.01), np.log(0.9), (B, R, 2)))
+    ctr = rng.uniform(0, 1, (B, R, 2))
+    y1 = np.clip(ctr[..., 0] - size[..., 0] / 2, 0, 1); y2 = np.clip(ctr[..., 0] + size[..., 0] / 2, 0, 1)
+    x1 = np.clip(ctr[..., 1] - size[..., 1] / 2, 0, 1); x2 = np.clip(ctr[..., 1] + size[..., 1] / 2, 0, 1)
+    rois = np.stack([y1, x1, y2, x2], -1).astype(np.float32)
+    if zero_tail:
+        rois[:, -zero_tail:] = 0
+    return rois
+
+
+@pytest.mark.parametrize("pool", [7, 14])
+def test_roialign_fwd_bwd(dev, pool):
+    ops = _ops()
+    rng = np.random.default_rng(pool)
+    B, R, C = 2, 60, 256
+    fms = [torch.tensor(_rand(rng, B, s, s, C), requires_grad=True) for s in (64, 32, 16, 8)]
+    rois = _random_rois(rng, B, R, zero_tail=3)
+    rois[0, 0] = [0.2, 0.2, 1.2, 0.7]       # partly outside -> extrapolation zeros
+    ref = orc.pyramid_roi_align(rois, fms, pool, 1024.0 * 1024.0)
+    dout = torch.tensor(_rand(rng, *ref.shape))
+    ref.backward(dout)
+    fd = [f.detach().to(dev) for f in fms]
+    out, lv = ops.roialign(torch.tensor(rois, device=dev), fd, pool, 1024.0 * 1024.0, want_levels=True)
+    torch.cuda.synchronize()
+    assert torch.equal(lv.cpu().long(), orc.roi_levels(rois, 1024.0 * 1024.0))
+    assert len(set(lv.cpu().numpy().ravel().tolist())) == 4
+    torch.testing.assert_close(out.cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    dfm = [torch.zeros_like(f) for f in fd]
+    ops.roialign_bwd(torch.tensor(rois, device=dev), dout.to(dev), dfm, pool, 1024.0 * 1024.0)
+    torch.cuda.synchronize()
+    for a, f in zip(dfm, fms):
+        torch.testing.assert_close(a.cpu(), f.grad, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("A,limit,count,thr", [(16368, 6000, 2000, 0.7), (16368, 6000, 1000, 0.7), (3000, 6000, 1000, 0.5),
+                                                (65472, 6000, 1000, 0.9)])
+def test_proposal_layer(dev, A, limit, count, thr):
+    ops = _ops()
+    rng = np.random.default_rng(A + count)
+    B = 2
+    cfg = _cfg()
+    cfg.PRE_NMS_LIMIT, cfg.RPN_NMS_THRESHOLD = limit, thr
+    ctr = rng.uniform(0, 1, (A, 2)); sz = np.exp(rng.uniform(np.log(0.02), np.log(0.5), (A, 2)))
+    anchors = np.concatenate([ctr - sz / 2, ctr + sz / 2], 1).astype(np.float32)
+    fg = 1 / (1 + np.exp(-rng.normal(0, 2, (B, A))))
+    fg = np.round(fg, 3)                                  # many exact score ties -> exercises the tie rule
+    probs = np.stack([1 - fg, fg], -1).astype(np.float32)
+    deltas = _rand(rng, B, A, 4, scale=0.5)
+    o = orc.OracleMaskRCNN(cfg, {})
+    ref_rois, det = o.proposal_layer(torch.tensor(probs), torch.tensor(deltas), anchors, count, detail=True)
+    rois, top_idx, keep_idx, num_keep, boxes = ops.proposals(
+        torch.tensor(probs, device=dev), torch.tensor(deltas, device=dev), torch.tensor(anchors, device=dev),
+        limit, count, thr, cfg.RPN_BBOX_STD_DEV, debug=True)
+    torch.cuda.synchronize()
+    for b in range(B):
+        ix, ref_boxes, keep = det[b]
+        assert np.array_equal(top_idx[b].cpu().numpy(), ix.astype(np.int32)), "top-k order differs"
+        gb = boxes[b].cpu().numpy()
+        np.testing.assert_allclose(gb, ref_boxes, rtol=0, atol=2e-6)   # expf vs np.exp: a few ulp
+        # NMS is checked index-exact on identical inputs: the oracle re-runs on the GPU-decoded boxes
+        keep2 = orc.tf_non_max_suppression(gb, probs[b, ix, 1], count, thr)
+        n = int(num_keep[b])
+        assert n == len(keep2)
+        assert np.array_equal(keep_idx[b, :n].cpu().numpy(), keep2.astype(np.int32))
+        assert np.all(keep_idx[b, n:].cpu().numpy() == -1)
+        np.testing.assert_array_equal(rois[b, :n].cpu().numpy(), gb[keep2])
+        assert np.all(rois[b, n:].cpu().numpy() == 0)
+
+
+def test_detection_layer(dev):
+    ops = _ops()
+    rng = np.random.default_rng(21)
+    cfg = _cfg(mode="inference")
+    B, R, C = 2, 1000, cfg.NUM_CLASSES
+    rois = _random_rois(rng, B, R, zero_tail=50)
+    lg = _rand(rng, B, R, C, scale=2.0)
+    probs = np.exp(lg) / np.exp(lg).sum(-1, keepdims=True)
+    probs = np.round(probs, 2).astype(np.float32)            # score ties
+    deltas = _rand(rng, B, R, C, 4, scale=0.5)
+    windows = np.array([[0, 0, 1, 1], [0.1, 0.05, 0.9, 0.95]], np.float32)
+    o = orc.OracleMaskRCNN(cfg, {})
+    for minconf in (0, 0.5):
+        cfg.DETECTION_MIN_CONFIDENCE = minconf
+        out = ops.detections(torch.tensor(rois, device=dev), torch.tensor(probs, device=dev),
+                             torch.tensor(deltas, device=dev), torch.tensor(windows, device=dev),
+                             cfg.DETECTION_MAX_INSTANCES, minconf, cfg.DETECTION_NMS_THRESHOLD, cfg.BBOX_STD_DEV)
+        torch.cuda.synchronize()
+        for b in range(B):
+            ref = o.refine_detections(rois[b], probs[b], deltas[b], windows[b])
+            got = out[b].cpu().numpy()
+            assert np.array_equal(got[:, 4], ref[:, 4]), "class ids / order differ"
+            assert np.array_equal(got[:, 5], ref[:, 5])
+            np.testing.assert_allclose(got[:, :4], ref[:, :4], rtol=0, atol=2e-6)
+            assert (ref[:, 4] > 0).sum() > 10
+
+
+def test_detection_targets(dev):
+    ops = _ops()
+    rng = np.random.default_rng(31)
+    cfg = _cfg()
+    B, R, G, T, HW = 2, 2000, cfg.MAX_GT_INSTANCES, cfg.TRAIN_ROIS_PER_IMAGE, 64
+    gt_boxes = np.zeros((B, G, 4), np.float32); gt_cls = np.zeros((B, G), np.int32)
+    gt_masks = np.zeros((B, HW, HW, G), np.uint8)
+    props = _random_rois(rng, B, R, zero_tail=300)
+    for b in range(B):
+        ng = 7 + b
+        for g in range(ng):
+            y1, x1 = rng.integers(0, HW - 12, 2); h, w = rng.integers(4, 12, 2)
+            gt_masks[b, y1:y1 + h, x1:x1 + w, g] = 1
+            gt_masks[b, y1, x1, g] = 0
+            box = np.array([y1, x1, y1 + h, x1 + w], np.float32)
+            gt_boxes[b, g] = (box - [0, 0, 1, 1]) / (HW - 1)
+            gt_cls[b, g] = rng.integers(1, cfg.NUM_CLASSES)
+            # jittered proposals around every GT so there are positives
+            for j in range(40):
+                props[b, g * 40 + j] = np.clip(gt_boxes[b, g] + rng.normal(0, 0.01, 4), 0, 1)
+        gt_cls[b, ng - 1] = -1           # one crowd box
+    props[0, 5] = 0                      # a zero row in the middle
+    keys = rng.uniform(0, 1, (B, R)).astype(np.float32)
+    o = orc.OracleMaskRCNN(cfg, {})
+    got = ops.detection_targets(*(torch.tensor(a, device=dev) for a in (props, gt_cls, gt_boxes, gt_masks, keys)),
+                                T, cfg.ROI_POSITIVE_RATIO, cfg.BBOX_STD_DEV, cfg.MASK_SHAPE)
+    torch.cuda.synchronize()
+    rois, tcls, tbbox, tmask, assign, counts = (t.cpu().numpy() for t in got)
+    for b in range(B):
+        r_rois, r_cls, r_bb, r_m, (P, N) = o.detection_targets(props[b], gt_cls[b], gt_boxes[b], gt_masks[b].astype(bool), keys[b])
+        assert (counts[b, 0], counts[b, 1]) == (P, N) and P > 20 and N > 20
+        np.testing.assert_array_equal(rois[b], r_rois)
+        np.testing.assert_array_equal(tcls[b], r_cls)
+        np.testing.assert_allclose(tbbox[b], r_bb, rtol=1e-5, atol=1e-5)
+        assert np.mean(tmask[b] != r_m) < 1e-4          # rounding of exact .5 samples may differ by ulp
+        assert r_m.sum() > 0
+
+
+@pytest.mark.parametrize("dice", [False, True])
+def test_losses(dev, dice):
+    ops = _ops()
+    rng = np.random.default_rng(41)
+    cfg = _cfg()
+    cfg.MASK_LOSS_FUNCTION = "dice_coef_loss" if dice else "binary_crossentropy"
+    B, A, T, C = 2, 4092, 64, cfg.NUM_CLASSES
+    rpn_match = rng.choice([-1, 0, 1], size=(B, A, 1), p=[0.1, 0.85, 0.05]).astype(np.int32)
+    maxpos = int((rpn_match == 1).sum(1).max()) + 5
+    rpn_bbox_t = _rand(rng, B, maxpos, 4)
+    rpn_logits = torch.tensor(_rand(rng, B, A, 2, scale=2), requires_grad=True)
+    rpn_bbox = torch.tensor(_rand(rng, B, A, 4, scale=1.5), requires_grad=True)
+    tcls = np.zeros((B, T), np.int32); tcls[:, :20] = rng.integers(1, C, (B, 20))
+    tbbox = _rand(rng, B, T, 4); tmask = (rng.uniform(0, 1, (B, T, 28, 28)) > 0.5).astype(np.float32)
+    active = np.ones((B, C), np.int32); active[:, 2] = 0
+    logits = torch.tensor(_rand(rng, B, T, C, scale=2), requires_grad=True)
+    mbbox = torch.tensor(_rand(rng, B, T, C, 4, scale=1.5), requires_grad=True)
+    mm = rng.uniform(0, 1, (B, T, 28, 28, C)).astype(np.float32); mm[0, 0, 0, :4, :] = [[0.0] * C, [1.0] * C, [1e-9] * C, [0.5] * C]
+    mmask = torch.tensor(mm, requires_grad=True)
+    w = [1.0, 0.5, 1.0, 2.0, 1.5]
+    o = orc.OracleMaskRCNN(cfg, {})
+    ls = o.losses(rpn_match, rpn_bbox_t, rpn_logits, rpn_bbox, tcls, tbbox, tmask, active, logits, mbbox, mmask)
+    sum(wi * li for wi, li in zip(w, ls)).backward()
+    D = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev) if isinstance(a, np.ndarray) else a.detach().to(dev)
+    out = ops.losses_fwd_bwd(D(rpn_match), D(rpn_bbox_t), D(rpn_logits), D(rpn_bbox), D(tcls), D(tbbox), D(tmask),
+                             D(active[0].copy()), D(logits), D(mbbox), D(mmask), w, dice)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out[0].cpu().numpy(), [float(l) for l in ls], rtol=2e-5, atol=1e-6)
+    for got, ref in zip(out[1:], (rpn_logits, rpn_bbox, logits, mbbox, mmask)):
+        torch.testing.assert_close(got.cpu(), ref.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_sgd_step(dev):
+    ops = _ops()
+    rng = np.random.default_rng(51)
+    sizes = [1000, 64, 4097, 3]
+    offs, off = [], 0
+    for n in sizes:
+        offs.append(off); off += (n + 63) // 64 * 64
+    total = off
+    P = np.zeros(total, np.float32); G = np.zeros(total, np.float32); V = np.zeros(total, np.float32)
+    params, grads, vel = {}, {}, {}
+    for i, (o, n) in enumerate(zip(offs, sizes)):
+        params[i], grads[i], vel[i] = _rand(rng, n), _rand(rng, n, scale=3.0), _rand(rng, n, scale=0.1)
+        P[o:o + n], G[o:o + n], V[o:o + n] = params[i], grads[i], vel[i]
+    l2 = np.array([2e-4 / 1000, 0, 2e-4 / 4097, 0], np.float32)
+    world = 2
+    for i in params:
+        grads[i] = grads[i] * np.float32(1.0 / world) + l2[i] * params[i]
+    Pd, Gd, Vd = (torch.tensor(a, device=dev) for a in (P, G, V))
+    so, sn = torch.tensor(offs, dtype=torch.int64, device=dev), torch.tensor(sizes, dtype=torch.int64, device=dev)
+    tr = torch.ones(4, dtype=torch.uint8, device=dev)
+    ss = torch.zeros(1, device=dev)
+    ops.grad_prepare(Gd, Pd, 1.0 / world, tr, so, sn, torch.tensor(l2, device=dev))
+    ops.sumsq(Gd, ss)
+    ops.sgd_momentum(Pd, Vd, Gd, ss, 5.0, 0.01, 0.9, tr, so, sn)
+    torch.cuda.synchronize()
+    norm = orc.sgd_step(params, grads, vel, 0.01, 0.9, 5.0)
+    assert norm > 5.0
+    np.testing.assert_allclose(float(ss.sqrt()), norm, rtol=1e-5)
+    for i, (o, n) in enumerate(zip(offs, sizes)):
+        np.testing.assert_allclose(Pd[o:o + n].cpu().numpy(), params[i], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(Vd[o:o + n].cpu().numpy(), vel[i], rtol=1e-5, atol=1e-6)
