@@ -1,0 +1,159 @@
+"""CPU input pipeline of training (mrcnn/model.py:1277-1377, 1536-1644, 1721-1904): per-image ground
+truth loading, RPN target building and batch assembly.  NumPy on the host, exactly where the reference
+runs it (Keras generator workers); the device step consumes the seven arrays it yields.
+"""
+import logging
+
+import numpy as np
+
+from . import utils
+
+logger = logging.getLogger("mrcnn")
+
+
+def load_image_gt(dataset, config, image_id, augment=False, augmentation=None, use_mini_mask=False):
+    """image, image_meta, class_ids, bbox, mask for one dataset entry (model.py:1277-1377).
+    `augmentation` may be an imgaug augmenter (if imgaug is installed) or any callable
+    ``f(image, mask) -> (image, mask)`` that preserves shapes."""
+    image = dataset.load_image(image_id)
+    mask, class_ids = dataset.load_mask(image_id)
+    original_shape = image.shape
+    image, window, scale, padding, crop = utils.resize_image(
+        image, min_dim=config.IMAGE_MIN_DIM, min_scale=config.IMAGE_MIN_SCALE, max_dim=config.IMAGE_MAX_DIM,
+        mode=config.IMAGE_RESIZE_MODE)
+    mask = utils.resize_mask(mask, scale, padding, crop)
+    if augment:
+        logging.warning("'augment' is deprecated. Use 'augmentation' instead.")
+        import random
+        if random.randint(0, 1):
+            image, mask = np.fliplr(image), np.fliplr(mask)
+    if augmentation is not None:
+        shape_i, shape_m = image.shape, mask.shape
+        if hasattr(augmentation, "to_deterministic"):
+            import imgaug
+            safe = ["Sequential", "SomeOf", "OneOf", "Sometimes", "Fliplr", "Flipud", "CropAndPad", "Affine",
+                    "PiecewiseAffine"]
+            det = augmentation.to_deterministic()
+            image = det.augment_image(image)
+            mask = det.augment_image(mask.astype(np.uint8), hooks=imgaug.HooksImages(
+                activator=lambda images, augmenter, parents, default: augmenter.__class__.__name__ in safe))
+        else:
+            image, mask = augmentation(image, mask)
+        assert image.shape == shape_i, "Augmentation shouldn't change image size"
+        assert mask.shape == shape_m, "Augmentation shouldn't change mask size"
+        mask = mask.astype(bool)
+    keep = np.sum(mask, axis=(0, 1)) > 0
+    mask = mask[:, :, keep]
+    class_ids = class_ids[keep]
+    bbox = utils.extract_bboxes(mask)
+    active_class_ids = np.zeros([dataset.num_classes], dtype=np.int32)
+    source_class_ids = dataset.source_class_ids[dataset.image_info[image_id]["source"]]
+    active_class_ids[source_class_ids] = 1
+    if use_mini_mask:
+        mask = utils.minimize_mask(bbox, mask, config.MINI_MASK_SHAPE)
+    image_meta = utils.compose_image_meta(image_id, original_shape, image.shape, window, scale, active_class_ids)
+    return image, image_meta, class_ids, bbox, mask
+
+
+def build_rpn_targets(image_shape, anchors, gt_class_ids, gt_boxes, config, rng=np.random):
+    """rpn_match [A] in {-1,0,1} and rpn_bbox [RPN_TRAIN_ANCHORS_PER_IMAGE, 4] (model.py:1536-1644)."""
+    n_train = config.RPN_TRAIN_ANCHORS_PER_IMAGE
+    rpn_match = np.zeros([anchors.shape[0]], dtype=np.int32)
+    rpn_bbox = np.zeros((n_train, 4))
+    crowd_ix = np.where(gt_class_ids < 0)[0]
+    if crowd_ix.shape[0] > 0:
+        non_crowd_ix = np.where(gt_class_ids > 0)[0]
+        crowd_boxes = gt_boxes[crowd_ix]
+        gt_class_ids, gt_boxes = gt_class_ids[non_crowd_ix], gt_boxes[non_crowd_ix]
+        no_crowd = np.amax(utils.compute_overlaps(anchors, crowd_boxes), axis=1) < 0.001
+    else:
+        no_crowd = np.ones([anchors.shape[0]], dtype=bool)
+    overlaps = utils.compute_overlaps(anchors, gt_boxes)
+    arg = np.argmax(overlaps, axis=1)
+    best = overlaps[np.arange(overlaps.shape[0]), arg]
+    rpn_match[(best < 0.3) & no_crowd] = -1
+    rpn_match[np.argwhere(overlaps == np.max(overlaps, axis=0))[:, 0]] = 1      # every GT keeps its best anchors
+    rpn_match[best >= 0.7] = 1
+    ids = np.where(rpn_match == 1)[0]
+    extra = len(ids) - (n_train // 2)
+    if extra > 0:
+        rpn_match[rng.choice(ids, extra, replace=False)] = 0
+    ids = np.where(rpn_match == -1)[0]
+    extra = len(ids) - (n_train - np.sum(rpn_match == 1))
+    if extra > 0:
+        rpn_match[rng.choice(ids, extra, replace=False)] = 0
+    ids = np.where(rpn_match == 1)[0]
+    for ix, (i, a) in enumerate(zip(ids, anchors[ids])):
+        gt = gt_boxes[arg[i]]
+        gh, gw = gt[2] - gt[0], gt[3] - gt[1]
+        gcy, gcx = gt[0] + 0.5 * gh, gt[1] + 0.5 * gw
+        ah, aw = a[2] - a[0], a[3] - a[1]
+        acy, acx = a[0] + 0.5 * ah, a[1] + 0.5 * aw
+        rpn_bbox[ix] = [(gcy - acy) / ah, (gcx - acx) / aw, np.log(gh / ah), np.log(gw / aw)]
+        rpn_bbox[ix] /= config.RPN_BBOX_STD_DEV
+    return rpn_match, rpn_bbox
+
+
+def data_generator(dataset, config, shuffle=True, augment=False, augmentation=None, batch_size=1,
+                   no_augmentation_sources=None, rank=0, world_size=1, seed=None):
+    """Yields ([images, image_meta, rpn_match, rpn_bbox, gt_class_ids, gt_boxes, gt_masks], []) forever
+    (model.py:1721-1904).  With world_size > 1 each rank walks its own stride of the (identically
+    shuffled) image list -- the data-parallel replacement of tf.split in parallel_model.py:60-62."""
+    b = 0
+    image_index = -1
+    image_ids = np.copy(dataset.image_ids)
+    error_count = 0
+    no_augmentation_sources = no_augmentation_sources or []
+    rng = np.random.RandomState(seed) if seed is not None else np.random
+    backbone_shapes = utils.compute_backbone_shapes(config, config.IMAGE_SHAPE)
+    anchors = utils.generate_pyramid_anchors(config.RPN_ANCHOR_SCALES, config.RPN_ANCHOR_RATIOS, backbone_shapes,
+                                             config.BACKBONE_STRIDES, config.RPN_ANCHOR_STRIDE)
+    while True:
+        try:
+            image_index = (image_index + 1) % len(image_ids)
+            if shuffle and image_index == 0:
+                rng.shuffle(image_ids)
+            if image_index % world_size != rank:
+                continue
+            image_id = image_ids[image_index]
+            if dataset.image_info[image_id]['source'] in no_augmentation_sources:
+                image, image_meta, gt_class_ids, gt_boxes, gt_masks = load_image_gt(
+                    dataset, config, image_id, augment=augment, augmentation=None, use_mini_mask=config.USE_MINI_MASK)
+            else:
+                image, image_meta, gt_class_ids, gt_boxes, gt_masks = load_image_gt(
+                    dataset, config, image_id, augment=augment, augmentation=augmentation,
+                    use_mini_mask=config.USE_MINI_MASK)
+            if not np.any(gt_class_ids > 0):
+                continue
+            rpn_match, rpn_bbox = build_rpn_targets(image.shape, anchors, gt_class_ids, gt_boxes, config)
+            if b == 0:
+                batch_image_meta = np.zeros((batch_size,) + image_meta.shape, dtype=image_meta.dtype)
+                batch_rpn_match = np.zeros([batch_size, anchors.shape[0], 1], dtype=rpn_match.dtype)
+                batch_rpn_bbox = np.zeros([batch_size, config.RPN_TRAIN_ANCHORS_PER_IMAGE, 4], dtype=rpn_bbox.dtype)
+                batch_images = np.zeros((batch_size,) + image.shape, dtype=np.float32)
+                batch_gt_class_ids = np.zeros((batch_size, config.MAX_GT_INSTANCES), dtype=np.int32)
+                batch_gt_boxes = np.zeros((batch_size, config.MAX_GT_INSTANCES, 4), dtype=np.int32)
+                batch_gt_masks = np.zeros((batch_size, gt_masks.shape[0], gt_masks.shape[1], config.MAX_GT_INSTANCES),
+                                          dtype=gt_masks.dtype)
+            if gt_boxes.shape[0] > config.MAX_GT_INSTANCES:
+                ids = np.random.choice(np.arange(gt_boxes.shape[0]), config.MAX_GT_INSTANCES, replace=False)
+                gt_class_ids, gt_boxes, gt_masks = gt_class_ids[ids], gt_boxes[ids], gt_masks[:, :, ids]
+            batch_image_meta[b] = image_meta
+            batch_rpn_match[b] = rpn_match[:, np.newaxis]
+            batch_rpn_bbox[b] = rpn_bbox
+            batch_images[b] = utils.mold_image(image.astype(np.float32), config)
+            batch_gt_class_ids[b, :gt_class_ids.shape[0]] = gt_class_ids
+            batch_gt_boxes[b, :gt_boxes.shape[0]] = gt_boxes
+            batch_gt_masks[b, :, :, :gt_masks.shape[-1]] = gt_masks
+            b += 1
+            if b >= batch_size:
+                yield [batch_images, batch_image_meta, batch_rpn_match, batch_rpn_bbox, batch_gt_class_ids,
+                       batch_gt_boxes, batch_gt_masks], []
+                b = 0
+        except (GeneratorExit, KeyboardInterrupt):
+            raise
+        except Exception:
+            logger.exception("Error processing image {}".format(dataset.image_info[image_id]))
+            error_count += 1
+            if error_count > 5:
+                raise

@@ -1,0 +1,535 @@
+"""Device-side execution of the Mask R-CNN graph wired by MaskRCNN.build (mrcnn/model.py:1935-2166):
+forward (inference and training), the hand-derived backward pass, and the optimiser step
+(MaskRCNN.compile, mrcnn/model.py:2255-2291).  Every arithmetic step is a launch into
+libmrcnn_hip.so; torch only owns the buffers.
+
+Gradient plumbing conventions
+  * all parameter gradients live in one flat buffer (params.ParamLayout) that is zeroed per step;
+    bias / BatchNorm gamma,beta gradients are accumulated by the epilogue-backward kernel;
+  * a tensor consumed by several ops gets its gradient summed by chaining: every data-gradient
+    convolution can add an existing buffer in its epilogue (res_mode SAME, in place);
+  * the ROIAlign adjoints scatter-add into zero-initialised pyramid gradients first.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from ._hip import ACT_NONE, ACT_RELU, ACT_SIGMOID, RES_NONE, RES_SAME, RES_UP2
+from .params import ParamLayout, deconv_gemm_to_keras, deconv_keras_to_gemm, init_weights
+
+LOSS_NAMES = ("rpn_class_loss", "rpn_bbox_loss", "mrcnn_class_loss", "mrcnn_bbox_loss", "mrcnn_mask_loss")
+
+
+class ConvOp(object):
+    """One named Conv2D/Dense(+BatchNorm) layer: views into the flat buffers + fwd/bwd launches."""
+
+    def __init__(self, model, spec):
+        L = model.layout
+        self.spec = spec
+        self.name = spec.name
+        off, n, shape = L.offsets[spec.name + "/kernel"]
+        if spec.kind == "deconv":                       # [Cin, (a,b,co)] GEMM == 1x1 conv Cin -> 4*Cd
+            self.wshape = (1, 1, shape[0], shape[1] * shape[2] * shape[3])
+        else:
+            self.wshape = tuple(shape)
+        kh, kw, cin, cout = self.wshape
+        self.w = model.params[off:off + n].view(self.wshape)
+        self.dw = model.grads[off:off + n].view(self.wshape)
+        self.wt = model.wt[off:off + n].view(kh, kw, cout, cin)
+        boff, bn_, _ = L.offsets[spec.name + "/bias"]
+        self.b = model.params[boff:boff + bn_]
+        self.db = model.grads[boff:boff + bn_]
+        self.stride, self.padding = spec.stride, spec.padding
+        self.bn = spec.bn
+        self.scale = self.shift = self.mean = self.rstd = self.dgamma = self.dbeta = None
+        if spec.bn:
+            c0, c = L.bn_channel_offset[spec.bn], spec.shape[3]
+            self.scale, self.shift = model.bn_scale[c0:c0 + c], model.bn_shift[c0:c0 + c]
+            self.mean, self.rstd = model.bn_mean[c0:c0 + c], model.bn_rstd[c0:c0 + c]
+            self.dgamma = model.grads[L.gamma_offset + c0:L.gamma_offset + c0 + c]
+            self.dbeta = model.grads[L.beta_offset + c0:L.beta_offset + c0 + c]
+
+    # ---- forward ---------------------------------------------------------------------------
+    def forward(self, x, act=ACT_NONE, res=None, res_mode=RES_NONE, train=False):
+        z = None
+        d = ops.conv_desc(tuple(x.shape), self.wshape, self.stride, self.padding, act, res_mode)
+        out = torch.empty((d.N, d.OH, d.OW, d.Cout), dtype=torch.float32, device=x.device)
+        if train and self.bn:
+            z = torch.empty_like(out)
+        ops.conv2d(x, self.w, self.b, self.scale, self.shift, res, out=out, z_out=z, desc=d)
+        ctx = (x, z, out, act) if train else None
+        return out, ctx
+
+    # ---- backward pieces ---------------------------------------------------------------------
+    def epilogue_bwd(self, dout, ctx, want_dy=False):
+        """Returns (dz, dy): gradient w.r.t. the raw conv output, and (optionally) the gradient after
+        the activation mask, which is what a residual input receives."""
+        x, z, out, act = ctx
+        if self.bn is None and act == ACT_NONE:
+            ops.epilogue_bwd(dout, dbias=self.db)
+            return dout, dout
+        dz = torch.empty_like(dout)
+        dy = torch.empty_like(dout) if want_dy else None
+        ops.epilogue_bwd(dout, out if act != ACT_NONE else None, z, self.scale, self.mean, self.rstd, dy, dz,
+                         self.dgamma, self.dbeta, self.db, act)
+        return dz, dy
+
+    def wgrad(self, dz, ctx, accumulate=False):
+        x = ctx[0]
+        ops.conv2d_wgrad(x, dz.view(dz.shape[0], dz.shape[1], dz.shape[2], self.wshape[3]), self.wshape, self.stride,
+                         self.padding, dw=self.dw, accumulate=accumulate)
+
+    def dgrad(self, dz, ctx, out=None, accumulate=False):
+        """dx = adjoint of the convolution applied to dz.  `out` (shape of x) receives the result;
+        accumulate=True adds to what `out` already holds (in place)."""
+        x = ctx[0]
+        kh, kw, cin, cout = self.wshape
+        N, H, W, _ = x.shape
+        if not (self.padding == "valid" and kh > 1):
+            ops.weight_flip_transpose(self.w, self.wt)
+        res = out if accumulate else None
+        rm = RES_SAME if accumulate else RES_NONE
+        if self.stride == 1 and self.padding == "same":
+            if out is None:
+                out = torch.empty_like(x)
+            ops.conv2d(dz, self.wt, res=res, stride=1, padding=((kh - 1) // 2, (kw - 1) // 2), res_mode=rm, out=out)
+        elif kh == 1 and kw == 1 and self.stride == 1:
+            if out is None:
+                out = torch.empty_like(x)
+            ops.conv2d(dz, self.wt, res=res, stride=1, padding="valid", res_mode=rm, out=out)
+        elif kh == 1 and kw == 1 and self.stride == 2:
+            if out is None:
+                out = torch.empty_like(x)
+                ops.fill_zero(out)
+            d = ops.conv_desc(tuple(dz.shape), (1, 1, cout, cin), 1, "valid", ACT_NONE, rm)
+            d.out_w_stride, d.out_h_stride, d.out_n_stride = 2 * cin, 2 * W * cin, H * W * cin
+            ops.conv2d(dz, self.wt, res=res, out=out, desc=d)
+        elif self.padding == "valid" and x.shape[1] == kh and x.shape[2] == kw:
+            # "FC as VALID conv" (mrcnn_class_conv1): dx[M, (kh,kw,ci)] = dz[M, Cout] . W^T
+            if out is None:
+                out = torch.empty_like(x)
+            wt2 = self.wt.view(1, 1, cout, kh * kw * cin)
+            ops.weight_flip_transpose(self.w.view(1, 1, kh * kw * cin, cout), wt2)
+            ops.conv2d(dz.view(N, 1, 1, cout), wt2, res=None if res is None else res.view(N, 1, 1, -1), stride=1,
+                       padding="valid", res_mode=rm, out=out.view(N, 1, 1, kh * kw * cin))
+        else:
+            raise NotImplementedError("dgrad for layer %s" % self.name)
+        return out
+
+
+class Block(object):
+    def __init__(self, model, stage, letter, has_shortcut, stride):
+        base = "res%d%s_branch" % (stage, letter)
+        self.c2a, self.c2b, self.c2c = model.op(base + "2a"), model.op(base + "2b"), model.op(base + "2c")
+        self.c1 = model.op(base + "1") if has_shortcut else None
+        self.stage, self.stride = stage, stride
+
+
+class MaskRCNNEngine(object):
+    def __init__(self, config, device, weights=None, seed=0):
+        self.cfg = config
+        self.dev = device
+        self.layout = L = ParamLayout(config)
+        n = L.total
+        f = dict(dtype=torch.float32, device=device)
+        self.params = torch.zeros(n, **f)
+        self.grads = torch.zeros(n, **f)
+        self.momentum = torch.zeros(n, **f)
+        self.wt = torch.empty(n, **f)
+        c = max(L.bn_channels, 64)
+        self.bn_mean, self.bn_var = torch.zeros(c, **f), torch.ones(c, **f)
+        self.bn_scale, self.bn_shift, self.bn_rstd = torch.empty(c, **f), torch.empty(c, **f), torch.empty(c, **f)
+        self.seg_offset = torch.tensor([s[1] for s in L.segments], dtype=torch.int64, device=device)
+        self.seg_numel = torch.tensor([s[2] for s in L.segments], dtype=torch.int64, device=device)
+        self.sumsq = torch.zeros(1, **f)
+        self._ops = {}
+        for l in L.layers:
+            self._ops[l.name] = ConvOp(self, l)
+        arch = config.BACKBONE
+        n4 = {"resnet50": 5, "resnet101": 22, "custom": 1}[arch]
+        letters = {2: "abc", 3: "abcd", 4: "a" + "".join(chr(98 + i) for i in range(n4)), 5: "abc"}
+        self.stages = [[Block(self, s, b, i == 0, 2 if (i == 0 and s > 2) else 1) for i, b in enumerate(letters[s])]
+                       for s in (2, 3, 4, 5)]
+        self.set_trainable("all")
+        self.set_weights(weights if weights is not None else init_weights(L, seed))
+        self._anchor_cache = {}
+        # contiguous gradient ranges in the order the backward pass finalises them (for overlapped
+        # data-parallel reduction): heads+RPN+FPN kernels, then res5..res2, then conv1 + BatchNorm blocks
+        first = lambda prefix: min(o for n_, (o, _, _) in L.offsets.items() if n_.startswith(prefix) and "/kernel" in n_)
+        s2, s3, s4, s5, fp = first("res2"), first("res3"), first("res4"), first("res5"), first("fpn_")
+        self.grad_ranges = {"tail": (fp, L.gamma_offset), 5: (s5, fp), 4: (s4, s5), 3: (s3, s4), 2: (s2, s3),
+                            "head": (0, s2), "bn": (L.gamma_offset, L.total)}
+        self.grad_ready = None          # callable(start, end) or None
+
+    def op(self, name):
+        return self._ops[name]
+
+    # ---- weights in / out (Keras layouts at this boundary) --------------------------------------
+    def set_weights(self, weights, strict=True):
+        L = self.layout
+        for name, (off, n, shape) in L.offsets.items():
+            if name not in weights:
+                if strict:
+                    raise KeyError("missing weight tensor " + name)
+                continue
+            a = np.asarray(weights[name], dtype=np.float32)
+            if name == "mrcnn_mask_deconv/kernel" and a.shape == (2, 2, shape[3], shape[0]):
+                a = deconv_keras_to_gemm(a)
+            if a.size != n:
+                raise ValueError("shape mismatch for %s: %s vs %s" % (name, a.shape, shape))
+            self.params[off:off + n].copy_(torch.from_numpy(np.ascontiguousarray(a).reshape(-1)))
+        for l in L.bn_layers:
+            c0, c = L.bn_channel_offset[l.bn], l.shape[3]
+            for key, buf in (("moving_mean", self.bn_mean), ("moving_variance", self.bn_var)):
+                if l.bn + "/" + key in weights:
+                    buf[c0:c0 + c].copy_(torch.from_numpy(np.asarray(weights[l.bn + "/" + key], dtype=np.float32)))
+                elif strict:
+                    raise KeyError("missing weight tensor %s/%s" % (l.bn, key))
+        self.fold_bn()
+
+    def get_weights(self, grads=False):
+        L = self.layout
+        src = (self.grads if grads else self.params).detach().cpu().numpy()
+        out = {}
+        for name, (off, n, shape) in L.offsets.items():
+            a = src[off:off + n].reshape(shape).copy()
+            if name == "mrcnn_mask_deconv/kernel":
+                a = deconv_gemm_to_keras(a)
+            out[name] = a
+        if not grads:
+            mean, var = self.bn_mean.cpu().numpy(), self.bn_var.cpu().numpy()
+            for l in L.bn_layers:
+                c0, c = L.bn_channel_offset[l.bn], l.shape[3]
+                out[l.bn + "/moving_mean"] = mean[c0:c0 + c].copy()
+                out[l.bn + "/moving_variance"] = var[c0:c0 + c].copy()
+        return out
+
+    def fold_bn(self):
+        L = self.layout
+        if L.bn_channels:
+            g = self.params[L.gamma_offset:L.gamma_offset + L.bn_channels]
+            b = self.params[L.beta_offset:L.beta_offset + L.bn_channels]
+            ops.bn_fold(g, b, self.bn_mean[:L.bn_channels], self.bn_var[:L.bn_channels],
+                        self.bn_scale[:L.bn_channels], self.bn_shift[:L.bn_channels], self.bn_rstd[:L.bn_channels])
+
+    def set_trainable(self, layer_regex):
+        mask = self.layout.trainable_mask(layer_regex)
+        self.trainable_host = mask
+        self.trainable = torch.tensor(mask, dtype=torch.uint8, device=self.dev)
+        self.seg_l2 = torch.tensor(self.layout.l2_coefficients(self.cfg.WEIGHT_DECAY, mask), dtype=torch.float32,
+                                   device=self.dev)
+
+    # ---- anchors -------------------------------------------------------------------------------
+    def anchors(self, image_shape):
+        from . import utils
+        key = tuple(int(v) for v in image_shape)
+        if key not in self._anchor_cache:
+            a = utils.get_anchors(self.cfg, key)
+            self._anchor_cache[key] = torch.tensor(a, dtype=torch.float32, device=self.dev)
+        return self._anchor_cache[key]
+
+    # =========================================================================================
+    #  forward
+    # =========================================================================================
+    def _trunk_fwd(self, images, train):
+        """resnet_graph + FPN (model.py:175-210, 2005-2026).  Returns pyramid [P2..P6] and the tape."""
+        tape = {}
+        c1 = self.op("conv1")
+        x, tape["conv1"] = c1.forward(images, ACT_RELU, train=train)
+        if train:
+            x, am = ops.maxpool3x3s2(x, want_argmax=True)
+            tape["pool"] = (am, tuple(tape["conv1"][2].shape))
+        else:
+            x = ops.maxpool3x3s2(x)
+        feats = []
+        for stage in self.stages:
+            for blk in stage:
+                a, ca = blk.c2a.forward(x, ACT_RELU, train=train)
+                b, cb = blk.c2b.forward(a, ACT_RELU, train=train)
+                if blk.c1 is not None:
+                    sc, c1c = blk.c1.forward(x, ACT_NONE, train=train)
+                else:
+                    sc, c1c = x, None
+                x, cc = blk.c2c.forward(b, ACT_RELU, res=sc, res_mode=RES_SAME, train=train)
+                if train:
+                    tape[id(blk)] = (ca, cb, cc, c1c)
+            feats.append(x)
+        C2, C3, C4, C5 = feats
+        P5s, tape["fpn_c5p5"] = self.op("fpn_c5p5").forward(C5, train=train)
+        P4s, tape["fpn_c4p4"] = self.op("fpn_c4p4").forward(C4, res=P5s, res_mode=RES_UP2, train=train)
+        P3s, tape["fpn_c3p3"] = self.op("fpn_c3p3").forward(C3, res=P4s, res_mode=RES_UP2, train=train)
+        P2s, tape["fpn_c2p2"] = self.op("fpn_c2p2").forward(C2, res=P3s, res_mode=RES_UP2, train=train)
+        P2, tape["fpn_p2"] = self.op("fpn_p2").forward(P2s, train=train)
+        P3, tape["fpn_p3"] = self.op("fpn_p3").forward(P3s, train=train)
+        P4, tape["fpn_p4"] = self.op("fpn_p4").forward(P4s, train=train)
+        P5, tape["fpn_p5"] = self.op("fpn_p5").forward(P5s, train=train)
+        P6 = ops.subsample2(P5)
+        return [P2, P3, P4, P5, P6], tape
+
+    def _rpn_fwd(self, pyramid, train):
+        """rpn_graph over the 5 levels with shared weights, outputs concatenated level-major
+        (model.py:916-957, 2040-2055)."""
+        B = pyramid[0].shape[0]
+        na = len(self.cfg.RPN_ANCHOR_RATIOS)
+        A = sum(p.shape[1] * p.shape[2] * na for p in pyramid)
+        logits = torch.empty((B, A, 2), dtype=torch.float32, device=self.dev)
+        bbox = torch.empty((B, A, 4), dtype=torch.float32, device=self.dev)
+        shared, cls, box = self.op("rpn_conv_shared"), self.op("rpn_class_raw"), self.op("rpn_bbox_pred")
+        tape, off = [], 0
+        for p in pyramid:
+            s, cs = shared.forward(p, ACT_RELU, train=train)
+            H, W = p.shape[1], p.shape[2]
+            ops.conv2d_into(s, cls.w, cls.b, logits.data_ptr() + off * 2 * 4, A * 2, W * 2 * na, 2 * na, 1, "valid")
+            ops.conv2d_into(s, box.w, box.b, bbox.data_ptr() + off * 4 * 4, A * 4, W * 4 * na, 4 * na, 1, "valid")
+            tape.append((cs, (s, None, None, ACT_NONE), off, H, W))
+            off += H * W * na
+        probs = ops.softmax_rows(logits)
+        return logits, probs, bbox, tape
+
+    def _class_head_fwd(self, rois, fms, image_area, train):
+        """fpn_classifier_graph (model.py:986-1039)."""
+        cfg = self.cfg
+        B, R = rois.shape[0], rois.shape[1]
+        pooled = ops.roialign(rois, fms, cfg.POOL_SIZE, image_area)
+        x = pooled.view(B * R, cfg.POOL_SIZE, cfg.POOL_SIZE, -1)
+        h1, c1 = self.op("mrcnn_class_conv1").forward(x, ACT_RELU, train=train)
+        h2, c2 = self.op("mrcnn_class_conv2").forward(h1, ACT_RELU, train=train)
+        lg, c3 = self.op("mrcnn_class_logits").forward(h2, train=train)
+        bb, c4 = self.op("mrcnn_bbox_fc").forward(h2, train=train)
+        logits = lg.view(B, R, cfg.NUM_CLASSES)
+        probs = ops.softmax_rows(logits)
+        return logits, probs, bb.view(B, R, cfg.NUM_CLASSES, 4), (c1, c2, c3, c4)
+
+    def _mask_head_fwd(self, rois, fms, image_area, train):
+        """build_fpn_mask_graph (model.py:1042-1091)."""
+        cfg = self.cfg
+        B, R = rois.shape[0], rois.shape[1]
+        pooled = ops.roialign(rois, fms, cfg.MASK_POOL_SIZE, image_area)
+        x = pooled.view(B * R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1)
+        ctxs = []
+        for i in range(1, 5):
+            x, c = self.op("mrcnn_mask_conv%d" % i).forward(x, ACT_RELU, train=train)
+            ctxs.append(c)
+        dc = self.op("mrcnn_mask_deconv")
+        up = ops.deconv2x2(x, dc.w.view(dc.wshape[2], dc.wshape[3]), dc.b, ACT_RELU)
+        m, cm = self.op("mrcnn_mask").forward(up, ACT_SIGMOID, train=train)
+        ctxs.append((x, None, up, ACT_RELU) if train else None)
+        ctxs.append(cm)
+        return m.view(B, R, m.shape[1], m.shape[2], m.shape[3]), ctxs
+
+    def infer(self, images, windows_norm):
+        """Inference graph (model.py:2133-2159).  images [B,H,W,3] float32 device tensor (molded);
+        windows_norm [B,4] device.  Returns the 7 outputs of the Keras inference model."""
+        cfg = self.cfg
+        B, H, W = images.shape[0], images.shape[1], images.shape[2]
+        area = float(H * W)
+        pyr, _ = self._trunk_fwd(images, False)
+        _, rpn_probs, rpn_bbox, _ = self._rpn_fwd(pyr, False)
+        anchors = self.anchors((H, W, images.shape[3]))
+        rois = ops.proposals(rpn_probs, rpn_bbox, anchors, cfg.PRE_NMS_LIMIT, cfg.POST_NMS_ROIS_INFERENCE,
+                             cfg.RPN_NMS_THRESHOLD, np.asarray(cfg.RPN_BBOX_STD_DEV, np.float32))
+        _, probs, bbox, _ = self._class_head_fwd(rois, pyr[:4], area, False)
+        det = ops.detections(rois, probs, bbox, windows_norm, cfg.DETECTION_MAX_INSTANCES,
+                             cfg.DETECTION_MIN_CONFIDENCE, cfg.DETECTION_NMS_THRESHOLD,
+                             np.asarray(cfg.BBOX_STD_DEV, np.float32))
+        det_boxes = torch.empty((B, cfg.DETECTION_MAX_INSTANCES, 4), dtype=torch.float32, device=self.dev)
+        ops.copy2d(det_boxes.data_ptr(), 16, det.data_ptr(), 24, 16, B * cfg.DETECTION_MAX_INSTANCES)
+        masks, _ = self._mask_head_fwd(det_boxes, pyr[:4], area, False)
+        return {"detections": det, "mrcnn_class": probs, "mrcnn_bbox": bbox, "mrcnn_mask": masks, "rpn_rois": rois,
+                "rpn_class": rpn_probs, "rpn_bbox": rpn_bbox, "pyramid": pyr}
+
+    # =========================================================================================
+    #  training step: forward + backward (gradients left in self.grads)
+    # =========================================================================================
+    def loss_weights(self):
+        cfg = self.cfg
+        return [float(cfg.LOSS_WEIGHTS.get(n, 1.)) if cfg.USE_LOSSES.get(n, True) else 0.0 for n in LOSS_NAMES]
+
+    def forward_backward(self, images, rpn_match, rpn_bbox_t, gt_class_ids, gt_boxes_norm, gt_masks, active_class_ids,
+                         rand_keys, keep_outputs=False):
+        """One training forward/backward on this rank's batch.  All arguments are device tensors:
+        images [B,H,W,3] f32, rpn_match [B,A,1] i32, rpn_bbox_t [B,Np,4] f32, gt_class_ids [B,G] i32,
+        gt_boxes_norm [B,G,4] f32 (norm_boxes_graph applied), gt_masks [B,H,W,G] u8,
+        active_class_ids [C] i32 (row 0 of the batch, model.py:1182), rand_keys [B,R] f32.
+        Returns losses[5] (device)."""
+        cfg = self.cfg
+        B, H, W = images.shape[0], images.shape[1], images.shape[2]
+        area = float(H * W)
+        ops.fill_zero(self.grads)
+        pyr, tape = self._trunk_fwd(images, True)
+        rpn_logits, rpn_probs, rpn_bbox, rpn_tape = self._rpn_fwd(pyr, True)
+        anchors = self.anchors((H, W, images.shape[3]))
+        rpn_rois = ops.proposals(rpn_probs, rpn_bbox, anchors, cfg.PRE_NMS_LIMIT, cfg.POST_NMS_ROIS_TRAINING,
+                                 cfg.RPN_NMS_THRESHOLD, np.asarray(cfg.RPN_BBOX_STD_DEV, np.float32))
+        rois, tcls, tbbox, tmask, assign, counts = ops.detection_targets(
+            rpn_rois, gt_class_ids, gt_boxes_norm, gt_masks, rand_keys, cfg.TRAIN_ROIS_PER_IMAGE,
+            cfg.ROI_POSITIVE_RATIO, cfg.BBOX_STD_DEV, cfg.MASK_SHAPE, cfg.USE_MINI_MASK)
+        logits, probs, mbbox, ctx_cls = self._class_head_fwd(rois, pyr[:4], area, True)
+        mmask, ctx_mask = self._mask_head_fwd(rois, pyr[:4], area, True)
+        out = ops.losses_fwd_bwd(rpn_match, rpn_bbox_t, rpn_logits, rpn_bbox, tcls, tbbox, tmask, active_class_ids,
+                                 logits, mbbox, mmask, self.loss_weights(),
+                                 cfg.MASK_LOSS_FUNCTION == "dice_coef_loss")
+        losses, d_rpn_logits, d_rpn_bbox, d_logits, d_mbbox, d_mmask = out
+
+        # ---- pyramid gradient accumulators ------------------------------------------------------
+        dP = [torch.empty_like(p) for p in pyr[:4]]
+        for t in dP:
+            ops.fill_zero(t)
+        self._mask_head_bwd(d_mmask, ctx_mask, rois, dP, area)
+        self._class_head_bwd(d_logits, d_mbbox, ctx_cls, rois, dP, area)
+        dP6 = self._rpn_bwd(d_rpn_logits, d_rpn_bbox, rpn_tape, dP)
+        self._trunk_bwd(dP, dP6, tape)
+        if keep_outputs:
+            self.last = {"rpn_class_logits": rpn_logits, "rpn_class": rpn_probs, "rpn_bbox": rpn_bbox,
+                         "rpn_rois": rpn_rois, "rois": rois, "target_class_ids": tcls, "target_bbox": tbbox,
+                         "target_mask": tmask, "mrcnn_class_logits": logits, "mrcnn_class": probs,
+                         "mrcnn_bbox": mbbox, "mrcnn_mask": mmask, "counts": counts, "pyramid": pyr}
+        return losses
+
+    # ---- head backward --------------------------------------------------------------------------
+    def _mask_head_bwd(self, d_mmask, ctxs, rois, dP, area):
+        cfg = self.cfg
+        c1, c2, c3, c4, cdec, cm = ctxs
+        mop, dc = self.op("mrcnn_mask"), self.op("mrcnn_mask_deconv")
+        g = d_mmask.view(cm[2].shape)
+        dz, _ = mop.epilogue_bwd(g, cm)
+        mop.wgrad(dz, cm)
+        d_up = mop.dgrad(dz, cm)                                    # [M,28,28,256]
+        # deconv: relu mask + bias, regroup to GEMM columns, then the two GEMM adjoints
+        x_in, _, up, _ = cdec
+        dzu = torch.empty_like(d_up)
+        ops.epilogue_bwd(d_up, up, None, None, None, None, None, dzu, None, None, dc.db, ACT_RELU)
+        dzg = ops.pixel_unshuffle2(dzu)                             # [M,14,14,1024]
+        ops.conv2d_wgrad(x_in, dzg, dc.wshape, 1, "valid", dw=dc.dw)
+        ops.weight_flip_transpose(dc.w, dc.wt)
+        d = ops.conv2d(dzg, dc.wt, stride=1, padding="valid")
+        for i, c in ((4, c4), (3, c3), (2, c2), (1, c1)):
+            op = self.op("mrcnn_mask_conv%d" % i)
+            dz, _ = op.epilogue_bwd(d, c)
+            op.wgrad(dz, c)
+            d = op.dgrad(dz, c)
+        B, R = rois.shape[0], rois.shape[1]
+        ops.roialign_bwd(rois, d.view(B, R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1), dP, cfg.MASK_POOL_SIZE, area)
+
+    def _class_head_bwd(self, d_logits, d_mbbox, ctxs, rois, dP, area):
+        cfg = self.cfg
+        c1, c2, c3, c4 = ctxs
+        lo, bo = self.op("mrcnn_class_logits"), self.op("mrcnn_bbox_fc")
+        M = d_logits.shape[0] * d_logits.shape[1]
+        g1 = d_logits.view(M, 1, 1, -1)
+        g2 = d_mbbox.view(M, 1, 1, -1)
+        dz, _ = lo.epilogue_bwd(g1, c3)
+        lo.wgrad(dz, c3)
+        d_h2 = lo.dgrad(dz, c3)
+        dz, _ = bo.epilogue_bwd(g2, c4)
+        bo.wgrad(dz, c4)
+        bo.dgrad(dz, c4, out=d_h2, accumulate=True)
+        op2, op1 = self.op("mrcnn_class_conv2"), self.op("mrcnn_class_conv1")
+        dz, _ = op2.epilogue_bwd(d_h2, c2)
+        op2.wgrad(dz, c2)
+        d_h1 = op2.dgrad(dz, c2)
+        dz, _ = op1.epilogue_bwd(d_h1, c1)
+        op1.wgrad(dz, c1)
+        d_pool = op1.dgrad(dz, c1)
+        B, R = rois.shape[0], rois.shape[1]
+        ops.roialign_bwd(rois, d_pool.view(B, R, cfg.POOL_SIZE, cfg.POOL_SIZE, -1), dP, cfg.POOL_SIZE, area)
+
+    def _rpn_bwd(self, d_logits, d_bbox, rpn_tape, dP):
+        na = len(self.cfg.RPN_ANCHOR_RATIOS)
+        B, A = d_logits.shape[0], d_logits.shape[1]
+        shared, cls, box = self.op("rpn_conv_shared"), self.op("rpn_class_raw"), self.op("rpn_bbox_pred")
+        dP6 = None
+        for lvl, (cs, chead, off, H, W) in enumerate(rpn_tape):
+            gl = torch.empty((B, H, W, 2 * na), dtype=torch.float32, device=self.dev)
+            gb = torch.empty((B, H, W, 4 * na), dtype=torch.float32, device=self.dev)
+            ops.copy2d(gl.data_ptr(), H * W * 2 * na * 4, d_logits.data_ptr() + off * 2 * 4, A * 2 * 4, H * W * 2 * na * 4, B)
+            ops.copy2d(gb.data_ptr(), H * W * 4 * na * 4, d_bbox.data_ptr() + off * 4 * 4, A * 4 * 4, H * W * 4 * na * 4, B)
+            acc = lvl > 0                                            # weights shared by the 5 levels
+            dz, _ = cls.epilogue_bwd(gl, chead)
+            cls.wgrad(dz, chead, accumulate=acc)
+            d_s = cls.dgrad(dz, chead)
+            dz, _ = box.epilogue_bwd(gb, chead)
+            box.wgrad(dz, chead, accumulate=acc)
+            box.dgrad(dz, chead, out=d_s, accumulate=True)
+            dz, _ = shared.epilogue_bwd(d_s, cs)
+            shared.wgrad(dz, cs, accumulate=acc)
+            if lvl < 4:
+                shared.dgrad(dz, cs, out=dP[lvl], accumulate=True)
+            else:
+                dP6 = shared.dgrad(dz, cs)
+        return dP6
+
+    # ---- FPN + backbone backward ------------------------------------------------------------------
+    def _trunk_bwd(self, dP, dP6, tape):
+        dP2, dP3, dP4, dP5 = dP
+        ops.subsample2_bwd_acc(dP6, dP5)
+        dS = {}
+        for name, g in (("fpn_p5", dP5), ("fpn_p4", dP4), ("fpn_p3", dP3), ("fpn_p2", dP2)):
+            op, c = self.op(name), tape[name]
+            dz, _ = op.epilogue_bwd(g, c)
+            op.wgrad(dz, c)
+            dS[name] = op.dgrad(dz, c)
+        d5s, d4s, d3s, d2s = dS["fpn_p5"], dS["fpn_p4"], dS["fpn_p3"], dS["fpn_p2"]
+        ops.upsample2_bwd(d2s, d3s, True)
+        ops.upsample2_bwd(d3s, d4s, True)
+        ops.upsample2_bwd(d4s, d5s, True)
+        dC = []
+        for name, g in (("fpn_c2p2", d2s), ("fpn_c3p3", d3s), ("fpn_c4p4", d4s), ("fpn_c5p5", d5s)):
+            op, c = self.op(name), tape[name]
+            dz, _ = op.epilogue_bwd(g, c)
+            op.wgrad(dz, c)
+            dC.append(op.dgrad(dz, c))
+        if self.grad_ready:
+            self.grad_ready(*self.grad_ranges["tail"])
+        d_out = dC[3]                                   # gradient w.r.t. C5
+        for si in (3, 2, 1, 0):
+            stage = self.stages[si]
+            for bi in range(len(stage) - 1, -1, -1):
+                blk = stage[bi]
+                # the first block of stage s+1 consumes C_s, whose FPN gradient is already in dC[si-1]
+                acc_buf = dC[si - 1] if (bi == 0 and si > 0) else None
+                d_out = self._block_bwd(blk, d_out, tape[id(blk)], acc_buf)
+            if self.grad_ready:
+                self.grad_ready(*self.grad_ranges[si + 2])
+        am, pre_shape = tape["pool"]
+        d_relu = ops.maxpool3x3s2_bwd(d_out, am, pre_shape)
+        c1 = self.op("conv1")
+        dz, _ = c1.epilogue_bwd(d_relu, tape["conv1"])
+        c1.wgrad(dz, tape["conv1"])
+        if self.grad_ready:
+            self.grad_ready(*self.grad_ranges["head"])
+            self.grad_ready(*self.grad_ranges["bn"])
+
+    def _block_bwd(self, blk, d_out, ctxs, acc_buf):
+        ca, cb, cc, c1c = ctxs
+        dz, dy = blk.c2c.epilogue_bwd(d_out, cc, want_dy=True)
+        blk.c2c.wgrad(dz, cc)
+        d = blk.c2c.dgrad(dz, cc)
+        dz, _ = blk.c2b.epilogue_bwd(d, cb)
+        blk.c2b.wgrad(dz, cb)
+        d = blk.c2b.dgrad(dz, cb)
+        dza, _ = blk.c2a.epilogue_bwd(d, ca)
+        blk.c2a.wgrad(dza, ca)
+        if blk.c1 is None:
+            # identity shortcut: dx = dy + dgrad_2a (in place on dy)
+            return blk.c2a.dgrad(dza, ca, out=dy, accumulate=True)
+        dz1, _ = blk.c1.epilogue_bwd(dy, c1c)
+        blk.c1.wgrad(dz1, c1c)
+        if acc_buf is not None:
+            dx = blk.c1.dgrad(dz1, c1c, out=acc_buf, accumulate=True)
+        else:
+            dx = blk.c1.dgrad(dz1, c1c)
+        return blk.c2a.dgrad(dza, ca, out=dx, accumulate=True)
+
+    # =========================================================================================
+    #  optimiser (MaskRCNN.compile, model.py:2255-2291)
+    # =========================================================================================
+    def apply_gradients(self, learning_rate, momentum, world_size=1):
+        """grads (already summed over ranks) -> /world, + L2 term, global-norm clip, SGD-momentum."""
+        cfg = self.cfg
+        ops.grad_prepare(self.grads, self.params, 1.0 / world_size, self.trainable, self.seg_offset, self.seg_numel,
+                         self.seg_l2)
+        ops.sumsq(self.grads, self.sumsq)
+        ops.sgd_momentum(self.params, self.momentum, self.grads, self.sumsq, cfg.GRADIENT_CLIP_NORM, learning_rate,
+                         momentum, self.trainable, self.seg_offset, self.seg_numel)
+        self.fold_bn()

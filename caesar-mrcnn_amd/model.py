@@ -1,0 +1,351 @@
+"""``MaskRCNN(mode, config, model_dir)`` -- the drop-in boundary of the reference
+(mrcnn/model.py:1917-2784; members used by run.py / analyze.py / sfinder.py: SURVEY.md section 8b).
+
+Same constructor, ``train`` / ``detect`` / ``detect_molded`` / ``load_weights`` / ``find_last`` /
+``get_anchors`` / ``mold_inputs`` / ``unmold_detections`` / ``set_trainable`` / ``compile`` signatures,
+same result dictionaries and the same assertion behaviour; the Keras graph behind it is replaced by
+``engine.MaskRCNNEngine`` (HIP kernels on the local MI355X).  Multi-GPU is one process per GPU
+(torchrun), not in-graph towers: ``config.GPU_COUNT`` is the world size.
+"""
+import datetime
+import logging
+import os
+import re
+
+import numpy as np
+
+from . import utils
+from .datagen import data_generator
+
+logger = logging.getLogger("mrcnn")
+
+
+def log(text, array=None):
+    if array is not None:
+        text = text.ljust(25) + "shape: {:20}  ".format(str(array.shape))
+        if array.size:
+            text += "min: {:10.5f}  max: {:10.5f}".format(array.min(), array.max())
+        else:
+            text += "min: {:10}  max: {:10}".format("", "")
+        text += "  {}".format(array.dtype)
+    print(text)
+
+
+class _GraphHandle(object):
+    """Stands where callers expect ``model.keras_model``: predict() on molded inputs and summary()."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def predict(self, inputs, verbose=0):
+        molded_images, image_metas, anchors = inputs
+        return self._o._predict_molded(molded_images, image_metas)
+
+    def summary(self):
+        lines = ["%-28s %-8s %s" % (l.name, l.kind, l.shape) for l in self._o.engine.layout.layers]
+        return "\n".join(lines + ["total trainable parameters: %d" % sum(s[2] for s in self._o.engine.layout.segments)])
+
+
+class MaskRCNN(object):
+    def __init__(self, mode, config, model_dir, device=None, weights=None, seed=0):
+        assert mode in ['training', 'inference']
+        self.mode = mode
+        self.config = config
+        self.model_dir = model_dir
+        self.set_log_dir()
+        self.engine = self.build(mode=mode, config=config, device=device, weights=weights, seed=seed)
+        self.keras_model = _GraphHandle(self)
+        self._lr, self._momentum = config.LEARNING_RATE, config.LEARNING_MOMENTUM
+
+    def print_model(self):
+        print(self.keras_model.summary())
+
+    def build(self, mode, config, device=None, weights=None, seed=0):
+        assert mode in ['training', 'inference']
+        h, w = config.IMAGE_SHAPE[:2]
+        if h / 2 ** 6 != int(h / 2 ** 6) or w / 2 ** 6 != int(w / 2 ** 6):
+            raise Exception("Image size must be dividable by 2 at least 6 times "
+                            "to avoid fractions when downscaling and upscaling."
+                            "For example, use 256, 320, 384, 448, 512, ... etc. ")
+        import torch
+        from . import _hip
+        from .engine import MaskRCNNEngine
+        _hip.lib()       # fail loudly if the kernel library is missing
+        if device is None:
+            if not torch.cuda.is_available():
+                raise _hip.HipPathError("MaskRCNN needs an MI355X (torch.cuda.is_available() is False); "
+                                        "there is no CPU execution path")
+            device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+            torch.cuda.set_device(device)
+        return MaskRCNNEngine(config, device, weights=weights, seed=seed)
+
+    # ---- checkpoints ------------------------------------------------------------------------------
+    def find_last(self):
+        """Last checkpoint of the last run under model_dir (mrcnn/model.py:2168-2195)."""
+        import errno
+        key = self.config.NAME.lower()
+        dir_names = sorted(d for d in next(os.walk(self.model_dir))[1] if d.startswith(key))
+        if not dir_names:
+            raise FileNotFoundError(errno.ENOENT, "Could not find model directory under {}".format(self.model_dir))
+        dir_name = os.path.join(self.model_dir, dir_names[-1])
+        checkpoints = sorted(f for f in next(os.walk(dir_name))[2] if f.startswith("mask_rcnn"))
+        if not checkpoints:
+            raise FileNotFoundError(errno.ENOENT, "Could not find weight files in {}".format(dir_name))
+        return os.path.join(dir_name, checkpoints[-1])
+
+    def load_weights(self, filepath, by_name=False, exclude=None):
+        """Keras-HDF5 (or .npz) weights by layer name (mrcnn/model.py:2197-2239).  ``exclude`` keeps
+        the reference's quirk: callers pass a *string* ('conv1'), so it is a substring test on the
+        layer name."""
+        from . import weights_io
+        if exclude:
+            by_name = True
+        tensors = weights_io.load(filepath)
+        if exclude:
+            tensors = {k: v for k, v in tensors.items() if k.split("/")[0] not in exclude}
+        known = self.engine.layout.offsets
+        stats = ("moving_mean", "moving_variance")
+        picked = {k: v for k, v in tensors.items() if k in known or k.split("/")[-1] in stats}
+        if not by_name and len(picked) != len(tensors):
+            raise ValueError("weight file does not match the model topology; use by_name=True")
+        self.engine.set_weights(picked, strict=False)
+        self.set_log_dir(filepath)
+
+    def save_weights(self, filepath):
+        from . import weights_io
+        weights_io.save(filepath, self.engine.get_weights(), self.engine.layout)
+
+    def get_imagenet_weights(self):
+        raise RuntimeError("get_imagenet_weights downloads from the network (mrcnn/model.py:2241-2253); "
+                           "not available offline -- pass a local weights file to load_weights()")
+
+    # ---- training set-up ----------------------------------------------------------------------------
+    def compile(self, learning_rate, momentum):
+        """Optimiser set-up (mrcnn/model.py:2255-2318): SGD(lr, momentum, clipnorm=GRADIENT_CLIP_NORM),
+        weighted losses per USE_LOSSES/LOSS_WEIGHTS and the L2/numel regulariser, all applied by
+        ``engine.apply_gradients``."""
+        self._lr, self._momentum = learning_rate, momentum
+        for name in ("rpn_class_loss", "rpn_bbox_loss", "mrcnn_class_loss", "mrcnn_bbox_loss", "mrcnn_mask_loss"):
+            if not self.config.USE_LOSSES.get(name, True):
+                print('Will not include %s in total loss ...' % name)
+        print("Optimizer SGD: lr=%f, momentum=%f, clipnorm=%f" % (learning_rate, momentum, self.config.GRADIENT_CLIP_NORM))
+        print("weight_decay=%f" % (self.config.WEIGHT_DECAY))
+
+    def set_trainable(self, layer_regex, keras_model=None, indent=0, verbose=1):
+        if verbose > 0:
+            log("Selecting layers to train")
+        self.engine.set_trainable(layer_regex)
+        if verbose > 0:
+            seen = set()
+            for (name, _, _, _, _), t in zip(self.engine.layout.segments, self.engine.trainable_host):
+                base = name.split("/")[0]
+                if t and base not in seen:
+                    seen.add(base)
+                    log("{}{:20}".format(" " * indent, base))
+
+    def get_trainable_layers(self):
+        return [l for l in self.engine.layout.layers]
+
+    def set_log_dir(self, model_path=None):
+        """Log directory + epoch counter from a checkpoint path (mrcnn/model.py:2357-2393)."""
+        self.epoch = 0
+        now = datetime.datetime.now()
+        if model_path:
+            regex = r".*[/\\][\w-]+(\d{4})(\d{2})(\d{2})T(\d{2})(\d{2})[/\\]mask\_rcnn\_[\w-]+(\d{4})\.(h5|npz)"
+            m = re.match(regex, model_path)
+            if m:
+                now = datetime.datetime(int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)),
+                                        int(m.group(5)))
+                self.epoch = int(m.group(6)) - 1 + 1
+                print('Re-starting from epoch %d' % self.epoch)
+        name = (self.config.NAME or "mrcnn").lower()
+        self.log_dir = os.path.join(self.model_dir, "{}{:%Y%m%dT%H%M}".format(name, now))
+        self.checkpoint_path = os.path.join(self.log_dir, "mask_rcnn_{}_*epoch*.h5".format(name))
+        self.checkpoint_path = self.checkpoint_path.replace("*epoch*", "{epoch:04d}")
+
+    # ---- one optimisation step (device) -------------------------------------------------------------
+    def _to_device(self, inputs, rand_keys=None):
+        import torch
+        dev = self.engine.dev
+        images, image_meta, rpn_match, rpn_bbox, gt_class_ids, gt_boxes, gt_masks = inputs
+        H, W = images.shape[1], images.shape[2]
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev, non_blocking=True)
+        # norm_boxes_graph (model.py:1971, 3003-3017), float32
+        gtn = (gt_boxes.astype(np.float32) - np.array([0., 0., 1., 1.], np.float32)) / \
+              (np.array([H, W, H, W], np.float32) - np.float32(1.0))
+        active = np.asarray(image_meta)[0, 12:].astype(np.int32)
+        if rand_keys is None:
+            rand_keys = np.random.uniform(0, 1, (images.shape[0], self.config.POST_NMS_ROIS_TRAINING))
+        return (t(images, np.float32), t(rpn_match, np.int32), t(rpn_bbox, np.float32), t(gt_class_ids, np.int32),
+                t(gtn, np.float32), t(gt_masks, np.uint8), t(active, np.int32), t(rand_keys, np.float32))
+
+    def train_on_batch(self, inputs, rand_keys=None, reducer=None, world_size=1, apply=True, keep_outputs=False):
+        """Forward + backward + (all-reduce) + SGD step on one generator batch.  Returns the five
+        losses (host array, this rank's batch means)."""
+        eng = self.engine
+        dev_inputs = self._to_device(inputs, rand_keys)
+        eng.grad_ready = reducer.ready if reducer is not None else None
+        losses = eng.forward_backward(*dev_inputs, keep_outputs=keep_outputs)
+        if reducer is not None:
+            reducer.finish()
+        if apply:
+            eng.apply_gradients(self._lr, self._momentum, world_size)
+        return losses
+
+    def train(self, train_dataset, val_dataset, learning_rate, epochs, layers, augmentation=None,
+              custom_callbacks=None, no_augmentation_sources=None, n_worker_threads=-1, class_weights=None,
+              draw_loss=False):
+        """Training loop (mrcnn/model.py:2395-2517): ``epochs`` is the total target epoch, one weight
+        file per epoch under log_dir, validation losses per epoch; returns None."""
+        assert self.mode == "training", "Create model in training mode."
+        import torch
+        from .parallel import GradReducer, allreduce_mean_scalars, init_distributed
+        rank, _, world = init_distributed()
+        cfg = self.config
+        train_gen = data_generator(train_dataset, cfg, shuffle=True, augmentation=augmentation,
+                                   batch_size=cfg.IMAGES_PER_GPU, no_augmentation_sources=no_augmentation_sources,
+                                   rank=rank, world_size=world, seed=1234)
+        val_gen = data_generator(val_dataset, cfg, shuffle=True, batch_size=cfg.IMAGES_PER_GPU, rank=rank,
+                                 world_size=world, seed=4321)
+        if rank == 0 and not os.path.exists(self.log_dir):
+            os.makedirs(self.log_dir)
+        log("\nStarting at epoch {}. LR={}\n".format(self.epoch, learning_rate))
+        log("Checkpoint Path: {}".format(self.checkpoint_path))
+        self.set_trainable(layers, verbose=1 if rank == 0 else 0)
+        self.compile(learning_rate, cfg.LEARNING_MOMENTUM)
+        reducer = GradReducer(self.engine.grads, world) if world > 1 else None
+        names = ["rpn_class_loss", "rpn_bbox_loss", "mrcnn_class_loss", "mrcnn_bbox_loss", "mrcnn_mask_loss"]
+        self.history = {"loss": [], "val_loss": []}
+        for epoch in range(self.epoch, epochs):
+            acc = torch.zeros(5, device=self.engine.dev)
+            for step in range(cfg.STEPS_PER_EPOCH):
+                inputs, _ = next(train_gen)
+                acc += self.train_on_batch(inputs, reducer=reducer, world_size=world)
+            tr = allreduce_mean_scalars(acc / cfg.STEPS_PER_EPOCH, world).cpu().numpy()
+            vacc = torch.zeros(5, device=self.engine.dev)
+            for step in range(cfg.VALIDATION_STEPS):
+                inputs, _ = next(val_gen)
+                vacc += self.train_on_batch(inputs, reducer=None, world_size=1, apply=False)
+            va = allreduce_mean_scalars(vacc / max(cfg.VALIDATION_STEPS, 1), world).cpu().numpy()
+            w = np.array(self.engine.loss_weights())
+            self.history["loss"].append(float((tr * w).sum()))
+            self.history["val_loss"].append(float((va * w).sum()))
+            if rank == 0:
+                print("Epoch %d/%d - loss: %.4f - %s - val_loss: %.4f" % (
+                    epoch + 1, epochs, self.history["loss"][-1],
+                    " - ".join("%s: %.4f" % (n, v) for n, v in zip(names, tr)), self.history["val_loss"][-1]))
+                self.save_weights(self.checkpoint_path.format(epoch=epoch + 1))
+                for cb in (custom_callbacks or []):
+                    if callable(cb):
+                        cb(epoch, dict(zip(names, tr.tolist())))
+        self.epoch = max(self.epoch, epochs)
+
+    # ---- inference ------------------------------------------------------------------------------------
+    def mold_inputs(self, images):
+        """Resize/pad, subtract MEAN_PIXEL, build image_meta (mrcnn/model.py:2519-2556)."""
+        molded_images, image_metas, windows = [], [], []
+        for image in images:
+            molded, window, scale, padding, crop = utils.resize_image(
+                image, min_dim=self.config.IMAGE_MIN_DIM, min_scale=self.config.IMAGE_MIN_SCALE,
+                max_dim=self.config.IMAGE_MAX_DIM, mode=self.config.IMAGE_RESIZE_MODE)
+            molded = utils.mold_image(molded, self.config)
+            meta = utils.compose_image_meta(0, image.shape, molded.shape, window, scale,
+                                            np.zeros([self.config.NUM_CLASSES], dtype=np.int32))
+            molded_images.append(molded)
+            windows.append(window)
+            image_metas.append(meta)
+        return np.stack(molded_images), np.stack(image_metas), np.stack(windows)
+
+    def unmold_detections(self, detections, mrcnn_mask, original_image_shape, image_shape, window):
+        """Network output -> boxes/class ids/scores/full-size masks of one image
+        (mrcnn/model.py:2558-2621)."""
+        zero_ix = np.where(detections[:, 4] == 0)[0]
+        N = zero_ix[0] if zero_ix.shape[0] > 0 else detections.shape[0]
+        boxes = detections[:N, :4]
+        class_ids = detections[:N, 4].astype(np.int32)
+        scores = detections[:N, 5]
+        masks = mrcnn_mask[np.arange(N), :, :, class_ids]
+        window = utils.norm_boxes(window, image_shape[:2])
+        wy1, wx1, wy2, wx2 = window
+        shift = np.array([wy1, wx1, wy1, wx1])
+        wh, ww = wy2 - wy1, wx2 - wx1
+        scale = np.array([wh, ww, wh, ww])
+        boxes = np.divide(boxes - shift, scale)
+        boxes = utils.denorm_boxes(boxes, original_image_shape[:2])
+        exclude_ix = np.where((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]) <= 0)[0]
+        if exclude_ix.shape[0] > 0:
+            boxes = np.delete(boxes, exclude_ix, axis=0)
+            class_ids = np.delete(class_ids, exclude_ix, axis=0)
+            scores = np.delete(scores, exclude_ix, axis=0)
+            masks = np.delete(masks, exclude_ix, axis=0)
+            N = class_ids.shape[0]
+        full_masks = [utils.unmold_mask(masks[i], boxes[i], original_image_shape) for i in range(N)]
+        full_masks = np.stack(full_masks, axis=-1) if full_masks else np.empty(tuple(original_image_shape[:2]) + (0,))
+        return boxes, class_ids, scores, full_masks
+
+    def _predict_molded(self, molded_images, image_metas):
+        """The seven outputs of the inference graph as host arrays (model.py:2156-2159)."""
+        import torch
+        eng = self.engine
+        x = torch.from_numpy(np.ascontiguousarray(molded_images, dtype=np.float32)).to(eng.dev)
+        meta = np.asarray(image_metas)
+        shape = meta[0, 4:6].astype(np.float32)          # image_shape of the first image (model.py:891-893)
+        win = (meta[:, 7:11].astype(np.float32) - np.array([0., 0., 1., 1.], np.float32)) / \
+              (np.array([shape[0], shape[1], shape[0], shape[1]], np.float32) - np.float32(1.0))
+        out = eng.infer(x, torch.from_numpy(np.ascontiguousarray(win, dtype=np.float32)).to(eng.dev))
+        torch.cuda.synchronize(eng.dev)
+        return [out[k].cpu().numpy() for k in ("detections", "mrcnn_class", "mrcnn_bbox", "mrcnn_mask", "rpn_rois",
+                                               "rpn_class", "rpn_bbox")]
+
+    def detect(self, images, verbose=0):
+        """List of [h,w,3] images -> list of {rois, class_ids, scores, masks} (mrcnn/model.py:2623-2704)."""
+        assert self.mode == "inference", "Create model in inference mode."
+        assert len(images) == self.config.BATCH_SIZE, "len(images) must be equal to BATCH_SIZE"
+        if verbose:
+            log("Processing {} images".format(len(images)))
+            for image in images:
+                log("image", image)
+        molded_images, image_metas, windows = self.mold_inputs(images)
+        image_shape = molded_images[0].shape
+        for g in molded_images[1:]:
+            assert g.shape == image_shape, \
+                "After resizing, all images must have the same size. Check IMAGE_RESIZE_MODE and image sizes."
+        if verbose:
+            log("molded_images", molded_images)
+            log("image_metas", image_metas)
+        detections, _, _, mrcnn_mask, _, _, _ = self._predict_molded(molded_images, image_metas)
+        results = []
+        for i, image in enumerate(images):
+            rois, class_ids, scores, masks = self.unmold_detections(detections[i], mrcnn_mask[i], image.shape,
+                                                                    molded_images[i].shape, windows[i])
+            results.append({"rois": rois, "class_ids": class_ids, "scores": scores, "masks": masks})
+        return results
+
+    def detect_molded(self, molded_images, image_metas, verbose=0):
+        """As detect() but on already molded inputs (mrcnn/model.py:2706-2762)."""
+        assert self.mode == "inference", "Create model in inference mode."
+        assert len(molded_images) == self.config.BATCH_SIZE, "Number of images must be equal to BATCH_SIZE"
+        image_shape = molded_images[0].shape
+        for g in molded_images[1:]:
+            assert g.shape == image_shape, "Images must have the same size"
+        detections, _, _, mrcnn_mask, _, _, _ = self._predict_molded(np.asarray(molded_images), image_metas)
+        results = []
+        for i, image in enumerate(molded_images):
+            window = [0, 0, image.shape[0], image.shape[1]]
+            rois, class_ids, scores, masks = self.unmold_detections(detections[i], mrcnn_mask[i], image.shape,
+                                                                    molded_images[i].shape, window)
+            results.append({"rois": rois, "class_ids": class_ids, "scores": scores, "masks": masks})
+        return results
+
+    def get_anchors(self, image_shape):
+        """Normalised anchor pyramid for an image shape, cached (mrcnn/model.py:2764-2784)."""
+        if not hasattr(self, "_anchor_cache"):
+            self._anchor_cache = {}
+        key = tuple(image_shape)
+        if key not in self._anchor_cache:
+            shapes = utils.compute_backbone_shapes(self.config, image_shape)
+            a = utils.generate_pyramid_anchors(self.config.RPN_ANCHOR_SCALES, self.config.RPN_ANCHOR_RATIOS, shapes,
+                                               self.config.BACKBONE_STRIDES, self.config.RPN_ANCHOR_STRIDE)
+            self.anchors = a
+            self._anchor_cache[key] = utils.norm_boxes(a, image_shape[:2])
+        return self._anchor_cache[key]

@@ -667,8 +667,11 @@ class OracleMaskRCNN(object):
         return [l1, l2, l3, l4, l5]
 
     def forward_training(self, images, rpn_match, rpn_bbox_t, gt_class_ids, gt_boxes, gt_masks, active_class_ids,
-                         anchors, rand_keys):
-        """Training graph, mrcnn/model.py:2068-2132.  gt_boxes in pixels; gt_masks [B,H,W,G]."""
+                         anchors, rand_keys, forced=None):
+        """Training graph, mrcnn/model.py:2068-2132.  gt_boxes in pixels; gt_masks [B,H,W,G].
+        `forced` = {"rois", "target_class_ids", "target_bbox", "target_mask"} replaces the (discrete,
+        gradient-free) proposal + target stages, so a test can compare the differentiable part on
+        identical ROIs."""
         cfg = self.config
         x = torch.as_tensor(images, dtype=torch.float32)
         H, W = x.shape[1], x.shape[2]
@@ -676,14 +679,19 @@ class OracleMaskRCNN(object):
         C2, C3, C4, C5 = self.backbone(x)
         pyr = self.fpn(C2, C3, C4, C5)
         rpn_logits, rpn_probs, rpn_bbox = self.rpn(pyr)
-        rpn_rois = self.proposal_layer(rpn_probs, rpn_bbox, anchors, cfg.POST_NMS_ROIS_TRAINING)
-        # norm_boxes_graph, model.py:3003-3017
-        gtn = ((gt_boxes.astype(np.float32) - np.array([0., 0., 1., 1.], np.float32)) /
-               (np.array([H, W, H, W], np.float32) - np.float32(1.0))).astype(np.float32)
-        tg = [self.detection_targets(rpn_rois[b], gt_class_ids[b], gtn[b], gt_masks[b], rand_keys[b])
-              for b in range(x.shape[0])]
-        rois = np.stack([t[0] for t in tg]); tcls = np.stack([t[1] for t in tg])
-        tbbox = np.stack([t[2] for t in tg]); tmask = np.stack([t[3] for t in tg])
+        if forced is None:
+            rpn_rois = self.proposal_layer(rpn_probs, rpn_bbox, anchors, cfg.POST_NMS_ROIS_TRAINING)
+            # norm_boxes_graph, model.py:3003-3017
+            gtn = ((gt_boxes.astype(np.float32) - np.array([0., 0., 1., 1.], np.float32)) /
+                   (np.array([H, W, H, W], np.float32) - np.float32(1.0))).astype(np.float32)
+            tg = [self.detection_targets(rpn_rois[b], gt_class_ids[b], gtn[b], gt_masks[b], rand_keys[b])
+                  for b in range(x.shape[0])]
+            rois = np.stack([t[0] for t in tg]); tcls = np.stack([t[1] for t in tg])
+            tbbox = np.stack([t[2] for t in tg]); tmask = np.stack([t[3] for t in tg])
+        else:
+            rpn_rois, tg = None, []
+            rois, tcls = forced["rois"], forced["target_class_ids"]
+            tbbox, tmask = forced["target_bbox"], forced["target_mask"]
         logits, probs, mbbox = self.classifier_head(rois, pyr[:4], image_area)
         mmask = self.mask_head(rois, pyr[:4], image_area)
         ls = self.losses(rpn_match, rpn_bbox_t, rpn_logits, rpn_bbox, tcls, tbbox, tmask, active_class_ids, logits,

@@ -1,0 +1,251 @@
+"""Graph-level parity of the HIP engine against the CPU oracle.
+
+The network's discrete stages (top-k, NMS, ROI sampling) amplify float noise into different index
+sets, so the comparison is staged ("teacher forced"): every stage of the oracle is fed the GPU's own
+inputs for that stage and must reproduce the GPU's outputs -- exactly for indices, within the stated
+tolerance for floats (fp32 contractions with a different summation order: rtol 1e-3 on activations
+that went through ~50 conv layers, 2e-3 relative to the largest entry on gradients)."""
+import numpy as np
+import pytest
+import torch
+
+import mrcnn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_cfg(backbone="custom", size=128, mode="training", **kw):
+    from caesar_mrcnn_amd.config import run_py_config
+    cfg = run_py_config(backbone=backbone, imgsize=size, mode=mode)
+    cfg.POST_NMS_ROIS_TRAINING = 1500
+    cfg.POST_NMS_ROIS_INFERENCE = 200
+    cfg.TRAIN_ROIS_PER_IMAGE = 48
+    cfg.MAX_GT_INSTANCES = 20
+    cfg.RPN_TRAIN_ANCHORS_PER_IMAGE = 64
+    cfg.DETECTION_MAX_INSTANCES = 30
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _scene(cfg, B, seed):
+    """Synthetic tiles: noise + bright boxes.  Every GT instance is laid over a (pixel-rounded) anchor of
+    scale >= 8 px so that, with RPN deltas kept small, some proposals reach IoU >= 0.5 and the
+    detection-target / mask / bbox branches are exercised."""
+    rng = np.random.default_rng(seed)
+    S = int(cfg.IMAGE_SHAPE[0])
+    G = cfg.MAX_GT_INSTANCES
+    anchors = orc.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS,
+                                           orc.compute_backbone_shapes(cfg.BACKBONE_STRIDES, cfg.IMAGE_SHAPE),
+                                           cfg.BACKBONE_STRIDES, cfg.RPN_ANCHOR_STRIDE)
+    ok = np.where((anchors[:, 0] >= 0) & (anchors[:, 1] >= 0) & (anchors[:, 2] <= S) & (anchors[:, 3] <= S) &
+                  ((anchors[:, 2] - anchors[:, 0]) >= 6) & ((anchors[:, 3] - anchors[:, 1]) >= 6))[0]
+    images = rng.normal(0, 8, (B, S, S, 3)).astype(np.float32) + 20
+    gt_masks = np.zeros((B, S, S, G), bool)
+    gt_boxes = np.zeros((B, G, 4), np.int32)
+    gt_cls = np.zeros((B, G), np.int32)
+    for b in range(B):
+        for g in range(G - 4 - b):
+            y1, x1, y2, x2 = np.round(anchors[rng.choice(ok)]).astype(int)
+            gt_masks[b, y1:y2, x1:x2, g] = True
+            gt_masks[b, (y1 + y2) // 2, (x1 + x2) // 2, g] = False
+            images[b, y1:y2, x1:x2] += rng.uniform(60, 200)
+            gt_boxes[b, g] = [y1, x1, y2, x2]
+            gt_cls[b, g] = rng.integers(1, cfg.NUM_CLASSES)
+    return images, gt_cls, gt_boxes, gt_masks
+
+
+def _train_inputs(cfg, B, seed):
+    images, gt_cls, gt_boxes, gt_masks = _scene(cfg, B, seed)
+    anchors_px = orc.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS,
+                                              orc.compute_backbone_shapes(cfg.BACKBONE_STRIDES, cfg.IMAGE_SHAPE),
+                                              cfg.BACKBONE_STRIDES, cfg.RPN_ANCHOR_STRIDE)
+    rng = np.random.RandomState(seed)
+    rpn_match = np.zeros((B, anchors_px.shape[0], 1), np.int32)
+    rpn_bbox = np.zeros((B, cfg.RPN_TRAIN_ANCHORS_PER_IMAGE, 4), np.float32)
+    for b in range(B):
+        n = int((gt_cls[b] > 0).sum())
+        m, bb = orc.build_rpn_targets(anchors_px, gt_cls[b, :n], gt_boxes[b, :n], cfg.RPN_TRAIN_ANCHORS_PER_IMAGE,
+                                      cfg.RPN_BBOX_STD_DEV, rng)
+        rpn_match[b, :, 0], rpn_bbox[b] = m, bb
+    meta = np.stack([orc.compose_image_meta(b, images[b].shape, images[b].shape, (0, 0) + images[b].shape[:2], 1.0,
+                                            np.ones(cfg.NUM_CLASSES, np.int32)) for b in range(B)])
+    keys = np.random.default_rng(seed + 1).uniform(0, 1, (B, cfg.POST_NMS_ROIS_TRAINING)).astype(np.float32)
+    return [images, meta, rpn_match, rpn_bbox, gt_cls, gt_boxes, gt_masks], keys
+
+
+def _weights(cfg, seed):
+    from caesar_mrcnn_amd.params import ParamLayout, init_weights, deconv_gemm_to_keras
+    w = init_weights(ParamLayout(cfg), seed=seed, perturb_bn=True)
+    w["mrcnn_mask_deconv/kernel"] = deconv_gemm_to_keras(w["mrcnn_mask_deconv/kernel"])   # Keras layout at the boundary
+    # keep RPN box deltas small so proposals stay near their anchors and some reach IoU >= 0.5 with the GT
+    w["rpn_bbox_pred/kernel"] = w["rpn_bbox_pred/kernel"] * np.float32(0.02)
+    w["rpn_bbox_pred/bias"] = w["rpn_bbox_pred/bias"] * np.float32(0.02)
+    return w
+
+
+def _close(got, ref, rtol, name):
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    scale = max(float(np.abs(ref).max()), 1e-12)
+    err = float(np.abs(got - ref).max()) / scale
+    assert err <= rtol, "%s: max error %.3g of max |ref| %.3g (allowed %.3g)" % (name, err, scale, rtol)
+
+
+@pytest.mark.parametrize("backbone,size", [("custom", 128), ("resnet50", 128)])
+def test_inference_graph_staged(dev, backbone, size):
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _small_cfg(backbone, size, mode="inference")
+    w = _weights(cfg, 3)
+    model = MaskRCNN("inference", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+    images, _, _, _ = _scene(cfg, 1, 7)
+    molded, metas, windows = model.mold_inputs([images[0].astype(np.float32)])
+    molded = molded.astype(np.float32)
+    win = torch.tensor(orc.norm_boxes(windows.astype(np.float32), molded.shape[1:3]), device=dev)
+    out = model.engine.infer(torch.tensor(molded, device=dev), win)
+    torch.cuda.synchronize()
+    o = orc.OracleMaskRCNN(cfg, w)
+    x = torch.tensor(molded)
+    area = float(size * size)
+    with torch.no_grad():
+        pyr = o.fpn(*o.backbone(x))
+        _, rp, rb = o.rpn(pyr)
+    for i, p in enumerate(pyr):
+        _close(out["pyramid"][i].cpu(), p, 1e-3, "P%d" % (i + 2))
+    _close(out["rpn_class"].cpu(), rp, 1e-3, "rpn_class")
+    _close(out["rpn_bbox"].cpu(), rb, 1e-3, "rpn_bbox")
+    # proposal layer on the GPU's RPN outputs
+    anchors = orc.get_anchors(cfg, molded.shape[1:])
+    np.testing.assert_array_equal(model.engine.anchors(molded.shape[1:]).cpu().numpy(), anchors)
+    np.testing.assert_array_equal(model.get_anchors(molded.shape[1:]), anchors)
+    rois_ref = o.proposal_layer(out["rpn_class"].cpu(), out["rpn_bbox"].cpu(), anchors, cfg.POST_NMS_ROIS_INFERENCE)
+    rois = out["rpn_rois"].cpu().numpy()
+    # allow a handful of ulp-level NMS flips; rows must agree for >= 98 %
+    same = np.mean(np.all(np.abs(rois - rois_ref) < 1e-5, axis=-1))
+    assert same >= 0.98, same
+    # heads on the GPU's ROIs and the GPU's pyramid
+    gp = [p.cpu() for p in out["pyramid"][:4]]
+    with torch.no_grad():
+        _, probs, bbox = o.classifier_head(rois, gp, area)
+    _close(out["mrcnn_class"].cpu(), probs, 1e-3, "mrcnn_class")
+    _close(out["mrcnn_bbox"].cpu(), bbox, 1e-3, "mrcnn_bbox")
+    det_ref = o.refine_detections(rois[0], out["mrcnn_class"][0].cpu().numpy(), out["mrcnn_bbox"][0].cpu().numpy(),
+                                  win[0].cpu().numpy())
+    det = out["detections"][0].cpu().numpy()
+    np.testing.assert_array_equal(det[:, 4:], det_ref[:, 4:])
+    np.testing.assert_allclose(det[:, :4], det_ref[:, :4], atol=2e-6)
+    with torch.no_grad():
+        masks = o.mask_head(det[None, :, :4], gp, area)
+    _close(out["mrcnn_mask"].cpu(), masks, 1e-3, "mrcnn_mask")
+    # the public entry point returns the reference's result structure
+    res = model.detect([images[0].astype(np.float32)])[0]
+    assert set(res) == {"rois", "class_ids", "scores", "masks"}
+    assert res["masks"].shape[:2] == images[0].shape[:2] and res["masks"].shape[2] == res["rois"].shape[0]
+
+
+@pytest.mark.parametrize("backbone,size,dice", [("custom", 128, False), ("resnet50", 128, False), ("custom", 128, True)])
+def test_training_step_staged(dev, backbone, size, dice):
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _small_cfg(backbone, size, MASK_LOSS_FUNCTION="dice_coef_loss" if dice else "binary_crossentropy")
+    cfg.LOSS_WEIGHTS = dict(cfg.LOSS_WEIGHTS, rpn_bbox_loss=0.7, mrcnn_mask_loss=1.3)
+    B = 2
+    w = _weights(cfg, 11)
+    model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+    inputs, keys = _train_inputs(cfg, B, 5)
+    losses = model.train_on_batch(inputs, rand_keys=keys, apply=False, keep_outputs=True)
+    torch.cuda.synchronize()
+    eng = model.engine
+    last = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in eng.last.items() if k != "pyramid"}
+    images, meta, rpn_match, rpn_bbox_t, gt_cls, gt_boxes, gt_masks = inputs
+    o = orc.OracleMaskRCNN(cfg, w, requires_grad=True)
+    anchors = orc.get_anchors(cfg, images.shape[1:])
+    # (a) sampling stage on the GPU's proposals
+    S = float(size)
+    gtn = ((gt_boxes.astype(np.float32) - np.array([0, 0, 1, 1], np.float32)) / np.float32(S - 1)).astype(np.float32)
+    npos = 0
+    for b in range(B):
+        r_rois, r_cls, r_bb, r_m, (P, N) = o.detection_targets(last["rpn_rois"][b], gt_cls[b], gtn[b], gt_masks[b], keys[b])
+        assert tuple(last["counts"][b]) == (P, N)
+        np.testing.assert_array_equal(last["rois"][b], r_rois)
+        np.testing.assert_array_equal(last["target_class_ids"][b], r_cls)
+        np.testing.assert_allclose(last["target_bbox"][b], r_bb, rtol=1e-5, atol=1e-5)
+        assert np.mean(last["target_mask"][b] != r_m) < 1e-3
+        npos += P
+    assert npos > 0, "scene produced no positive ROIs; the mask/bbox losses would be untested"
+    # (b) differentiable part on identical ROIs / targets
+    forced = {k: last[k] for k in ("rois", "target_class_ids", "target_bbox", "target_mask")}
+    ref = o.forward_training(images, rpn_match, rpn_bbox_t.astype(np.float32), gt_cls, gt_boxes, gt_masks,
+                             meta[:, 12:].astype(np.int32), anchors, keys, forced=forced)
+    _close(last["rpn_class_logits"], ref["rpn_class_logits"].detach(), 1e-3, "rpn_class_logits")
+    _close(last["mrcnn_class_logits"], ref["mrcnn_class_logits"].detach(), 1e-3, "mrcnn_class_logits")
+    _close(last["mrcnn_mask"], ref["mrcnn_mask"].detach(), 1e-3, "mrcnn_mask")
+    np.testing.assert_allclose(losses.cpu().numpy(), [float(l.detach()) for l in ref["losses"]], rtol=2e-3, atol=1e-5)
+    total = o.total_loss(ref["losses"])
+    total.backward()
+    g = eng.get_weights(grads=True)
+    # the GPU buffer holds the data gradients; the regulariser is added by grad_prepare -> compare after it
+    eng.apply_gradients(0.0, 0.0, world_size=1)      # lr = 0: only prepares (adds L2) and clips into eng.grads
+    torch.cuda.synchronize()
+    g = eng.get_weights(grads=True)
+    gnorm = float(eng.sumsq.sqrt())
+    ref_sq = 0.0
+    bad = []
+    for name in eng.layout.offsets:
+        rg = o.w[name].grad
+        assert rg is not None, name
+        rg = rg.numpy()
+        ref_sq += float((rg.astype(np.float64) ** 2).sum())
+        scale = max(float(np.abs(rg).max()), 1e-8)
+        err = float(np.abs(g[name] - rg).max()) / scale
+        if err > 5e-3:
+            bad.append((name, err, scale))
+    assert not bad, "gradient mismatch (name, rel err, max|ref|): %s" % bad[:8]
+    np.testing.assert_allclose(gnorm, np.sqrt(ref_sq), rtol=1e-3)
+
+
+def test_optimizer_update_matches_oracle(dev):
+    """grad_prepare + global-norm clip + SGD-momentum on the real flat buffer."""
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _small_cfg("custom", 128)
+    w = _weights(cfg, 13)
+    model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+    eng = model.engine
+    rng = np.random.default_rng(3)
+    G = (rng.standard_normal(eng.layout.total) * 0.05).astype(np.float32)
+    V = (rng.standard_normal(eng.layout.total) * 0.01).astype(np.float32)
+    live = np.zeros(eng.layout.total, bool)          # alignment padding between tensors carries no gradient
+    for _, off, n, _, _ in eng.layout.segments:
+        live[off:off + n] = True
+    G[~live] = 0
+    eng.grads.copy_(torch.tensor(G)); eng.momentum.copy_(torch.tensor(V))
+    world = 4
+    params = {k: np.asarray(v, np.float32).copy() for k, v in eng.get_weights().items() if k in eng.layout.offsets}
+    grads, vel = {}, {}
+    for name, (off, n, shape) in eng.layout.offsets.items():
+        p = eng.params[off:off + n].cpu().numpy()
+        l2 = 0.0 if ("gamma" in name or "beta" in name) else 2.0 * cfg.WEIGHT_DECAY / n
+        grads[name] = G[off:off + n] * np.float32(1.0 / world) + np.float32(l2) * p
+        vel[name] = V[off:off + n].copy()
+        params[name] = p.copy()
+    eng.apply_gradients(0.01, 0.9, world_size=world)
+    torch.cuda.synchronize()
+    norm = orc.sgd_step(params, grads, vel, 0.01, 0.9, cfg.GRADIENT_CLIP_NORM)
+    assert norm > cfg.GRADIENT_CLIP_NORM            # the clip is active in this test
+    np.testing.assert_allclose(float(eng.sumsq.sqrt()), norm, rtol=1e-4)
+    for name, (off, n, shape) in eng.layout.offsets.items():
+        np.testing.assert_allclose(eng.params[off:off + n].cpu().numpy(), params[name], rtol=1e-5, atol=1e-6, err_msg=name)
+        np.testing.assert_allclose(eng.momentum[off:off + n].cpu().numpy(), vel[name], rtol=1e-5, atol=1e-7, err_msg=name)
+
+
+def test_frozen_layers_and_heads_preset(dev):
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _small_cfg("custom", 128)
+    model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=_weights(cfg, 17))
+    model.set_trainable("heads", verbose=0)
+    before = model.engine.params.clone()
+    inputs, keys = _train_inputs(cfg, 2, 9)
+    model.compile(0.01, 0.9)
+    model.train_on_batch(inputs, rand_keys=keys)
+    torch.cuda.synchronize()
+    changed = (model.engine.params != before).cpu().numpy()
+    for (name, off, n, _, _), t in zip(model.engine.layout.segments, model.engine.trainable_host):
+        assert changed[off:off + n].any() == bool(t) or (t and n < 8), name
