@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mask R-CNN training throughput (images/s, whole job) and detect latency on
+synthetic 256x256 3-class radio tiles, float32, on N MI355X of one node (one process per GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = forward + backward + gradient all-reduce (N > 1) + SGD update on IMAGES_PER_GPU images per
+rank, inputs resident in HBM.  Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def synthetic_batch(cfg, B, seed):
+    """Noise tiles + elliptical Gaussian sources with masks/boxes/classes and RPN targets
+    (SURVEY section 8d synthetic inputs; already 'molded': float32, MEAN_PIXEL = 0)."""
+    from caesar_mrcnn_amd import utils
+    from caesar_mrcnn_amd.datagen import build_rpn_targets
+    rng = np.random.RandomState(seed)
+    S, G = int(cfg.IMAGE_SHAPE[0]), cfg.MAX_GT_INSTANCES
+    anchors = utils.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS,
+                                             utils.compute_backbone_shapes(cfg, cfg.IMAGE_SHAPE),
+                                             cfg.BACKBONE_STRIDES, cfg.RPN_ANCHOR_STRIDE)
+    images = np.zeros((B, S, S, 3), np.float32)
+    gt_masks = np.zeros((B, S, S, G), bool)
+    gt_boxes = np.zeros((B, G, 4), np.int32)
+    gt_cls = np.zeros((B, G), np.int32)
+    rpn_match = np.zeros((B, anchors.shape[0], 1), np.int32)
+    rpn_bbox = np.zeros((B, cfg.RPN_TRAIN_ANCHORS_PER_IMAGE, 4), np.float32)
+    yy, xx = np.mgrid[0:S, 0:S]
+    for b in range(B):
+        img = rng.normal(0, 1, (S, S))
+        n = rng.randint(1, 7)
+        for g in range(n):
+            cy, cx = rng.uniform(12, S - 12, 2)
+            sy, sx = rng.uniform(1.5, 12, 2)
+            blob = np.exp(-0.5 * (((yy - cy) / sy) ** 2 + ((xx - cx) / sx) ** 2))
+            img += blob * rng.uniform(5, 200)
+            m = blob > 0.2
+            gt_masks[b, :, :, g] = m
+            gt_boxes[b, g] = utils.extract_bboxes(m[:, :, None])[0]
+            gt_cls[b, g] = rng.randint(1, cfg.NUM_CLASSES)
+        lo, hi = np.percentile(img, [1, 99.5])
+        img8 = np.clip((img - lo) / max(hi - lo, 1e-6), 0, 1) * 255.0      # stretch -> uint8-range RGB tile
+        images[b] = np.round(img8)[..., None]
+        m_, bb = build_rpn_targets(images[b].shape, anchors, gt_cls[b, :n], gt_boxes[b, :n], cfg, rng)
+        rpn_match[b, :, 0], rpn_bbox[b] = m_, bb
+    meta = np.stack([utils.compose_image_meta(b, (S, S, 3), (S, S, 3), (0, 0, S, S), 1.0,
+                                              np.ones(cfg.NUM_CLASSES, np.int32)) for b in range(B)])
+    return [images, meta, rpn_match, rpn_bbox, gt_cls, gt_boxes, gt_masks]
+
+
+def cpu_baseline(cfg, weights, batch, cores):
+    """The CPU oracle (restatement of the reference graph; NOT TensorFlow) on one image: forward +
+    backward + total-loss gradient, timed on the host cores.  Reported, never the target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch
+    import mrcnn_oracle as orc
+    torch.set_num_threads(cores)
+    one = [np.ascontiguousarray(a[:1]) for a in batch]
+    images, meta, rpn_match, rpn_bbox, gt_cls, gt_boxes, gt_masks = one
+    o = orc.OracleMaskRCNN(cfg, weights, requires_grad=True)
+    anchors = orc.get_anchors(cfg, images.shape[1:])
+    keys = np.random.RandomState(0).uniform(0, 1, (1, cfg.POST_NMS_ROIS_TRAINING)).astype(np.float32)
+    t0 = time.time()
+    ref = o.forward_training(images, rpn_match, rpn_bbox.astype(np.float32), gt_cls, gt_boxes, gt_masks,
+                             meta[:, 12:].astype(np.int32), anchors, keys)
+    o.total_loss(ref["losses"]).backward()
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "1 training step (fwd+bwd) on 1 image of the same workload, CPU oracle (torch-CPU fp32 "
+                      "restatement of the reference graph, not TF1), %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--backbone", default="resnet50")
+    ap.add_argument("--imgsize", type=int, default=256)
+    ap.add_argument("--nimg", type=int, default=2, help="images per GPU (IMAGES_PER_GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--detect-iters", type=int, default=10)
+    args = ap.parse_args()
+
+    import torch
+    from caesar_mrcnn_amd import ops
+    from caesar_mrcnn_amd.config import run_py_config
+    from caesar_mrcnn_amd.model import MaskRCNN
+    from caesar_mrcnn_amd.parallel import GradReducer, init_distributed
+    import torch.distributed as dist
+
+    rank, local_rank, world = init_distributed()
+    if world != args.gpus:
+        if rank == 0:
+            sys.stderr.write("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n" % (args.gpus, world))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    cfg = run_py_config(num_classes=4, imgsize=args.imgsize, backbone=args.backbone, images_per_gpu=args.nimg,
+                        gpu_count=world)
+    model = MaskRCNN("training", cfg, "/tmp/mrcnn_bench_logs", device=dev, seed=0)
+    model.compile(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM)
+    batch = synthetic_batch(cfg, args.nimg, seed=1234 + rank)
+    dev_inputs = model._to_device(batch)
+    eng = model.engine
+    reducer = GradReducer(eng.grads, world) if world > 1 else None
+    eng.grad_ready = reducer.ready if reducer else None
+
+    def step():
+        losses = eng.forward_backward(*dev_inputs)
+        if reducer:
+            reducer.finish()
+        eng.apply_gradients(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM, world)
+        return losses
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        losses = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    images_per_s = args.nimg * world * args.steps / dt
+    final_losses = [float(v) for v in losses.cpu().numpy()]
+
+    if rank == 0:
+        # ---- detect latency (inference graph, batch 1), same weights -------------------------------
+        x1 = dev_inputs[0][:1].contiguous()
+        win = torch.tensor([[0.0, 0.0, 1.0, 1.0]], device=dev)
+        icfg = run_py_config(num_classes=4, imgsize=args.imgsize, backbone=args.backbone, mode="inference")
+        eng.cfg = icfg
+        for _ in range(2):
+            eng.infer(x1, win)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        for _ in range(args.detect_iters):
+            eng.infer(x1, win)
+        torch.cuda.synchronize()
+        detect_ms = (time.time() - t1) / args.detect_iters * 1e3
+        eng.cfg = cfg
+
+        # ---- roofline of the dominant kernel: the mask-head 3x3 convolution (fwd instance) ----------
+        M_rois = args.nimg * cfg.TRAIN_ROIS_PER_IMAGE
+        xm = torch.randn((M_rois, 14, 14, 256), device=dev)
+        wm = torch.randn((3, 3, 256, 256), device=dev) * 0.02
+        bm = torch.zeros(256, device=dev)
+        sc = torch.ones(256, device=dev)
+        om = torch.empty((M_rois, 14, 14, 256), device=dev)
+        for _ in range(3):
+            ops.conv2d(xm, wm, bm, sc, bm, act=1, out=om)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 20
+        e0.record()
+        for _ in range(reps):
+            ops.conv2d(xm, wm, bm, sc, bm, act=1, out=om)
+        e1.record()
+        torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / reps
+        flops = 2.0 * (M_rois * 196) * 256 * 2304
+        achieved = flops / (k_ms * 1e-3) / 1e12
+        peak = 157.3
+
+        out = {
+            "metric": "train images/sec (whole node) + detect ms/image, ResNet-101 256x256",
+            "value": round(images_per_s, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s+FPN %dx%d 3-class (+bg), nimg_per_gpu=%d, train step (fwd+bwd+SGD%s), "
+                                   "512 train ROIs, 2000 proposals" % (args.backbone, args.imgsize, args.imgsize, args.nimg,
+                                                                       "+RCCL all-reduce" if world > 1 else ""),
+                       "global_batch": args.nimg * world, "parallelism": "dp%d" % world,
+                       "weights": "random init (Keras defaults)"},
+            "detect_ms_per_image": round(detect_ms, 3),
+            "losses_last_step": [round(v, 5) for v in final_losses],
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "kernel": "conv_fwd_kernel<128,128,2,2> (mask-head 3x3 conv, M=%d N=256 K=2304, "
+                                   "%.1f GFLOP/launch, %.3f ms/launch)" % (M_rois * 196, flops / 1e9, k_ms)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                cores = len(os.sched_getaffinity(0))
+                wts = eng.get_weights()
+                out["cpu_baseline"] = cpu_baseline(cfg, wts, batch, cores)
+            except Exception as e:      # the baseline is a report, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
