@@ -199,7 +199,7 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             try:
-                cores = len(os.sched_getaffinity(0))
+                cores = min(16, len(os.sched_getaffinity(0)))   # the GPU box grants 16 host cores per GPU
                 wts = eng.get_weights()
                 out["cpu_baseline"] = cpu_baseline(cfg, wts, batch, cores)
             except Exception as e:      # the baseline is a report, never a reason to lose the GPU number

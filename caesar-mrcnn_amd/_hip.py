@@ -55,6 +55,8 @@ OUT_NHWC, OUT_DECONV2 = 0, 1
 _P = C.c_void_p
 _SIGNATURES = {
     "mrcnn_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 9),
+    "mrcnn_conv2d_fwd_ws": (C.c_int, [C.POINTER(ConvDesc)] + [_P] * 9 + [C.c_size_t, _P]),
+    "mrcnn_conv2d_fwd_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "mrcnn_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, C.c_size_t, C.c_int, _P]),
     "mrcnn_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "mrcnn_weight_flip_transpose": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

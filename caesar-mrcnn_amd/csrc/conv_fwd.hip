@@ -18,6 +18,7 @@ struct ConvArgs {
     int act, res_mode, out_mode, cmod;
     long long ons, ohs, ows;
     int M, Ktot, nk, fastA, vecB, dense;
+    float* slab; int ksplit, ksteps;   // split-K: partial sums [ksplit][M][Cout], K-steps per split
 };
 
 // One 32x32 accumulator tile: lane holds column n, rows mbase + (r&3) + 8*(r>>2).
@@ -76,8 +77,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int ntiles = (p.Cout + BN - 1) / BN;
-    const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x % ntiles;
+    const int mtiles = (p.M + BM - 1) / BM;
+    const int kz = blockIdx.x / (mtiles * ntiles);
+    const int tile = blockIdx.x - kz * (mtiles * ntiles);
+    const int mtile = tile / ntiles, ntile = tile % ntiles;
     const int m0 = mtile * BM, n0 = ntile * BN;
+    const int ks_begin = kz * p.ksteps;
+    const int ks_end = (ks_begin + p.ksteps < p.nk) ? ks_begin + p.ksteps : p.nk;
 
     // ---- per-thread A row bookkeeping -------------------------------------------------------
     const int a_c4 = tid & 7;
@@ -99,6 +105,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
 
     f32x4 ra[AV], rb[BV];
     int kh = 0, kw = 0, ci0 = 0;   // fast-path K-step position
+    if (p.fastA && ks_begin > 0) {
+        const int k0 = ks_begin * 32, tap = k0 / p.Cin;
+        ci0 = k0 - tap * p.Cin;
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
+    }
 
     auto load_tiles = [&](int ks) {
         if (p.fastA) {
@@ -171,11 +183,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int li = lane & 31, lh = lane >> 5;
-    load_tiles(0);
+    load_tiles(ks_begin);
     store_tiles();
     __syncthreads();
-    for (int ks = 0; ks < p.nk; ++ks) {
-        if (ks + 1 < p.nk) load_tiles(ks + 1);
+    for (int ks = ks_begin; ks < ks_end; ++ks) {
+        if (ks + 1 < ks_end) load_tiles(ks + 1);
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             f32x4 av[TM];
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
             }
         }
         __syncthreads();
-        if (ks + 1 < p.nk) {
+        if (ks + 1 < ks_end) {
             store_tiles();
             __syncthreads();
         }
@@ -204,22 +216,124 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
 
     // ---- epilogue: bias, frozen-BN affine, residual, activation ---------------------------------
     const int mw0 = m0 + wm * TM * 32 + 4 * lh, nw0 = n0 + wn * TN * 32 + li;
+    if (p.ksplit > 1) {
+        float* slab = p.slab + (long long)kz * p.M * p.Cout;
+        auto put = [&](const f32x16& c, int mbase, int n) {
+            if (n >= p.Cout) return;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m < p.M) slab[(long long)m * p.Cout + n] = c[r];
+            }
+        };
+        if constexpr (TM >= 1 && TN >= 1) put(acc[0][0], mw0, nw0);
+        if constexpr (TM >= 1 && TN >= 2) put(acc[0][1], mw0, nw0 + 32);
+        if constexpr (TM >= 2 && TN >= 1) put(acc[1][0], mw0 + 32, nw0);
+        if constexpr (TM >= 2 && TN >= 2) put(acc[1][1], mw0 + 32, nw0 + 32);
+        return;
+    }
     if constexpr (TM >= 1 && TN >= 1) conv_epilogue_tile(p, acc[0][0], mw0, nw0);
     if constexpr (TM >= 1 && TN >= 2) conv_epilogue_tile(p, acc[0][1], mw0, nw0 + 32);
     if constexpr (TM >= 2 && TN >= 1) conv_epilogue_tile(p, acc[1][0], mw0 + 32, nw0);
     if constexpr (TM >= 2 && TN >= 2) conv_epilogue_tile(p, acc[1][1], mw0 + 32, nw0 + 32);
 }
 
+// Second pass of split-K: sum the slabs in a fixed order, then the ordinary epilogue.
+__global__ void conv_splitk_epilogue_kernel(const ConvArgs p) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)p.M * p.Cout) return;
+    const int m = (int)(i / p.Cout), n = (int)(i - (long long)m * p.Cout);
+    float a = 0.f;
+    for (int k = 0; k < p.ksplit; ++k) a += p.slab[(long long)k * p.M * p.Cout + i];
+    const int c = n % p.cmod;
+    float zv = a + (p.bias ? p.bias[c] : 0.f);
+    const float sc = p.scale ? p.scale[c] : 1.f, sh = p.scale ? p.shift[c] : 0.f;
+    const int ohw = p.OH * p.OW;
+    long long addr, raddr;
+    if (p.dense && p.res_mode != MRCNN_RES_UP2) {
+        addr = i;
+        raddr = i;
+    } else {
+        int ni = m / ohw, rem = m - ni * ohw;
+        int oh = rem / p.OW, ow = rem - oh * p.OW;
+        if (p.out_mode == MRCNN_OUT_DECONV2) {
+            int ab = n / p.cmod;
+            addr = (long long)ni * p.ons + (long long)(2 * oh + (ab >> 1)) * p.ohs + (long long)(2 * ow + (ab & 1)) * p.ows + c;
+        } else {
+            addr = (long long)ni * p.ons + (long long)oh * p.ohs + (long long)ow * p.ows + n;
+        }
+        raddr = addr;
+        if (p.res_mode == MRCNN_RES_UP2)
+            raddr = (((long long)ni * (p.OH >> 1) + (oh >> 1)) * (p.OW >> 1) + (ow >> 1)) * p.Cout + n;
+    }
+    if (p.z) p.z[addr] = zv;
+    float y = sc * zv + sh;
+    if (p.res_mode != MRCNN_RES_NONE) y += p.res[raddr];
+    if (p.act == MRCNN_ACT_RELU) y = fmaxf(y, 0.f);
+    else if (p.act == MRCNN_ACT_SIGMOID) y = 1.f / (1.f + expf(-y));
+    p.out[addr] = y;
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
     const int mt = (a.M + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN>), dim3((unsigned)(mt * nt)), dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);
+    if (a.ksplit > 1) {
+        const long long n = (long long)a.M * a.Cout;
+        hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, a);
+    }
     return mrcnn_launch_status();
 }
 
-extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc* d, const float* x, const float* w,
-                                const float* bias, const float* scale, const float* shift,
-                                const float* res, float* out, float* z_out, void* stream) {
+struct ConvPlan { int bm, bn, ksplit, ksteps; };
+
+// Tile + split-K choice.  Large problems: 128-row tiles, no split.  Small feature maps (C3..C5, P3..P6
+// at 256^2 inputs) have only 4..128 output tiles, far fewer than the 256 CUs, so the K loop is cut into
+// up to 16 slices that run as separate workgroups (slabs summed by conv_splitk_epilogue_kernel).
+static ConvPlan plan_conv(const mrcnn_conv_desc* d) {
+    ConvPlan pl;
+    const long long M = (long long)d->N * d->OH * d->OW;
+    const int Cout = d->Cout;
+    const int nk = (d->KH * d->KW * d->Cin + 31) / 32;
+    long long blocks;
+    if (Cout <= 32) {
+        pl.bn = 32;
+        pl.bm = ((M + 127) / 128 >= 256) ? 128 : 64;
+    } else if (Cout <= 64) {
+        pl.bn = 64;
+        pl.bm = ((M + 127) / 128 >= 256) ? 128 : 64;
+    } else {
+        pl.bn = 128;
+        pl.bm = (((M + 127) / 128) * ((Cout + 127) / 128) >= 256) ? 128 : 64;
+        if (pl.bm == 64 && ((M + 63) / 64) * ((Cout + 127) / 128) < 128) pl.bn = 64;   // more, smaller tiles
+    }
+    blocks = ((M + pl.bm - 1) / pl.bm) * ((Cout + pl.bn - 1) / pl.bn);
+    pl.ksplit = 1;
+    pl.ksteps = nk;
+    if (blocks < 192 && nk >= 8) {
+        long long want = (512 + blocks - 1) / blocks;          // aim at ~2 workgroups per CU
+        long long maxs = nk / 4;                               // at least 4 K-steps per slice
+        long long ks = want < maxs ? want : maxs;
+        if (ks > 16) ks = 16;
+        if (ks >= 2) {
+            pl.ksteps = (int)((nk + ks - 1) / ks);
+            pl.ksplit = (nk + pl.ksteps - 1) / pl.ksteps;
+        }
+    }
+    return pl;
+}
+
+extern "C" size_t mrcnn_conv2d_fwd_workspace(const mrcnn_conv_desc* d) {
+    if (!d || d->N <= 0 || d->OH <= 0 || d->OW <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->Cin <= 0) return 0;
+    ConvPlan pl = plan_conv(d);
+    if (pl.ksplit <= 1) return 0;
+    return (size_t)pl.ksplit * d->N * d->OH * d->OW * d->Cout * sizeof(float);
+}
+
+extern "C" int mrcnn_conv2d_fwd_ws(const mrcnn_conv_desc* d, const float* x, const float* w,
+                                   const float* bias, const float* scale, const float* shift,
+                                   const float* res, float* out, float* z_out, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
     if (!d || !x || !w || !out) return MRCNN_ERR_ARG;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 ||
         d->stride <= 0 || d->OH <= 0 || d->OW <= 0 || d->cmod <= 0)
@@ -248,16 +362,20 @@ extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc* d, const float* x, const 
               d->out_h_stride == (int64_t)d->OW * d->Cout && d->out_n_stride == (int64_t)d->OH * d->OW * d->Cout;
     hipStream_t s = (hipStream_t)stream;
 
-    const int Cout = d->Cout;
-    if (Cout <= 32) {
-        long long blocks128 = (M + 127) / 128;
-        return blocks128 >= 256 ? launch_conv<128, 32, 4, 1>(a, s) : launch_conv<64, 32, 2, 1>(a, s);
-    } else if (Cout <= 64) {
-        long long blocks128 = (M + 127) / 128;
-        return blocks128 >= 256 ? launch_conv<128, 64, 2, 2>(a, s) : launch_conv<64, 64, 2, 2>(a, s);
-    } else {
-        long long nt = (Cout + 127) / 128;
-        long long blocks128 = ((M + 127) / 128) * nt;
-        return blocks128 >= 256 ? launch_conv<128, 128, 2, 2>(a, s) : launch_conv<64, 128, 2, 2>(a, s);
+    ConvPlan pl = plan_conv(d);
+    const size_t need = pl.ksplit > 1 ? (size_t)pl.ksplit * M * d->Cout * sizeof(float) : 0;
+    if (need && (!workspace || workspace_bytes < need)) {        // no room: run unsplit
+        pl.ksplit = 1;
+        pl.ksteps = a.nk;
     }
+    a.ksplit = pl.ksplit; a.ksteps = pl.ksteps; a.slab = (float*)workspace;
+    if (pl.bn == 32) return pl.bm == 128 ? launch_conv<128, 32, 4, 1>(a, s) : launch_conv<64, 32, 2, 1>(a, s);
+    if (pl.bn == 64) return pl.bm == 128 ? launch_conv<128, 64, 2, 2>(a, s) : launch_conv<64, 64, 2, 2>(a, s);
+    return pl.bm == 128 ? launch_conv<128, 128, 2, 2>(a, s) : launch_conv<64, 128, 2, 2>(a, s);
+}
+
+extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc* d, const float* x, const float* w,
+                                const float* bias, const float* scale, const float* shift,
+                                const float* res, float* out, float* z_out, void* stream) {
+    return mrcnn_conv2d_fwd_ws(d, x, w, bias, scale, shift, res, out, z_out, nullptr, 0, stream);
 }

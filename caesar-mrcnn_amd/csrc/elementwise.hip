@@ -67,6 +67,71 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(
     }
 }
 
+// Vector form for C = 4 * 2^k (every BatchNorm layer of the graph): a thread owns one float4 channel
+// group and walks rows with stride 256/(C/4); sums stay in registers until one LDS + one global atomic
+// per channel per workgroup.
+__global__ __launch_bounds__(256) void epilogue_bwd_vec_kernel(
+    const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ z,
+    const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ rstd,
+    float* dy_out, float* dz_out, float* dgamma, float* dbeta, float* dbias, int64_t M, int C, int act,
+    int64_t rows_per_block) {
+    extern __shared__ float sacc[];   // [3][C]
+    for (int c = threadIdx.x; c < 3 * C; c += 256) sacc[c] = 0.f;
+    __syncthreads();
+    const int c4n = C >> 2;
+    const int L = c4n < 256 ? c4n : 256;          // lanes per row (power of two)
+    const int R = 256 / L;                        // rows in flight
+    const int rsub = threadIdx.x / L, lane = threadIdx.x % L;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    const bool need_stats = dgamma || dbeta;
+    for (int cg = lane; cg < c4n; cg += L) {
+        const int c = cg * 4;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, mu = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+        if (scale) sc = *(const f32x4*)(scale + c);
+        if (dgamma) { mu = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c); }
+        f32x4 a_db = {0.f, 0.f, 0.f, 0.f}, a_dg = a_db, a_bias = a_db;
+        for (int64_t r = r0 + rsub; r < r1; r += R) {
+            const int64_t e = r * C + c;
+            f32x4 g = *(const f32x4*)(dout + e);
+            if (act == MRCNN_ACT_RELU) {
+                f32x4 o = *(const f32x4*)(out + e);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = o[k] > 0.f ? g[k] : 0.f;
+            } else if (act == MRCNN_ACT_SIGMOID) {
+                f32x4 o = *(const f32x4*)(out + e);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = g[k] * o[k] * (1.f - o[k]);
+            }
+            if (dy_out) *(f32x4*)(dy_out + e) = g;
+            f32x4 dz;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) dz[k] = g[k] * sc[k];
+            if (dz_out) *(f32x4*)(dz_out + e) = dz;
+            if (dgamma) {
+                f32x4 zz = *(const f32x4*)(z + e);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a_dg[k] += g[k] * (zz[k] - mu[k]) * rs[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a_db[k] += g[k]; a_bias[k] += dz[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (need_stats) atomicAdd(&sacc[c + k], a_db[k]);
+            if (dgamma) atomicAdd(&sacc[C + c + k], a_dg[k]);
+            if (dbias) atomicAdd(&sacc[2 * C + c + k], a_bias[k]);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        if (dbeta) atomicAdd(&dbeta[c], sacc[c]);
+        if (dgamma) atomicAdd(&dgamma[c], sacc[C + c]);
+        if (dbias) atomicAdd(&dbias[c], sacc[2 * C + c]);
+    }
+}
+
 extern "C" int mrcnn_epilogue_bwd(const float* dout, const float* out, const float* z, const float* scale,
                                   const float* mean, const float* rstd, float* dy_out, float* dz_out,
                                   float* dgamma, float* dbeta, float* dbias, int64_t M, int C, int act,
@@ -79,9 +144,16 @@ extern "C" int mrcnn_epilogue_bwd(const float* dout, const float* out, const flo
     int64_t min_rows = cdiv64(4096, C);
     if (rows_per_block < min_rows) rows_per_block = min_rows;
     unsigned grid = (unsigned)cdiv64(M, rows_per_block);
-    hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(grid), dim3(256), 3 * C * sizeof(float), (hipStream_t)stream,
-                       dout, out, z, scale, mean, rstd, dy_out, dz_out, dgamma, dbeta, dbias, M, C, act,
-                       rows_per_block);
+    const bool pow2 = C >= 16 && (C & (C - 1)) == 0;
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (pow2 && al(dout) && al(out) && al(z) && al(scale) && al(mean) && al(rstd) && al(dy_out) && al(dz_out))
+        hipLaunchKernelGGL(epilogue_bwd_vec_kernel, dim3(grid), dim3(256), 3 * C * sizeof(float), (hipStream_t)stream,
+                           dout, out, z, scale, mean, rstd, dy_out, dz_out, dgamma, dbeta, dbias, M, C, act,
+                           rows_per_block);
+    else
+        hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(grid), dim3(256), 3 * C * sizeof(float), (hipStream_t)stream,
+                           dout, out, z, scale, mean, rstd, dy_out, dz_out, dgamma, dbeta, dbias, M, C, act,
+                           rows_per_block);
     return mrcnn_launch_status();
 }
 

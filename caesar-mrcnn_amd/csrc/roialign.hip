@@ -93,12 +93,16 @@ __global__ __launch_bounds__(256) void roialign_kernel(const RoiArgs p) {
         const float* g = p.dout + bin * p.C;
         const float wtl = (1.f - yl) * (1.f - xl), wtr = (1.f - yl) * xl, wbl = yl * (1.f - xl), wbr = yl * xl;
         // one dword per lane per atomic instruction: 256 contiguous bytes per wave-instruction
+        // exact zeros are skipped: ROIs that carry no gradient (zero-padded / non-positive rows of the
+        // mask head) and integer-aligned samples (weight 0 corners) would only add 0.0f -- and the
+        // padded ROIs all hit pixel (0,0) of P2, which serialises the atomics on one row
         for (int c = lane; c < p.C; c += 64) {
             float gv = g[c];
-            atomicAdd(tl + c, gv * wtl);
-            atomicAdd(tr + c, gv * wtr);
-            atomicAdd(bl + c, gv * wbl);
-            atomicAdd(br + c, gv * wbr);
+            if (gv == 0.f) continue;
+            if (wtl != 0.f) atomicAdd(tl + c, gv * wtl);
+            if (wtr != 0.f) atomicAdd(tr + c, gv * wtr);
+            if (wbl != 0.f) atomicAdd(bl + c, gv * wbl);
+            if (wbr != 0.f) atomicAdd(br + c, gv * wbr);
         }
     }
 }

@@ -60,8 +60,11 @@ def conv2d(x, w, bias=None, scale=None, shift=None, res=None, stride=1, padding=
     d = desc or conv_desc(tuple(x.shape), tuple(w.shape), stride, padding, act, res_mode)
     if out is None:
         out = torch.empty((d.N, d.OH, d.OW, d.Cout), dtype=torch.float32, device=x.device)
-    check(_hip.lib().mrcnn_conv2d_fwd(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(scale), ptr(shift), ptr(res),
-                                      ptr(out), ptr(z_out), current_stream()), "mrcnn_conv2d_fwd")
+    nbytes = _hip.lib().mrcnn_conv2d_fwd_workspace(C.byref(d))
+    ws = workspace(nbytes, x.device, "conv_splitk") if nbytes else None
+    check(_hip.lib().mrcnn_conv2d_fwd_ws(C.byref(d), ptr(x), ptr(w), ptr(bias), ptr(scale), ptr(shift), ptr(res),
+                                         ptr(out), ptr(z_out), ptr(ws), ws.numel() if ws is not None else 0,
+                                         current_stream()), "mrcnn_conv2d_fwd")
     return out
 
 

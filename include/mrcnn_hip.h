@@ -56,6 +56,15 @@ int mrcnn_conv2d_fwd(const mrcnn_conv_desc* d, const float* x, const float* w, c
                      const float* scale, const float* shift, const float* res, float* out,
                      float* z_out, void* stream);
 
+/* Same, with scratch for split-K: layers with few output tiles (small feature maps) cut the K loop
+ * into slices run by separate workgroups; partial slabs are summed in a fixed order by a second
+ * kernel that also applies the epilogue.  mrcnn_conv2d_fwd_workspace() gives the bytes needed
+ * (0 = no split); a NULL/short workspace silently runs unsplit.                                     */
+size_t mrcnn_conv2d_fwd_workspace(const mrcnn_conv_desc* d);
+int mrcnn_conv2d_fwd_ws(const mrcnn_conv_desc* d, const float* x, const float* w, const float* bias,
+                        const float* scale, const float* shift, const float* res, float* out,
+                        float* z_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* dW[K, Cout] = sum over pixels of im2col(x)^T . dy   (gradient of KL.Conv2D kernels, taken by TF
  * autodiff in the reference: keras fit_generator, mrcnn/model.py:2487).  dy is dense [N,OH,OW,Cout].
  * Partial sums over `splits` pixel ranges go to `workspace` (splits*K*Cout floats) and are reduced in

@@ -130,6 +130,8 @@ WGRAD_CASES = [
     (2, 16, 16, 512, 6, 1, 1, "valid"),
     (2, 16, 16, 64, 64, 3, 1, "same"),
     (3, 9, 9, 128, 64, 1, 1, "valid"),
+    (2, 16, 16, 1024, 512, 1, 2, "valid"),      # strided-scatter dgrad through the split-K path
+    (2, 8, 8, 2048, 512, 1, 1, "valid"),
 ]
 
 
