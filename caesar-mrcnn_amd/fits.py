@@ -1,0 +1,290 @@
+"""FITS tile reader + zscale pre-processing: the step right before ``detect`` / ``load_image``
+(reference: mrcnn/utils.py:989-1329 ``read_fits``, ``stretch_img``, ``normalize_img``, ``gray2rgb``,
+``crop_img``, ``get_fits_header``, ``get_fits_size``, ``generate_tiles``).
+
+astropy is not available on the target image, so this module carries
+  * a dependency-free reader for the primary HDU of simple FITS images (2880-byte blocks, 80-char cards,
+    BITPIX 8/16/32/64/-32/-64 big-endian, BSCALE/BZERO, NAXIS 2..4), and
+  * a restatement of astropy.visualization.ZScaleInterval / ContrastBiasStretch [3P; parity unpinned:
+    astropy itself cannot run here -- the algorithm follows the published astropy 2.x implementation,
+    SURVEY App. C-6].
+"""
+import logging
+
+import numpy as np
+
+logger = logging.getLogger("mrcnn")
+
+_BITPIX = {8: ">u1", 16: ">i2", 32: ">i4", 64: ">i8", -32: ">f4", -64: ">f8"}
+
+
+class FitsHeader(dict):
+    """Card values keyed by keyword (ints/floats/bools/strings parsed)."""
+
+
+def _parse_card(card):
+    key = card[:8].strip()
+    if card[8:10] != "= " or key in ("COMMENT", "HISTORY", ""):
+        return key, None
+    body = card[10:]
+    if body.lstrip().startswith("'"):
+        s = body.lstrip()[1:]
+        out, i = "", 0
+        while i < len(s):
+            if s[i] == "'":
+                if i + 1 < len(s) and s[i + 1] == "'":
+                    out += "'"
+                    i += 2
+                    continue
+                break
+            out += s[i]
+            i += 1
+        return key, out.rstrip()
+    val = body.split("/")[0].strip()
+    if val in ("T", "F"):
+        return key, val == "T"
+    try:
+        return key, int(val)
+    except ValueError:
+        try:
+            return key, float(val.replace("D", "E"))
+        except ValueError:
+            return key, val
+
+
+def read_primary_hdu(filename):
+    """Returns (data ndarray in native byte order with NAXISn..NAXIS1 axes, FitsHeader)."""
+    with open(filename, "rb") as f:
+        raw = f.read()
+    header = FitsHeader()
+    pos, done = 0, False
+    while not done:
+        block = raw[pos:pos + 2880]
+        if len(block) < 2880:
+            raise ValueError("truncated FITS header in %s" % filename)
+        for i in range(0, 2880, 80):
+            card = block[i:i + 80].decode("ascii", "replace")
+            if card.startswith("END") and card[3:].strip() == "":
+                done = True
+                break
+            k, v = _parse_card(card)
+            if v is not None and k not in header:
+                header[k] = v
+        pos += 2880
+    if not header.get("SIMPLE", False):
+        raise ValueError("%s is not a simple FITS file" % filename)
+    naxis = int(header.get("NAXIS", 0))
+    shape = [int(header["NAXIS%d" % (i + 1)]) for i in range(naxis)][::-1]
+    dt = np.dtype(_BITPIX[int(header["BITPIX"])])
+    n = int(np.prod(shape)) if shape else 0
+    data = np.frombuffer(raw, dtype=dt, count=n, offset=pos).reshape(shape)
+    bscale, bzero = header.get("BSCALE", 1), header.get("BZERO", 0)
+    if bscale != 1 or bzero != 0:
+        data = data.astype(np.float64) * bscale + bzero
+        if dt.kind in "iu" or dt == np.dtype(">f4"):
+            data = data.astype(np.float32)
+    else:
+        data = data.astype(dt.newbyteorder("="))
+    return data, header
+
+
+def write_fits(filename, data, extra_cards=None):
+    """Minimal writer (float32, BITPIX = -32) -- used to synthesise test/benchmark tiles."""
+    data = np.asarray(data, dtype=np.float32)
+    cards = [("SIMPLE", True), ("BITPIX", -32), ("NAXIS", data.ndim)]
+    cards += [("NAXIS%d" % (i + 1), n) for i, n in enumerate(data.shape[::-1])]
+    cards += list((extra_cards or {}).items())
+    lines = []
+    for k, v in cards:
+        if isinstance(v, bool):
+            sv = "%20s" % ("T" if v else "F")
+        elif isinstance(v, (int, np.integer)):
+            sv = "%20d" % v
+        elif isinstance(v, float):
+            sv = "%20s" % repr(v)
+        else:
+            sv = "'%-8s'" % str(v)
+        lines.append(("%-8s= %s" % (k, sv)).ljust(80))
+    lines.append("END".ljust(80))
+    hdr = "".join(lines)
+    hdr += " " * ((2880 - len(hdr) % 2880) % 2880)
+    body = data.astype(">f4").tobytes()
+    body += b"\0" * ((2880 - len(body) % 2880) % 2880)
+    with open(filename, "wb") as f:
+        f.write(hdr.encode("ascii"))
+        f.write(body)
+
+
+# ---- stretches -------------------------------------------------------------------------------------
+def zscale_limits(values, contrast=0.25, nsamples=1000, max_reject=0.5, min_npixels=5, krej=2.5,
+                  max_iterations=5):
+    """astropy.visualization.ZScaleInterval.get_limits [3P]."""
+    values = np.asarray(values)
+    values = values[np.isfinite(values)]
+    stride = int(max(1.0, values.size / nsamples))
+    samples = values[::stride][:nsamples]
+    samples = np.sort(samples)
+    npix = len(samples)
+    vmin, vmax = samples[0], samples[-1]
+    minpix = max(min_npixels, int(npix * max_reject))
+    x = np.arange(npix)
+    ngoodpix, last_ngoodpix = npix, npix + 1
+    badpix = np.zeros(npix, dtype=bool)
+    ngrow = max(1, int(npix * 0.01))
+    kernel = np.ones(ngrow, dtype=bool)
+    fit = (0.0, 0.0)
+    for _ in range(max_iterations):
+        if ngoodpix >= last_ngoodpix or ngoodpix < minpix:
+            break
+        fit = np.polyfit(x, samples, deg=1, w=(~badpix).astype(int))
+        flat = samples - np.poly1d(fit)(x)
+        threshold = krej * flat[~badpix].std()
+        badpix[(flat < -threshold) | (flat > threshold)] = True
+        badpix = np.convolve(badpix, kernel, mode='same')
+        last_ngoodpix = ngoodpix
+        ngoodpix = np.sum(~badpix)
+    slope = fit[0]
+    if ngoodpix >= minpix:
+        if contrast > 0:
+            slope = slope / contrast
+        center_pixel = (npix - 1) // 2
+        median = np.median(samples)
+        vmin = max(vmin, median - (center_pixel - 1) * slope)
+        vmax = min(vmax, median + (npix - center_pixel) * slope)
+    return vmin, vmax
+
+
+def stretch_img(data, contrast=0.25):
+    """ZScaleInterval(contrast)(data): map [vmin, vmax] to [0, 1] with clipping (utils.py:1166-1172)."""
+    vmin, vmax = zscale_limits(data, contrast)
+    out = np.subtract(data, float(vmin)).astype(np.float64)
+    if (vmax - vmin) != 0:
+        np.true_divide(out, vmax - vmin, out=out)
+    return np.clip(out, 0.0, 1.0)
+
+
+def stretch_img_biasconstrast(data, contrast=1, bias=0.5):
+    """ContrastBiasStretch(contrast, bias)(data) = clip((x - bias) * contrast + 0.5, 0, 1) [3P]."""
+    return np.clip((np.asarray(data, dtype=np.float64) - bias) * contrast + 0.5, 0.0, 1.0)
+
+
+def normalize_img(data):
+    return data / np.max(data)
+
+
+def gray2rgb(data_float, to_uint8=True):
+    if to_uint8:
+        chans = [np.array((c * 255).round(), dtype=np.uint8) for c in data_float[:3]]
+    else:
+        chans = [np.array(c * 255, dtype=np.float32) for c in data_float[:3]]
+    return np.stack(chans, axis=-1)
+
+
+def read_fits(filename, xmin=-1, xmax=-1, ymin=-1, ymax=-1, stretch=True, normalize=True, convertToRGB=True,
+              zscale_contrasts=[0.25, 0.25, 0.25], to_uint8=True, stretch_biascontrast=False, contrast=1, bias=0.5):
+    """Tile of a FITS image as the network's input image (utils.py:1033-1163): NaN -> min, per-channel
+    zscale, normalise by the channel maximum, uint8 RGB.  Returns (image, header) or None on error."""
+    if len(zscale_contrasts) != 3:
+        logger.warning("Size of input zscale_contrasts is !=3, ignoring inputs and using default (0.25,0.25,0.25)...")
+        zscale_contrasts = [0.25, 0.25, 0.25]
+    try:
+        data, header = read_primary_hdu(filename)
+    except Exception:
+        logger.error('ERROR: Cannot read image file: ' + filename)
+        return None
+    read_tile = (xmin >= 0 and xmax >= 0 and ymin >= 0 and ymax >= 0)
+    if read_tile:
+        if xmax <= xmin:
+            logger.error("xmax must be >xmin for tile reading!")
+            return None
+        if ymax <= ymin:
+            logger.error("ymax must be >ymin for tile reading!")
+            return None
+    if data.ndim == 4:
+        out = data[0, 0, ymin:ymax, xmin:xmax] if read_tile else data[0, 0, :, :]
+    elif data.ndim == 2:
+        out = data[ymin:ymax, xmin:xmax] if read_tile else data
+    else:
+        logger.error('ERROR: Invalid/unsupported number of channels found in file %s (nchan=%d)!' % (filename, data.ndim))
+        return None
+    out = out.astype(np.float32)
+    out[np.isnan(out)] = np.nanmin(out)
+    chans = [np.copy(out) for _ in range(3)]
+    if stretch:
+        chans = [stretch_img(c, zc).astype(np.float32) for c, zc in zip(chans, zscale_contrasts)]
+    if stretch_biascontrast:
+        chans = [stretch_img_biasconstrast(c, contrast, bias).astype(np.float32) for c in chans]
+    if normalize:
+        chans = [normalize_img(c).astype(np.float32) for c in chans]
+    if convertToRGB:
+        if not normalize:
+            chans = [normalize_img(c) for c in chans]
+        return gray2rgb(chans, to_uint8), header
+    return chans[0], header
+
+
+def get_fits_header(filename):
+    try:
+        return read_primary_hdu(filename)[1]
+    except Exception:
+        logger.error('ERROR: Cannot read image file: ' + filename)
+        return None
+
+
+def get_fits_size(filename):
+    """(nx, ny) of the image plane (utils.py:1007-1030)."""
+    try:
+        data, _ = read_primary_hdu(filename)
+    except Exception:
+        logger.error('ERROR: Cannot read image file: ' + filename)
+        return None
+    if data.ndim not in (2, 4):
+        return None
+    return data.shape[-1], data.shape[-2]
+
+
+def crop_img(data, x0, y0, dx, dy, stretch=False, normalize=False, convertToRGB=False):
+    """Sub-image of size (dx, dy) around pixel (x0, y0) (utils.py:1211-1249)."""
+    xmin, xmax = int(x0 - dx / 2), int(x0 + dx / 2)
+    ymin, ymax = int(y0 - dy / 2), int(y0 + dy / 2)
+    crop = data[ymin:ymax, xmin:xmax]
+    crop[np.isnan(crop)] = np.nanmin(crop)
+    if stretch:
+        crop = stretch_img(crop).astype(np.float32)
+    if normalize:
+        crop = normalize_img(crop).astype(np.float32)
+    if convertToRGB:
+        if not normalize:
+            crop = normalize_img(crop)
+        crop = gray2rgb([crop, crop, crop])
+    return crop
+
+
+def generate_tiles(img_xmin, img_xmax, img_ymin, img_ymax, tileSizeX, tileSizeY, gridStepSizeX, gridStepSizeY):
+    """(xmin, xmax, ymin, ymax) tuples covering the image, row-major (utils.py:1254-1329)."""
+    if img_xmax <= img_xmin or img_ymax <= img_ymin:
+        logger.error("xmax/ymax must be > xmin/ymin!")
+        return None
+    if tileSizeX <= 0 or tileSizeY <= 0:
+        logger.error("Invalid box size given!")
+        return None
+    if gridStepSizeX <= 0 or gridStepSizeY <= 0 or gridStepSizeX > 1 or gridStepSizeY > 1:
+        logger.error("Invalid grid step size given (null or negative)!")
+        return None
+    Nx, Ny = img_xmax - img_xmin + 1, img_ymax - img_ymin + 1
+    if tileSizeX > Nx or tileSizeY > Ny:
+        logger.warning("Invalid box size given (too small or larger than image size)!")
+        return None
+    stepX, stepY = int(np.round(gridStepSizeX * tileSizeX)), int(np.round(gridStepSizeY * tileSizeY))
+
+    def spans(N, tile, step):
+        out, idx = [], 0
+        while idx <= N:
+            off = min(tile, N - idx)
+            if idx >= N or off == 0:
+                break
+            out.append((idx, idx + off))
+            idx += step
+        return out
+    xs, ys = spans(Nx, tileSizeX, stepX), spans(Ny, tileSizeY, stepY)
+    return [(img_xmin + x0, img_xmin + x1, img_ymin + y0, img_ymin + y1) for (y0, y1) in ys for (x0, x1) in xs]

@@ -1,0 +1,280 @@
+"""CPU-only checks: the C-ABI library loads and exports every symbol of include/mrcnn_hip.h, host
+logic (config, parameter layout, FITS + zscale, weight files, data generator, facade error behaviour)
+and the world_size-2 gradient reducer over gloo.  No compute call touches a GPU here."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+G = np.load(os.path.join(GOLD, "reference_numpy_helpers.npz"))
+
+
+def test_cabi_library_exports_header_symbols():
+    import ctypes
+    import __graft_entry__ as ge
+    lib_path = ge.build()
+    assert os.path.exists(lib_path)
+    header = open(os.path.join(ROOT, "include", "mrcnn_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(mrcnn_[a-z0-9_]+)\s*\(", header, re.M))
+    assert len(declared) >= 30
+    lib = ctypes.CDLL(lib_path)
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, "declared in mrcnn_hip.h but not exported: %s" % missing
+    from caesar_mrcnn_amd import _hip
+    assert set(_hip.exported_symbols()) <= declared
+    lib.mrcnn_hip_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.mrcnn_hip_version()
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    from caesar_mrcnn_amd import ops, _hip
+    with pytest.raises(_hip.HipPathError):
+        ops.conv2d(torch.zeros(1, 4, 4, 32), torch.zeros(1, 1, 32, 32))
+    if not torch.cuda.is_available():
+        from caesar_mrcnn_amd.config import run_py_config
+        from caesar_mrcnn_amd.model import MaskRCNN
+        with pytest.raises(_hip.HipPathError):
+            MaskRCNN("inference", run_py_config(mode="inference"), "/tmp/x")
+    # nothing under the package imports the oracle
+    pkg = os.path.join(ROOT, "caesar-mrcnn_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            assert "mrcnn_oracle" not in open(os.path.join(pkg, fn)).read(), fn
+
+
+def test_same_padding_is_tf_asymmetric():
+    from caesar_mrcnn_amd.ops import same_padding
+    assert same_padding(128, 3, 2) == (64, 0)       # stem max-pool: pad 0 before / 1 after
+    assert same_padding(127, 3, 2) == (64, 1)
+    assert same_padding(64, 3, 1) == (64, 1)
+    assert same_padding(64, 1, 2) == (32, 0)
+
+
+def test_param_layout_counts_and_names():
+    from caesar_mrcnn_amd.config import run_py_config
+    from caesar_mrcnn_amd.params import ParamLayout, init_weights
+    for bb, nconv, total in (("resnet50", 53, 44.6e6), ("resnet101", 104, 63.6e6)):
+        L = ParamLayout(run_py_config(backbone=bb))
+        backbone = [l for l in L.layers if l.name.startswith("res") or l.name == "conv1"]
+        assert len(backbone) == nconv
+        real = sum(s[2] for s in L.segments)
+        assert abs(real - total) / total < 0.01
+        offs = [s[1] for s in L.segments]
+        assert offs == sorted(offs) and all(o % 64 == 0 for o in offs)
+        ends = [s[1] + s[2] for s in L.segments]
+        assert all(e <= o2 for e, o2 in zip(ends[:-1], offs[1:]))         # no overlap
+    L = ParamLayout(run_py_config(backbone="resnet101"))
+    assert "res4w_branch2c" in L.by_name and "res4x_branch2c" not in L.by_name
+    assert L.by_name["mrcnn_class_conv1"].shape == (7, 7, 256, 1024)
+    assert L.by_name["rpn_class_raw"].shape == (1, 1, 512, 6) and L.by_name["rpn_bbox_pred"].shape == (1, 1, 512, 12)
+    assert L.by_name["mrcnn_bbox_fc"].shape == (1, 1, 1024, 16) and L.by_name["mrcnn_mask"].shape == (1, 1, 256, 4)
+    # trainable presets (model.py:2432-2441)
+    m = L.trainable_mask("heads")
+    names = [s[0] for s in L.segments]
+    assert all(bool(t) == bool(re.fullmatch(r"(mrcnn\_.*)|(rpn\_.*)|(fpn\_.*)", n.split("/")[0])) for n, t in zip(names, m))
+    assert L.trainable_mask("all").all()
+    assert not L.trainable_mask("5+")[names.index("res4a_branch2a/kernel")] and L.trainable_mask("5+")[names.index("bn5a_branch2a/gamma")]
+    l2 = L.l2_coefficients(1e-4)
+    assert l2[names.index("conv1/bias")] > 0 and l2[names.index("bn_conv1/gamma")] == 0
+    w = init_weights(ParamLayout(run_py_config(backbone="custom")), seed=1)
+    assert w["conv1/kernel"].shape == (7, 7, 3, 16) and float(w["bn_conv1/gamma"].min()) == 1.0
+
+
+def test_weight_file_roundtrip_and_exclude_quirk(tmp_path):
+    from caesar_mrcnn_amd import weights_io
+    from caesar_mrcnn_amd.config import run_py_config
+    from caesar_mrcnn_amd.params import ParamLayout, init_weights
+    w = init_weights(ParamLayout(run_py_config(backbone="custom")), seed=2, perturb_bn=True)
+    p = str(tmp_path / "rg-dataset20240101T0000" / "mask_rcnn_rg-dataset_0007.npz")
+    weights_io.save(p, w)
+    back = weights_io.load(p)
+    assert set(back) == set(w) and all(np.array_equal(back[k], w[k]) for k in w)
+    # load_weights(exclude='conv1') is a substring test on the layer name in the reference
+    kept = {k for k in back if k.split("/")[0] not in "conv1"}
+    assert "conv1/kernel" not in kept and "bn_conv1/gamma" in kept and "mrcnn_mask_conv1/kernel" in kept
+
+
+def test_set_log_dir_epoch_parsing():
+    from caesar_mrcnn_amd.model import MaskRCNN
+    from caesar_mrcnn_amd.config import run_py_config
+    m = MaskRCNN.__new__(MaskRCNN)
+    m.config, m.model_dir = run_py_config(), "/tmp/logs"
+    m.set_log_dir("/tmp/logs/rg-dataset20171029T2315/mask_rcnn_rg-dataset_0012.h5")
+    assert m.epoch == 12 and m.log_dir.endswith("rg-dataset20171029T2315")
+    assert m.checkpoint_path.endswith("mask_rcnn_rg-dataset_{epoch:04d}.h5")
+    m.set_log_dir("/somewhere/else.h5")
+    assert m.epoch == 0
+
+
+# ---- FITS + zscale ------------------------------------------------------------------------------------
+def test_fits_reader_on_reference_cutouts():
+    from caesar_mrcnn_amd import fits
+    data, hdr = fits.read_primary_hdu(os.path.join(GOLD, "galaxy0002.fits"))
+    assert data.shape == (132, 132) and data.dtype == np.float32
+    assert int(np.isnan(data).sum()) == 288                     # SURVEY: galaxy0002 has 288 NaN pixels
+    assert hdr["BITPIX"] == -32 and hdr["NAXIS1"] == 132 and "BMAJ" in hdr and "CDELT1" not in hdr
+    assert fits.get_fits_size(os.path.join(GOLD, "sidelobe0001.fits")) == (132, 132)
+    img, hdr = fits.read_fits(os.path.join(GOLD, "galaxy0002.fits"))
+    assert img.shape == (132, 132, 3) and img.dtype == np.uint8 and img.max() == 255
+    assert np.array_equal(img[..., 0], img[..., 1])             # equal contrasts -> equal channels
+    tile, _ = fits.read_fits(os.path.join(GOLD, "galaxy0002.fits"), xmin=10, xmax=74, ymin=20, ymax=52)
+    assert tile.shape == (32, 64, 3)
+    assert fits.read_fits(os.path.join(GOLD, "galaxy0002.fits"), xmin=10, xmax=5, ymin=0, ymax=4) is None
+    assert fits.read_fits("/nonexistent.fits") is None
+    raw, _ = fits.read_fits(os.path.join(GOLD, "sidelobe0001.fits"), stretch=False, normalize=False, convertToRGB=False)
+    assert raw.dtype == np.float32 and not np.isnan(raw).any()
+
+
+def test_fits_writer_roundtrip_and_zscale_properties(tmp_path):
+    from caesar_mrcnn_amd import fits
+    rng = np.random.RandomState(0)
+    img = rng.normal(0, 1, (90, 70)).astype(np.float32)
+    img[40:50, 30:40] += 50.0
+    img[0, :5] = np.nan
+    p = str(tmp_path / "t.fits")
+    fits.write_fits(p, img, {"BUNIT": "JY/BEAM", "BMAJ": 0.0025})
+    back, hdr = fits.read_primary_hdu(p)
+    assert np.array_equal(np.isnan(back), np.isnan(img)) and np.array_equal(back[~np.isnan(back)], img[~np.isnan(img)])
+    assert hdr["BUNIT"] == "JY/BEAM" and abs(hdr["BMAJ"] - 0.0025) < 1e-12
+    clean = np.nan_to_num(img, nan=np.nanmin(img))
+    vmin, vmax = fits.zscale_limits(clean, 0.25)
+    assert clean.min() <= vmin < vmax <= clean.max()
+    assert vmax < 10.0                                            # the bright source is clipped away by zscale
+    lo2, hi2 = fits.zscale_limits(clean, 0.5)
+    assert (hi2 - lo2) <= (vmax - vmin) + 1e-9                    # higher contrast -> narrower interval
+    s = fits.stretch_img(clean, 0.25)
+    assert s.min() == 0.0 and s.max() == 1.0
+    flat = np.full((20, 20), 3.0)
+    assert np.all(fits.stretch_img(flat) == 0.0)                  # degenerate interval: (x - vmin), no division
+    assert np.allclose(fits.stretch_img_biasconstrast(np.array([0.0, 0.5, 1.0]), 2.0, 0.5), [0.0, 0.5, 1.0])
+    rgb = fits.gray2rgb([s, s, s], True)
+    assert rgb.dtype == np.uint8 and rgb.shape == (90, 70, 3)
+
+
+def test_generate_tiles_matches_reference():
+    from caesar_mrcnn_amd import fits
+    assert np.array_equal(np.array(fits.generate_tiles(0, 999, 0, 799, 256, 256, 0.5, 1.0)), G["tiles_a"])
+    assert np.array_equal(np.array(fits.generate_tiles(10, 521, 5, 300, 128, 100, 1.0, 0.75)), G["tiles_b"])
+    assert fits.generate_tiles(0, 10, 0, 10, 64, 64, 1, 1) is None
+    assert fits.generate_tiles(0, 100, 0, 100, 64, 64, 0, 1) is None
+
+
+# ---- data generator -------------------------------------------------------------------------------------
+class _ToyDataset(object):
+    """Duck-typed like mrcnn.utils.Dataset as the generator uses it (model.py:1302-1366, 1766, 1791)."""
+
+    def __init__(self, n=6, size=128, seed=0):
+        self.rng = np.random.RandomState(seed)
+        self.image_ids = np.arange(n)
+        self.image_info = [{"source": "toy", "id": i} for i in range(n)]
+        self.num_classes = 4
+        self.source_class_ids = {"toy": [0, 1, 2, 3]}
+        self.size = size
+        self._cache = {}
+
+    def _make(self, i):
+        if i not in self._cache:
+            r = np.random.RandomState(100 + i)
+            img = r.randint(0, 40, (self.size, self.size, 3)).astype(np.uint8)
+            k = r.randint(1, 4)
+            mask = np.zeros((self.size, self.size, k), bool)
+            ids = np.zeros(k, np.int32)
+            for g in range(k):
+                y, x = r.randint(5, self.size - 40, 2)
+                h, w = r.randint(8, 30, 2)
+                mask[y:y + h, x:x + w, g] = True
+                img[y:y + h, x:x + w] = 200
+                ids[g] = r.randint(1, 4)
+            self._cache[i] = (img, mask, ids)
+        return self._cache[i]
+
+    def load_image(self, i):
+        return self._make(i)[0]
+
+    def load_mask(self, i):
+        return self._make(i)[1], self._make(i)[2]
+
+
+def _gen_cfg():
+    from caesar_mrcnn_amd.config import run_py_config
+    cfg = run_py_config(backbone="custom", imgsize=128)
+    cfg.MAX_GT_INSTANCES = 10
+    cfg.RPN_TRAIN_ANCHORS_PER_IMAGE = 64
+    return cfg
+
+
+def test_data_generator_batches_and_rank_sharding():
+    from caesar_mrcnn_amd.datagen import data_generator, load_image_gt
+    from caesar_mrcnn_amd import utils
+    cfg, ds = _gen_cfg(), _ToyDataset()
+    gen = data_generator(ds, cfg, shuffle=False, batch_size=2)
+    inputs, outputs = next(gen)
+    images, meta, rpn_match, rpn_bbox, gt_ids, gt_boxes, gt_masks = inputs
+    A = utils.get_anchors(cfg, (128, 128, 3)).shape[0]
+    assert images.shape == (2, 128, 128, 3) and images.dtype == np.float32 and outputs == []
+    assert meta.shape == (2, cfg.IMAGE_META_SIZE) and rpn_match.shape == (2, A, 1) and rpn_match.dtype == np.int32
+    assert rpn_bbox.shape == (2, 64, 4) and gt_ids.shape == (2, 10) and gt_boxes.shape == (2, 10, 4)
+    assert gt_masks.shape == (2, 128, 128, 10) and gt_masks.dtype == bool
+    assert set(np.unique(rpn_match)) <= {-1, 0, 1} and (rpn_match == 1).sum() > 0
+    assert (np.abs(rpn_match).sum(axis=(1, 2)) <= 64).all()
+    # the first image of the batch is dataset image 0, boxes agree with the masks
+    _, m0, ids0, b0, mk0 = load_image_gt(ds, cfg, 0)
+    assert np.array_equal(gt_boxes[0, :len(b0)], b0) and np.array_equal(utils.extract_bboxes(mk0), b0)
+    # two ranks see disjoint strides of the same order
+    g0 = data_generator(ds, cfg, shuffle=True, batch_size=1, rank=0, world_size=2, seed=5)
+    g1 = data_generator(ds, cfg, shuffle=True, batch_size=1, rank=1, world_size=2, seed=5)
+    ids_r0 = [int(next(g0)[0][1][0, 0]) for _ in range(3)]
+    ids_r1 = [int(next(g1)[0][1][0, 0]) for _ in range(3)]
+    assert not set(ids_r0) & set(ids_r1) and len(set(ids_r0 + ids_r1)) == 6
+
+
+def test_augmentation_callable_keeps_shapes():
+    from caesar_mrcnn_amd.datagen import load_image_gt
+    cfg, ds = _gen_cfg(), _ToyDataset()
+    flip = lambda im, mk: (np.fliplr(im), np.fliplr(mk))
+    img, meta, ids, boxes, masks = load_image_gt(ds, cfg, 1, augmentation=flip)
+    img0, _, _, boxes0, _ = load_image_gt(ds, cfg, 1)
+    assert np.array_equal(img, np.fliplr(img0))
+    assert np.array_equal(np.sort(128 - boxes0[:, [3, 1]], axis=1), np.sort(boxes[:, [1, 3]], axis=1))
+
+
+# ---- data-parallel gradient reduction over gloo (world_size 2, CPU tensors) ----------------------------
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+from caesar_mrcnn_amd.parallel import GradReducer, init_distributed, allreduce_mean_scalars
+rank, local_rank, world = init_distributed(backend="gloo")
+assert world == 2
+g = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+red = GradReducer(g, world)
+for lo, hi in ((600, 1000), (200, 600), (0, 200)):      # ranges arrive in backward order
+    red.ready(lo, hi)
+red.finish()
+assert torch.equal(g, torch.arange(1000, dtype=torch.float32) * 3), g[:5]
+l = allreduce_mean_scalars(torch.full((5,), float(rank)), world)
+assert torch.allclose(l, torch.full((5,), 0.5))
+dist.barrier(); dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_grad_reducer_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"root": ROOT})
+    port = 29600 + (os.getpid() % 300)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)

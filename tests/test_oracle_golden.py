@@ -1,0 +1,153 @@
+"""Pins the CPU oracle (and the product's host-side twins in caesar_mrcnn_amd.utils / datagen) against
+golden vectors produced by the reference's own NumPy functions (tests/golden/make_reference_fixtures.py,
+run in the build container where /root/reference is mounted).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import mrcnn_oracle as orc
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_numpy_helpers.npz"))
+
+
+def _cfg():
+    from caesar_mrcnn_amd.config import run_py_config
+    return run_py_config()
+
+
+def _impls():
+    from caesar_mrcnn_amd import utils as U
+    return [("oracle", orc), ("product", U)]
+
+
+def test_config_derived_fields():
+    from caesar_mrcnn_amd.config import Config
+
+    class C(Config):
+        NUM_CLASSES = 4
+        IMAGE_MIN_DIM = 256
+        IMAGE_MAX_DIM = 256
+    c = C()
+    assert c.BATCH_SIZE == int(G["cfg_batch_size"])
+    assert np.array_equal(c.IMAGE_SHAPE, G["cfg_image_shape"])
+    assert c.IMAGE_META_SIZE == int(G["cfg_image_meta_size"])
+    c.IMAGES_PER_GPU, c.GPU_COUNT = 4, 8           # run.py-style late override stays consistent (App. D-1)
+    assert c.BATCH_SIZE == 32
+
+
+@pytest.mark.parametrize("name,mod", _impls())
+def test_anchors(name, mod):
+    cfg = _cfg()
+    for size in (256, 512):
+        if name == "oracle":
+            shapes = mod.compute_backbone_shapes(cfg.BACKBONE_STRIDES, (size, size, 3))
+        else:
+            shapes = mod.compute_backbone_shapes(cfg, (size, size, 3))
+        assert np.array_equal(shapes, G["backbone_shapes_%d" % size])
+        a = mod.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS, shapes, cfg.BACKBONE_STRIDES,
+                                         cfg.RPN_ANCHOR_STRIDE)
+        if size == 256:
+            assert a.dtype == G["anchors_px_256"].dtype and np.array_equal(a, G["anchors_px_256"])
+            n = mod.norm_boxes(a, (size, size))
+            assert n.dtype == np.float32 and np.array_equal(n, G["anchors_norm_256"])
+            assert np.array_equal(mod.get_anchors(cfg, (256, 256, 3)), G["anchors_norm_256"])
+        else:
+            assert np.array_equal(a[:64], G["anchors_px_512_head"]) and np.array_equal(a[-64:], G["anchors_px_512_tail"])
+            assert np.array_equal(np.array([a.shape[0], a.sum(), np.abs(a).sum()]), G["anchors_px_512_sum"])
+
+
+@pytest.mark.parametrize("name,mod", _impls())
+def test_box_helpers(name, mod):
+    boxes = G["boxes_in"]
+    assert np.array_equal(mod.norm_boxes(boxes, (256, 256)), G["norm_boxes"])
+    assert np.array_equal(mod.denorm_boxes(G["norm_boxes"], (256, 256)), G["denorm_boxes"])
+    assert np.array_equal(mod.compute_overlaps(boxes, G["gt_in"][:17]), G["compute_overlaps"])
+    assert np.array_equal(mod.trim_zeros(np.array([[0, 0, 0, 0], [1, 2, 3, 4], [0, 0, 0, 0], [5, 6, 7, 8]])), G["trim_zeros"])
+    assert np.array_equal(mod.extract_bboxes(G["masks_in"]), G["extract_bboxes"])
+
+
+def test_oracle_box_arithmetic():
+    boxes = G["boxes_in"]
+    got = orc.apply_box_deltas_np(boxes.astype(np.float32), G["deltas_in"])
+    assert got.dtype == np.float32 and np.array_equal(got, G["apply_box_deltas"])
+    assert np.array_equal(orc.box_refinement_np(boxes, G["gt_in"]), G["box_refinement"])
+
+
+def test_oracle_nms_matches_reference_numpy_nms():
+    nb, ns = G["nms_boxes"], G["nms_scores"]
+    for thr in (0.3, 0.5, 0.7):
+        ref = G["nms_keep_%d" % int(thr * 10)]
+        assert np.array_equal(orc.non_max_suppression_np(nb, ns, thr), ref)
+        # the restated TF kernel agrees with the reference's NumPy NMS wherever both are defined
+        # (positive-area boxes, distinct scores): same greedy rule, same IoU > thr test
+        tf_keep = orc.tf_non_max_suppression(nb, ns, nb.shape[0], thr)
+        assert np.array_equal(tf_keep.astype(np.int32), ref)
+
+
+def test_rpn_targets():
+    from caesar_mrcnn_amd.datagen import build_rpn_targets as product_rpn
+    cfg = _cfg()
+    anchors = G["anchors_px_256"]
+    for ids_key, m_key, b_key, seed in (("rpn_gt_ids", "rpn_match", "rpn_bbox", 7),
+                                        ("rpn_gt_ids_crowd", "rpn_match_crowd", "rpn_bbox_crowd", 11)):
+        np.random.seed(seed)
+        rm, rb = orc.build_rpn_targets(anchors, G[ids_key], G["rpn_gt_boxes"], cfg.RPN_TRAIN_ANCHORS_PER_IMAGE,
+                                       cfg.RPN_BBOX_STD_DEV)
+        assert np.array_equal(rm, G[m_key]) and np.array_equal(rb, G[b_key])
+        np.random.seed(seed)
+        rm, rb = product_rpn((256, 256, 3), anchors, G[ids_key], G["rpn_gt_boxes"], cfg)
+        assert np.array_equal(rm, G[m_key]) and np.array_equal(rb, G[b_key])
+    assert (G["rpn_match"] == 1).sum() > 0 and (G["rpn_match"] == -1).sum() > 0
+
+
+def test_image_meta_and_molding():
+    from caesar_mrcnn_amd import utils as U
+    from caesar_mrcnn_amd.config import Config
+    args = (7, (132, 132, 3), (256, 256, 3), (62, 62, 194, 194), 1.0, np.array([1, 1, 0, 1]))
+    for f in (orc.compose_image_meta, U.compose_image_meta):
+        assert np.array_equal(f(*args), G["image_meta"])
+    pm = U.parse_image_meta(G["image_meta"][None])
+    assert np.array_equal(pm["window"], G["parse_window"]) and np.array_equal(pm["active_class_ids"], G["parse_active"])
+
+    class C2(Config):
+        MEAN_PIXEL = np.array([1.5, 2.5, 3.5])
+    got = U.mold_image(G["resize_in"], C2())
+    assert got.dtype == G["mold_image"].dtype and np.array_equal(got, G["mold_image"])
+
+
+def test_resize_image_without_scaling():
+    from caesar_mrcnn_amd import utils as U
+    img, window, scale, padding, crop = U.resize_image(G["resize_big_in"], min_dim=256, max_dim=256, min_scale=0,
+                                                       mode="square")
+    assert img.dtype == np.uint8 and np.array_equal(img, G["resize_square_img"])
+    assert np.array_equal(np.array(window), G["resize_square_window"])
+    assert scale == G["resize_square_scale"] and np.array_equal(np.array(padding), G["resize_square_padding"])
+    img, window, _, _, _ = U.resize_image(G["resize_big_in"], min_dim=128, max_dim=None, min_scale=0, mode="pad64")
+    assert np.array_equal(img, G["resize_pad64_img"]) and np.array_equal(np.array(window), G["resize_pad64_window"])
+    with pytest.raises(Exception):
+        U.resize_image(G["resize_big_in"], min_dim=128, max_dim=128, mode="bogus")
+
+
+def test_recall():
+    from caesar_mrcnn_amd import utils as U
+    pb = G["boxes_in"][:12].astype(np.int32)
+    assert U.compute_recall(pb, G["gt_in"][:9].astype(np.int32), 0.5)[0] == float(G["recall"])
+
+
+def test_bilinear_resize_restatement_properties():
+    """skimage.transform.resize is not installed: the restatement (parity unpinned) is checked on
+    properties of the half-pixel-centre bilinear warp."""
+    from caesar_mrcnn_amd import utils as U
+    x = np.arange(12, dtype=np.float64).reshape(3, 4)
+    assert np.allclose(U.resize(x, (3, 4)), x)                       # identity
+    const = np.full((5, 7), 3.25)
+    up = U.resize(const, (13, 20))
+    assert np.allclose(up[2:-2, 2:-2], 3.25) and up.max() <= 3.25 + 1e-12     # interior exact, clip holds
+    ramp = np.tile(np.arange(8, dtype=np.float64), (8, 1))
+    r2 = U.resize(ramp, (16, 16))
+    assert np.all(np.diff(r2[8, 1:-1]) >= -1e-12)                   # monotone along the ramp
+    m = np.zeros((28, 28)); m[8:20, 8:20] = 1.0
+    full = U.unmold_mask(m, (10, 20, 66, 76), (100, 100, 3))
+    assert full.dtype == bool and full[:10].sum() == 0 and full[10:66, 20:76].sum() > 0
+    assert U.resize(np.ones((4, 4), bool), (8, 8)).max() <= 1.0      # bool input is scaled like img_as_float
