@@ -123,22 +123,32 @@ def main():
         eng.apply_gradients(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM, world)
         return losses
 
+    def timed(nsteps):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(nsteps):
+            ls = step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_ = time.time() - t0
+        if world > 1:
+            t = torch.tensor([dt_], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_ = float(t.item())
+        return dt_, ls
+
+    # headline: every multiplication of the reference graph is executed (dense mask-head backward)
+    eng.sparse_mask_bwd = False
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for _ in range(args.steps):
-        losses = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.time() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, losses = timed(args.steps)
+    # product default: rows of the mask-head backward whose gradient is exactly zero are skipped
+    eng.sparse_mask_bwd = True
+    step()
+    dt_sparse, _ = timed(args.steps)
     ms_per_step = dt / args.steps * 1e3
     images_per_s = args.nimg * world * args.steps / dt
     final_losses = [float(v) for v in losses.cpu().numpy()]
@@ -191,6 +201,10 @@ def main():
                        "global_batch": args.nimg * world, "parallelism": "dp%d" % world,
                        "weights": "random init (Keras defaults)"},
             "detect_ms_per_image": round(detect_ms, 3),
+            "value_exact_zero_skip": round(args.nimg * world * args.steps / dt_sparse, 3),
+            "note_exact_zero_skip": "same step with the mask-head backward restricted to the <=168 positive ROI rows "
+                                    "per image (all other rows have exactly-zero gradient; results identical, "
+                                    "tests/test_engine_gpu.py::test_sparse_mask_backward_equals_dense); product default",
             "losses_last_step": [round(v, 5) for v in final_losses],
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                          "frac": round(achieved / peak, 4), "traffic": None,

@@ -62,3 +62,18 @@ __device__ __forceinline__ void decode_clip_box(const float* box, float d0, floa
     o[2] = fmaxf(fminf(y2, wy2), wy1);
     o[3] = fmaxf(fminf(x2, wx2), wx1);
 }
+
+// Exact unsigned division by a runtime-constant divisor (n < 2^31): q = (umulhi(n, mul) + n) >> shift.
+struct FastDiv {
+    unsigned mul, shift, d;
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    f.mul = (unsigned)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.shift = l;
+    f.d = d;
+    return f;
+}
+__device__ __forceinline__ unsigned fast_div(unsigned n, const FastDiv& f) { return (__umulhi(n, f.mul) + n) >> f.shift; }

@@ -13,6 +13,7 @@ struct WgradArgs {
     const float* x; const float* dy; float* out;   // out: dw (splits==1) or slabs
     int N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW;
     int M, Ktot, fast, splits, chunk, acc;
+    FastDiv d_ohw, d_ow;
 };
 
 template <int BI, int BN, int WM, int WN>
@@ -49,8 +50,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(const Wgrad
             const int m = mb + row;
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if (m < m_end) {
-                const int n = m / ohw, rem = m - n * ohw;
-                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                const int n = (int)fast_div((unsigned)m, p.d_ohw), rem = m - n * ohw;
+                const int oh = (int)fast_div((unsigned)rem, p.d_ow), ow = rem - oh * p.OW;
                 if (p.fast) {
                     const int ih = oh * p.stride - p.pad_t + kh, iw = ow * p.stride - p.pad_l + kw;
                     if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
@@ -223,6 +224,7 @@ extern "C" int mrcnn_conv2d_wgrad(const mrcnn_conv_desc* d, const float* x, cons
     a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.OH = d->OH; a.OW = d->OW;
     a.M = (int)M; a.Ktot = d->KH * d->KW * d->Cin; a.fast = pl.fast; a.splits = pl.splits; a.chunk = pl.chunk;
     a.acc = beta_acc;
+    a.d_ohw = make_fastdiv((unsigned)(d->OH * d->OW)); a.d_ow = make_fastdiv((unsigned)d->OW);
     hipStream_t s = (hipStream_t)stream;
     if (pl.bi == 128) {
         if (pl.bn == 128) launch_wgrad<128, 128, 2, 2>(a, s);

@@ -160,6 +160,7 @@ class MaskRCNNEngine(object):
         self.grad_ranges = {"tail": (fp, L.gamma_offset), 5: (s5, fp), 4: (s4, s5), 3: (s3, s4), 2: (s2, s3),
                             "head": (0, s2), "bn": (L.gamma_offset, L.total)}
         self.grad_ready = None          # callable(start, end) or None
+        self.sparse_mask_bwd = True     # skip the exactly-zero rows of the mask-head backward
 
     def op(self, name):
         return self._ops[name]
@@ -388,25 +389,43 @@ class MaskRCNNEngine(object):
 
     # ---- head backward --------------------------------------------------------------------------
     def _mask_head_bwd(self, d_mmask, ctxs, rois, dP, area):
+        """Backward of build_fpn_mask_graph.  The mask loss only sees positive ROIs
+        (mrcnn_mask_loss_graph, model.py:1250-1257) and DetectionTargetLayer puts them first
+        (model.py:696), at most int(T*ROI_POSITIVE_RATIO) per image: every other row of d_mmask is
+        exactly zero and contributes exact zeros to every gradient.  With ``sparse_mask_bwd`` (default)
+        the backward therefore runs on rows [0, quota) of each image only -- same results, ~1/3 of the
+        mask-head backward FLOPs.  ``sparse_mask_bwd = False`` multiplies the zeros like TF does."""
+        B, T = rois.shape[0], rois.shape[1]
+        quota = min(T, int(T * self.cfg.ROI_POSITIVE_RATIO))
+        if not self.sparse_mask_bwd or quota == T or quota == 0:
+            self._mask_head_bwd_rows(d_mmask.view((B * T,) + tuple(d_mmask.shape[2:])), ctxs, rois, dP, area, False)
+            return
+        for b in range(B):
+            def sl(t):
+                return t.view((B, T) + tuple(t.shape[1:]))[b, :quota] if torch.is_tensor(t) else t
+            ctx_b = [tuple(sl(t) for t in c) for c in ctxs]
+            self._mask_head_bwd_rows(d_mmask[b, :quota], ctx_b, rois[b:b + 1, :quota], [p_[b:b + 1] for p_ in dP], area,
+                                     b > 0)
+
+    def _mask_head_bwd_rows(self, g, ctxs, rois, dP, area, acc):
         cfg = self.cfg
         c1, c2, c3, c4, cdec, cm = ctxs
         mop, dc = self.op("mrcnn_mask"), self.op("mrcnn_mask_deconv")
-        g = d_mmask.view(cm[2].shape)
         dz, _ = mop.epilogue_bwd(g, cm)
-        mop.wgrad(dz, cm)
+        mop.wgrad(dz, cm, accumulate=acc)
         d_up = mop.dgrad(dz, cm)                                    # [M,28,28,256]
         # deconv: relu mask + bias, regroup to GEMM columns, then the two GEMM adjoints
         x_in, _, up, _ = cdec
         dzu = torch.empty_like(d_up)
         ops.epilogue_bwd(d_up, up, None, None, None, None, None, dzu, None, None, dc.db, ACT_RELU)
         dzg = ops.pixel_unshuffle2(dzu)                             # [M,14,14,1024]
-        ops.conv2d_wgrad(x_in, dzg, dc.wshape, 1, "valid", dw=dc.dw)
+        ops.conv2d_wgrad(x_in, dzg, dc.wshape, 1, "valid", dw=dc.dw, accumulate=acc)
         ops.weight_flip_transpose(dc.w, dc.wt)
         d = ops.conv2d(dzg, dc.wt, stride=1, padding="valid")
         for i, c in ((4, c4), (3, c3), (2, c2), (1, c1)):
             op = self.op("mrcnn_mask_conv%d" % i)
             dz, _ = op.epilogue_bwd(d, c)
-            op.wgrad(dz, c)
+            op.wgrad(dz, c, accumulate=acc)
             d = op.dgrad(dz, c)
         B, R = rois.shape[0], rois.shape[1]
         ops.roialign_bwd(rois, d.view(B, R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1), dP, cfg.MASK_POOL_SIZE, area)

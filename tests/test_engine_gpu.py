@@ -249,3 +249,22 @@ def test_frozen_layers_and_heads_preset(dev):
     changed = (model.engine.params != before).cpu().numpy()
     for (name, off, n, _, _), t in zip(model.engine.layout.segments, model.engine.trainable_host):
         assert changed[off:off + n].any() == bool(t) or (t and n < 8), name
+
+
+def test_sparse_mask_backward_equals_dense(dev):
+    """Skipping the exactly-zero (non-positive) rows of the mask-head backward changes nothing."""
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _small_cfg("custom", 128)
+    w = _weights(cfg, 19)
+    inputs, keys = _train_inputs(cfg, 2, 21)
+    grads = []
+    for sparse in (True, False):
+        model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+        model.engine.sparse_mask_bwd = sparse
+        losses = model.train_on_batch(inputs, rand_keys=keys, apply=False)
+        torch.cuda.synchronize()
+        grads.append((losses.cpu().numpy(), model.engine.grads.cpu().numpy().copy()))
+    np.testing.assert_array_equal(grads[0][0], grads[1][0])
+    scale = np.abs(grads[1][1]).max()
+    assert np.abs(grads[0][1] - grads[1][1]).max() <= 2e-5 * scale
+    assert np.abs(grads[1][1]).sum() > 0

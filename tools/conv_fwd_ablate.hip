@@ -61,7 +61,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& p, const f32x
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool FAST>
+template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArgs p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -85,17 +85,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
     const int ks_begin = kz * p.ksteps;
     const int ks_end = (ks_begin + p.ksteps < p.nk) ? ks_begin + p.ksteps : p.nk;
 
-    // ---- per-thread tile-load bookkeeping --------------------------------------------------------
-    // FAST (Cin % 32 == 0, Cout % 4 == 0, 16-byte aligned x/w): every K-step lies inside one filter tap,
-    // so a lane's A address is  row_ptr + uniform_offset(tap, ci0)  and its validity one bit of a per-row
-    // tap mask; B is  col_ptr + uniform_offset(k).  Two 64-bit adds per load, no per-step index math.
+    // ---- per-thread A row bookkeeping -------------------------------------------------------
     const int a_c4 = tid & 7;
-    const int ohw = p.OH * p.OW;
-    const float* a_ptr[AV];
-    unsigned long long a_mask[AV];
     int a_ih0[AV], a_iw0[AV];
     long long a_nb[AV];
     bool a_ok[AV];
+    const int ohw = p.OH * p.OW;
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
         int m = m0 + (tid >> 3) + i * AROWSTEP;
@@ -106,51 +101,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
         a_ih0[i] = oh * p.stride - p.pad_t;
         a_iw0[i] = ow * p.stride - p.pad_l;
         a_nb[i] = (long long)n * p.H * p.W * p.Cin;
-        if (FAST) {
-            a_ptr[i] = p.x + a_nb[i] + ((long long)a_ih0[i] * p.W + a_iw0[i]) * p.Cin + a_c4 * 4;
-            unsigned long long mk = 0ull;
-            if (a_ok[i])
-                for (int t = 0; t < p.KH * p.KW; ++t) {
-                    int th = t / p.KW, tw = t - th * p.KW;
-                    if ((unsigned)(a_ih0[i] + th) < (unsigned)p.H && (unsigned)(a_iw0[i] + tw) < (unsigned)p.W) mk |= 1ull << t;
-                }
-            a_mask[i] = mk;
-        }
-    }
-    const float* b_ptr[BV];
-    bool b_ok[BV];
-#pragma unroll
-    for (int i = 0; i < BV; ++i) {
-        const int idx = tid + i * NT;
-        const int krow = idx / (BN / 4), c4 = idx % (BN / 4);
-        b_ok[i] = n0 + c4 * 4 < p.Cout;
-        b_ptr[i] = p.w + (long long)krow * p.Cout + n0 + c4 * 4;
     }
 
     f32x4 ra[AV], rb[BV];
-    int kh = 0, kw = 0, ci0 = 0, tap = 0;   // fast-path K-step position
-    if (FAST && ks_begin > 0) {
-        const int k0 = ks_begin * 32;
-        tap = k0 / p.Cin;
+    int kh = 0, kw = 0, ci0 = 0;   // fast-path K-step position
+    if (p.fastA && ks_begin > 0) {
+        const int k0 = ks_begin * 32, tap = k0 / p.Cin;
         ci0 = k0 - tap * p.Cin;
         kh = tap / p.KW;
         kw = tap - kh * p.KW;
     }
 
     auto load_tiles = [&](int ks) {
-        if (FAST) {
-            const long long aoff = ((long long)kh * p.W + kw) * p.Cin + ci0;
+        if (p.fastA) {
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
-                const bool v = (a_mask[i] >> tap) & 1ull;
-                ra[i] = v ? *(const f32x4*)(a_ptr[i] + aoff) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
+                bool v = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const float* ptr = p.x + a_nb[i] + ((long long)ih * p.W + iw) * p.Cin + ci0 + a_c4 * 4;
+                ra[i] = v ? *(const f32x4*)ptr : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             ci0 += 32;
-            if (ci0 >= p.Cin) { ci0 = 0; ++tap; if (++kw == p.KW) { kw = 0; ++kh; } }
-            const long long boff = (long long)ks * 32 * p.Cout;
-#pragma unroll
-            for (int i = 0; i < BV; ++i)
-                rb[i] = b_ok[i] ? *(const f32x4*)(b_ptr[i] + boff) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (ci0 >= p.Cin) { ci0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
         } else {
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
@@ -159,8 +131,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
                 for (int e = 0; e < 4; ++e) {
                     int k = ks * 32 + a_c4 * 4 + e;
                     if (a_ok[i] && k < p.Ktot) {
-                        int tp = k / p.Cin, ci = k - tp * p.Cin;
-                        int tkh = tp / p.KW, tkw = tp - tkh * p.KW;
+                        int tap = k / p.Cin, ci = k - tap * p.Cin;
+                        int tkh = tap / p.KW, tkw = tap - tkh * p.KW;
                         int ih = a_ih0[i] + tkh, iw = a_iw0[i] + tkw;
                         if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
                             v[e] = p.x[a_nb[i] + ((long long)ih * p.W + iw) * p.Cin + ci];
@@ -168,20 +140,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
                 }
                 ra[i] = v;
             }
+        }
 #pragma unroll
-            for (int i = 0; i < BV; ++i) {
-                int idx = tid + i * NT;
-                int krow = idx / (BN / 4), c4 = idx % (BN / 4);
-                int k = ks * 32 + krow, n = n0 + c4 * 4;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (k < p.Ktot) {
-                    const float* ptr = p.w + (long long)k * p.Cout + n;
+        for (int i = 0; i < BV; ++i) {
+            int idx = tid + i * NT;
+            int krow = idx / (BN / 4), c4 = idx % (BN / 4);
+            int k = ks * 32 + krow, n = n0 + c4 * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k < p.Ktot) {
+                const float* ptr = p.w + (long long)k * p.Cout + n;
+                if (p.vecB) {
+                    if (n < p.Cout) v = *(const f32x4*)ptr;
+                } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (n + e < p.Cout) v[e] = ptr[e];
                 }
-                rb[i] = v;
             }
+            rb[i] = v;
         }
     };
     auto store_tiles = [&]() {
@@ -211,7 +187,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
     store_tiles();
     __syncthreads();
     for (int ks = ks_begin; ks < ks_end; ++ks) {
+#ifndef ABL_NOGLOBAL
         if (ks + 1 < ks_end) load_tiles(ks + 1);
+#endif
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             f32x4 av[TM];
@@ -231,11 +209,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b], acc[a][b], 0, 0, 0);
             }
         }
+#ifndef ABL_NOBAR
         __syncthreads();
+#endif
+#ifndef ABL_NOSTORE
         if (ks + 1 < ks_end) {
             store_tiles();
             __syncthreads();
         }
+#endif
     }
 
     // ---- epilogue: bias, frozen-BN affine, residual, activation ---------------------------------
@@ -301,10 +283,7 @@ __global__ void conv_splitk_epilogue_kernel(const ConvArgs p) {
 template <int BM, int BN, int WM, int WN>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
     const int mt = (a.M + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
-    if (a.fastA && a.vecB)
-        hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);
-    else
-        hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);
     if (a.ksplit > 1) {
         const long long n = (long long)a.M * a.Cout;
         hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, a);
@@ -383,7 +362,7 @@ extern "C" int mrcnn_conv2d_fwd_ws(const mrcnn_conv_desc* d, const float* x, con
     a.act = d->act; a.res_mode = d->res_mode; a.out_mode = d->out_mode; a.cmod = d->cmod;
     a.ons = d->out_n_stride; a.ohs = d->out_h_stride; a.ows = d->out_w_stride;
     a.M = (int)M; a.Ktot = d->KH * d->KW * d->Cin; a.nk = (a.Ktot + 31) / 32;
-    a.fastA = (d->Cin % 32 == 0) && (d->KH * d->KW <= 64) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    a.fastA = (d->Cin % 32 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     a.vecB = (d->Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
     a.dense = d->out_mode == MRCNN_OUT_NHWC && d->out_w_stride == d->Cout &&
               d->out_h_stride == (int64_t)d->OW * d->Cout && d->out_n_stride == (int64_t)d->OH * d->OW * d->Cout;
