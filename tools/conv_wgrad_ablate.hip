@@ -119,7 +119,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(const Wgrad
         __syncthreads();
         for (int mb = m_begin; mb < m_end; mb += 32) {
             const bool more = mb + 32 < m_end;
+#ifndef ABL_NOGLOBAL
             if (more) load_tiles(mb + 32);
+#endif
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
                 const int prow = lh * 16 + t;
@@ -135,10 +137,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(const Wgrad
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
             }
             __syncthreads();
+#ifndef ABL_NOSTORE
             if (more) {
                 store_tiles();
                 __syncthreads();
             }
+#endif
         }
     }
 
@@ -153,130 +157,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_wgrad_kernel(const Wgrad
                 float* q = dst + (long long)i * p.Cout + n;
                 *q = accumulate ? *q + c[r] : c[r];
             }
-        }
-    };
-    const int ib = i0 + wm * TM * 32 + 4 * lh, nb = n0 + wn * TN * 32 + li;
-    if constexpr (TM >= 1 && TN >= 1) store_tile(acc[0][0], ib, nb);
-    if constexpr (TM >= 1 && TN >= 2) store_tile(acc[0][1], ib, nb + 32);
-    if constexpr (TM >= 2 && TN >= 1) store_tile(acc[1][0], ib + 32, nb);
-    if constexpr (TM >= 2 && TN >= 2) store_tile(acc[1][1], ib + 32, nb + 32);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// LDS-DMA variant for full tiles (Cin % BI == 0, Cout % BN == 0): both operand tiles are [BP pixels][128
-// channels] with 512-byte rows, exactly the lane-linear image a `global_load_lds_dwordx4` writes (1 KiB =
-// 2 rows per wave-instruction) and exactly what the MFMA operand reads want (lane = channel: conflict-free
-// ds_read_b32, no padding, no swizzle).  No staging VGPRs, no ds_write, one barrier per step: the DMA of
-// step t+1 lands in the other LDS buffer while the MFMAs of step t run.  Out-of-image taps and rows past
-// the pixel range read from a 64-byte zero page instead of being masked.
-__device__ __attribute__((aligned(64))) float g_zero_page[16];
-
-#ifndef WGRAD_BP
-#define WGRAD_BP 16
-#endif
-
-__device__ __forceinline__ void glds16(const float* gsrc, float* lds_dst) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-}
-
-template <int BI, int BN, int BP>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_glds_kernel(const WgradArgs p) {
-    constexpr int TM = BI / 2 / 32, TN = BN / 2 / 32;
-    constexpr int XF = BP * BI, YF = BP * BN;
-    constexpr int NXI = XF / 256, NYI = YF / 256;            // 1 KiB DMA pieces per tile
-    constexpr int XLPR = BI / 4, YLPR = BN / 4;              // lanes per row
-    constexpr int XRPI = 64 / XLPR, YRPI = 64 / YLPR;        // rows per piece
-    __shared__ __attribute__((aligned(16))) float lds[2 * (XF + YF)];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int ntiles = p.Cout / BN, itiles = p.Ktot / BI;
-    int bid = blockIdx.x;
-    const int ntile = bid % ntiles; bid /= ntiles;
-    const int itile = bid % itiles;
-    const int split = bid / itiles;
-    const int i0 = itile * BI, n0 = ntile * BN;
-    const int m_begin = split * p.chunk;
-    const int m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
-    const int tap = i0 / p.Cin, ci0 = i0 - tap * p.Cin;
-    const int kh = tap / p.KW, kw = tap - kh * p.KW;
-    const int ohw = p.OH * p.OW;
-
-    auto stage = [&](int buf, int mb) {
-        float* xb = lds + buf * (XF + YF);
-        float* yb = xb + XF;
-#pragma unroll
-        for (int jj = 0; jj < (NXI + 3) / 4; ++jj) {
-            const int j = wave + jj * 4;
-            if (j < NXI) {
-                const int m = mb + j * XRPI + lane / XLPR, c4 = lane % XLPR;
-                const float* src = g_zero_page;
-                if (m < m_end) {
-                    const int n = (int)fast_div((unsigned)m, p.d_ohw), rem = m - n * ohw;
-                    const int oh = (int)fast_div((unsigned)rem, p.d_ow), ow = rem - oh * p.OW;
-                    const int ih = oh * p.stride - p.pad_t + kh, iw = ow * p.stride - p.pad_l + kw;
-                    if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-                        src = p.x + (((long long)n * p.H + ih) * p.W + iw) * p.Cin + ci0 + c4 * 4;
-                }
-                glds16(src, xb + j * 256);
-            }
-        }
-#pragma unroll
-        for (int jj = 0; jj < (NYI + 3) / 4; ++jj) {
-            const int j = wave + jj * 4;
-            if (j < NYI) {
-                const int m = mb + j * YRPI + lane / YLPR, c4 = lane % YLPR;
-                const float* src = (m < m_end) ? p.dy + (long long)m * p.Cout + n0 + c4 * 4 : g_zero_page;
-                glds16(src, yb + j * 256);
-            }
-        }
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int li = lane & 31, lh = lane >> 5;
-    if (m_begin < m_end) {
-        stage(0, m_begin);
-        __syncthreads();
-        int cur = 0;
-        for (int mb = m_begin; mb < m_end; mb += BP) {
-            if (mb + BP < m_end) stage(cur ^ 1, mb + BP);
-            const float* xb = lds + cur * (XF + YF);
-            const float* yb = xb + XF;
-#pragma unroll
-            for (int t = 0; t < BP / 2; ++t) {
-                const int prow = lh * (BP / 2) + t;
-                float av[TM], bv[TN];
-#pragma unroll
-                for (int a = 0; a < TM; ++a) av[a] = xb[prow * BI + wm * TM * 32 + a * 32 + li];
-#pragma unroll
-                for (int b = 0; b < TN; ++b) bv[b] = yb[prow * BN + wn * TN * 32 + b * 32 + li];
-#pragma unroll
-                for (int a = 0; a < TM; ++a)
-#pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
-            }
-            __syncthreads();
-            cur ^= 1;
-        }
-    }
-
-    float* dst = p.out + (p.splits > 1 ? (long long)split * p.Ktot * p.Cout : 0LL);
-    const bool accumulate = p.splits == 1 && p.acc;
-    auto store_tile = [&](const f32x16& c, int ibase, int n) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = ibase + (r & 3) + 8 * (r >> 2);
-            float* q = dst + (long long)i * p.Cout + n;
-            *q = accumulate ? *q + c[r] : c[r];
         }
     };
     const int ib = i0 + wm * TM * 32 + 4 * lh, nb = n0 + wn * TN * 32 + li;
@@ -350,10 +230,7 @@ extern "C" int mrcnn_conv2d_wgrad(const mrcnn_conv_desc* d, const float* x, cons
     a.acc = beta_acc;
     a.d_ohw = make_fastdiv((unsigned)(d->OH * d->OW)); a.d_ow = make_fastdiv((unsigned)d->OW);
     hipStream_t s = (hipStream_t)stream;
-    if (pl.fast && pl.bi == 128 && pl.bn == 128 && d->Cout % 128 == 0 && a.Ktot % 128 == 0) {
-        const int blocks = (a.Ktot / 128) * (a.Cout / 128) * a.splits;
-        hipLaunchKernelGGL((conv_wgrad_glds_kernel<128, 128, WGRAD_BP>), dim3((unsigned)blocks), dim3(256), 0, s, a);
-    } else if (pl.bi == 128) {
+    if (pl.bi == 128) {
         if (pl.bn == 128) launch_wgrad<128, 128, 2, 2>(a, s);
         else if (pl.bn == 64) launch_wgrad<128, 64, 2, 2>(a, s);
         else launch_wgrad<128, 32, 4, 1>(a, s);
