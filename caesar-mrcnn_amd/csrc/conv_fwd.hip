@@ -262,6 +262,128 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
     if constexpr (TM >= 2 && TN >= 2) conv_epilogue_tile(p, acc[1][1], mw0 + 32, nw0 + 32);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the 128x128 tile for the large layers (no split-K, Cin % 32 == 0, Cout % 128 == 0):
+// tiles go global -> LDS with `global_load_lds_dwordx4` (no staging VGPRs, no ds_write), double buffered,
+// K-step 16, one barrier per step.  The DMA writes LDS lane-linearly (wave base + 16 B * lane), so
+//   A [128 rows][16 k] is stored row-major with 64-byte rows and its four 16-byte chunks XOR-swizzled on the
+//     SOURCE side (lane (r, c) fetches logical chunk c ^ ((r >> 2) & 3)); the MFMA operand read
+//     (ds_read_b128 of logical chunk q of row r at physical chunk q ^ ((r >> 2) & 3)) is then conflict-free
+//     for the ds_read_b128 lane groups;
+//   B [16 k][128 n] is stored as is (512-byte rows) and read with conflict-free ds_read_b32 (lane = n).
+// Padding taps / rows past M fetch from a zero page.
+__device__ __attribute__((aligned(64))) float g_conv_zero_page[16];
+
+__device__ __forceinline__ void conv_glds16(const float* gsrc, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvArgs p) {
+    constexpr int BM = 128, BN = 128, BK = 16, TM = 2, TN = 2;
+    constexpr int AF = BM * BK, BF = BK * BN;                  // floats per tile (8 KiB each)
+    __shared__ __attribute__((aligned(16))) float lds[2 * (AF + BF)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.Cout / BN;
+    const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x % ntiles;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int ohw = p.OH * p.OW;
+
+    // this wave stages A pieces {wave, wave+4} (16 rows each) and B pieces {wave, wave+4} (2 k-rows each)
+    const float* a_ptr[2];
+    unsigned long long a_mask[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int r = (wave + jj * 4) * 16 + (lane >> 2);
+        const int cl = (lane & 3) ^ ((r >> 2) & 3);
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / ohw, rem = mm - n * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
+        a_ptr[jj] = p.x + (long long)n * p.H * p.W * p.Cin + ((long long)ih0 * p.W + iw0) * p.Cin + cl * 4;
+        unsigned long long mk = 0ull;
+        if (ok)
+            for (int t = 0; t < p.KH * p.KW; ++t) {
+                const int th = t / p.KW, tw = t - th * p.KW;
+                if ((unsigned)(ih0 + th) < (unsigned)p.H && (unsigned)(iw0 + tw) < (unsigned)p.W) mk |= 1ull << t;
+            }
+        a_mask[jj] = mk;
+    }
+    const float* b_ptr[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+        b_ptr[jj] = p.w + (long long)((wave + jj * 4) * 2 + (lane >> 5)) * p.Cout + n0 + (lane & 31) * 4;
+
+    int kh = 0, kw = 0, ci0 = 0, tap = 0;
+    auto stage = [&](int buf, int ks) {
+        float* ab = lds + buf * (AF + BF);
+        float* bb = ab + AF;
+        const long long aoff = ((long long)kh * p.W + kw) * p.Cin + ci0;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const bool v = (a_mask[jj] >> tap) & 1ull;
+            conv_glds16(v ? a_ptr[jj] + aoff : g_conv_zero_page, ab + (wave + jj * 4) * 256);
+        }
+        // K is walked channel-chunk outer / filter-tap inner: the KH*KW shifted reads of one 64-byte
+        // channel chunk follow each other in time, so all but the first hit L2 (the weights just follow)
+        const long long boff = ((long long)tap * p.Cin + ci0) * p.Cout;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) conv_glds16(b_ptr[jj] + boff, bb + (wave + jj * 4) * 256);
+        ++tap;
+        if (++kw == p.KW) { kw = 0; if (++kh == p.KH) { kh = 0; tap = 0; ci0 += BK; } }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    const int nk = p.Ktot / BK;
+    stage(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + 1 < nk) stage(cur ^ 1, ks + 1);
+        const float* ab = lds + cur * (AF + BF);
+        const float* bb = ab + AF;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {              // logical chunk 2*lh + q of this half-wave's 8 k values
+            f32x4 av[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int row = wm * 64 + a * 32 + li;
+                av[a] = *(const f32x4*)&ab[row * BK + (((2 * lh + q) ^ ((row >> 2) & 3)) << 2)];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = lh * 8 + q * 4 + e;
+                float bv[TN];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bv[b] = bb[k * BN + wn * 64 + b * 32 + li];
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b], acc[a][b], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    const int mw0 = m0 + wm * 64 + 4 * lh, nw0 = n0 + wn * 64 + li;
+    conv_epilogue_tile(p, acc[0][0], mw0, nw0);
+    conv_epilogue_tile(p, acc[0][1], mw0, nw0 + 32);
+    conv_epilogue_tile(p, acc[1][0], mw0 + 32, nw0);
+    conv_epilogue_tile(p, acc[1][1], mw0 + 32, nw0 + 32);
+}
+
 // Second pass of split-K: sum the slabs in a fixed order, then the ordinary epilogue.
 __global__ void conv_splitk_epilogue_kernel(const ConvArgs p) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -396,6 +518,11 @@ extern "C" int mrcnn_conv2d_fwd_ws(const mrcnn_conv_desc* d, const float* x, con
         pl.ksteps = a.nk;
     }
     a.ksplit = pl.ksplit; a.ksteps = pl.ksteps; a.slab = (float*)workspace;
+    if (pl.bm == 128 && pl.bn == 128 && pl.ksplit == 1 && a.fastA && a.vecB && d->Cout % 128 == 0) {
+        const int mt = (a.M + 127) / 128, nt = a.Cout / 128;
+        hipLaunchKernelGGL(conv_fwd_glds_kernel, dim3((unsigned)(mt * nt)), dim3(256), 0, s, a);
+        return mrcnn_launch_status();
+    }
     if (pl.bn == 32) return pl.bm == 128 ? launch_conv<128, 32, 4, 1>(a, s) : launch_conv<64, 32, 2, 1>(a, s);
     if (pl.bn == 64) return pl.bm == 128 ? launch_conv<128, 64, 2, 2>(a, s) : launch_conv<64, 64, 2, 2>(a, s);
     return pl.bm == 128 ? launch_conv<128, 128, 2, 2>(a, s) : launch_conv<64, 128, 2, 2>(a, s);

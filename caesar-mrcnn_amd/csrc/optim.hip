@@ -15,7 +15,13 @@ __device__ __forceinline__ int find_seg(const int64_t* __restrict__ seg_offset, 
     return lo;
 }
 
-__global__ void sumsq_kernel(const float* __restrict__ g, int64_t n, float* out) {
+// Global squared norm in two fixed-order stages (per-workgroup partials, then one workgroup sums them in
+// index order): every data-parallel rank must derive bit-identical clip factors from identical gradients,
+// so no float atomics here.
+#define SUMSQ_BLOCKS 1024
+__device__ float g_sumsq_partials[SUMSQ_BLOCKS];
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n) {
     __shared__ float sbuf[4];
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -24,16 +30,29 @@ __global__ void sumsq_kernel(const float* __restrict__ g, int64_t n, float* out)
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) sbuf[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, sbuf[0] + sbuf[1] + sbuf[2] + sbuf[3]);
+    if (threadIdx.x == 0) g_sumsq_partials[blockIdx.x] = (sbuf[0] + sbuf[1]) + (sbuf[2] + sbuf[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(float* out, int nblocks) {
+    __shared__ float sbuf[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) s += g_sumsq_partials[i];
+    sbuf[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) sbuf[threadIdx.x] += sbuf[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sbuf[0];
 }
 
 extern "C" int mrcnn_sumsq(const float* g, int64_t n, float* out_scalar, void* stream) {
     if (!g || !out_scalar || n <= 0) return MRCNN_ERR_ARG;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(out_scalar, 0, sizeof(float), s) != hipSuccess) return MRCNN_ERR_LAUNCH;
     int64_t blocks = cdiv64(n, 256 * 8);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, n, out_scalar);
+    if (blocks > SUMSQ_BLOCKS) blocks = SUMSQ_BLOCKS;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, n);
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, s, out_scalar, (int)blocks);
     return mrcnn_launch_status();
 }
 

@@ -61,7 +61,7 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& p, const f32x
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool FAST>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArgs p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -85,12 +85,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
     const int ks_begin = kz * p.ksteps;
     const int ks_end = (ks_begin + p.ksteps < p.nk) ? ks_begin + p.ksteps : p.nk;
 
-    // ---- per-thread A row bookkeeping -------------------------------------------------------
+    // ---- per-thread tile-load bookkeeping --------------------------------------------------------
+    // FAST (Cin % 32 == 0, Cout % 4 == 0, 16-byte aligned x/w): every K-step lies inside one filter tap,
+    // so a lane's A address is  row_ptr + uniform_offset(tap, ci0)  and its validity one bit of a per-row
+    // tap mask; B is  col_ptr + uniform_offset(k).  Two 64-bit adds per load, no per-step index math.
     const int a_c4 = tid & 7;
+    const int ohw = p.OH * p.OW;
+    const float* a_ptr[AV];
+    unsigned long long a_mask[AV];
     int a_ih0[AV], a_iw0[AV];
     long long a_nb[AV];
     bool a_ok[AV];
-    const int ohw = p.OH * p.OW;
 #pragma unroll
     for (int i = 0; i < AV; ++i) {
         int m = m0 + (tid >> 3) + i * AROWSTEP;
@@ -101,28 +106,51 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
         a_ih0[i] = oh * p.stride - p.pad_t;
         a_iw0[i] = ow * p.stride - p.pad_l;
         a_nb[i] = (long long)n * p.H * p.W * p.Cin;
+        if (FAST) {
+            a_ptr[i] = p.x + a_nb[i] + ((long long)a_ih0[i] * p.W + a_iw0[i]) * p.Cin + a_c4 * 4;
+            unsigned long long mk = 0ull;
+            if (a_ok[i])
+                for (int t = 0; t < p.KH * p.KW; ++t) {
+                    int th = t / p.KW, tw = t - th * p.KW;
+                    if ((unsigned)(a_ih0[i] + th) < (unsigned)p.H && (unsigned)(a_iw0[i] + tw) < (unsigned)p.W) mk |= 1ull << t;
+                }
+            a_mask[i] = mk;
+        }
+    }
+    const float* b_ptr[BV];
+    bool b_ok[BV];
+#pragma unroll
+    for (int i = 0; i < BV; ++i) {
+        const int idx = tid + i * NT;
+        const int krow = idx / (BN / 4), c4 = idx % (BN / 4);
+        b_ok[i] = n0 + c4 * 4 < p.Cout;
+        b_ptr[i] = p.w + (long long)krow * p.Cout + n0 + c4 * 4;
     }
 
     f32x4 ra[AV], rb[BV];
-    int kh = 0, kw = 0, ci0 = 0;   // fast-path K-step position
-    if (p.fastA && ks_begin > 0) {
-        const int k0 = ks_begin * 32, tap = k0 / p.Cin;
+    int kh = 0, kw = 0, ci0 = 0, tap = 0;   // fast-path K-step position
+    if (FAST && ks_begin > 0) {
+        const int k0 = ks_begin * 32;
+        tap = k0 / p.Cin;
         ci0 = k0 - tap * p.Cin;
         kh = tap / p.KW;
         kw = tap - kh * p.KW;
     }
 
     auto load_tiles = [&](int ks) {
-        if (p.fastA) {
+        if (FAST) {
+            const long long aoff = ((long long)kh * p.W + kw) * p.Cin + ci0;
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
-                int ih = a_ih0[i] + kh, iw = a_iw0[i] + kw;
-                bool v = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                const float* ptr = p.x + a_nb[i] + ((long long)ih * p.W + iw) * p.Cin + ci0 + a_c4 * 4;
-                ra[i] = v ? *(const f32x4*)ptr : (f32x4){0.f, 0.f, 0.f, 0.f};
+                const bool v = (a_mask[i] >> tap) & 1ull;
+                ra[i] = v ? *(const f32x4*)(a_ptr[i] + aoff) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             ci0 += 32;
-            if (ci0 >= p.Cin) { ci0 = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+            if (ci0 >= p.Cin) { ci0 = 0; ++tap; if (++kw == p.KW) { kw = 0; ++kh; } }
+            const long long boff = (long long)ks * 32 * p.Cout;
+#pragma unroll
+            for (int i = 0; i < BV; ++i)
+                rb[i] = b_ok[i] ? *(const f32x4*)(b_ptr[i] + boff) : (f32x4){0.f, 0.f, 0.f, 0.f};
         } else {
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
@@ -131,8 +159,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
                 for (int e = 0; e < 4; ++e) {
                     int k = ks * 32 + a_c4 * 4 + e;
                     if (a_ok[i] && k < p.Ktot) {
-                        int tap = k / p.Cin, ci = k - tap * p.Cin;
-                        int tkh = tap / p.KW, tkw = tap - tkh * p.KW;
+                        int tp = k / p.Cin, ci = k - tp * p.Cin;
+                        int tkh = tp / p.KW, tkw = tp - tkh * p.KW;
                         int ih = a_ih0[i] + tkh, iw = a_iw0[i] + tkw;
                         if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
                             v[e] = p.x[a_nb[i] + ((long long)ih * p.W + iw) * p.Cin + ci];
@@ -140,24 +168,20 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
                 }
                 ra[i] = v;
             }
-        }
 #pragma unroll
-        for (int i = 0; i < BV; ++i) {
-            int idx = tid + i * NT;
-            int krow = idx / (BN / 4), c4 = idx % (BN / 4);
-            int k = ks * 32 + krow, n = n0 + c4 * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k < p.Ktot) {
-                const float* ptr = p.w + (long long)k * p.Cout + n;
-                if (p.vecB) {
-                    if (n < p.Cout) v = *(const f32x4*)ptr;
-                } else {
+            for (int i = 0; i < BV; ++i) {
+                int idx = tid + i * NT;
+                int krow = idx / (BN / 4), c4 = idx % (BN / 4);
+                int k = ks * 32 + krow, n = n0 + c4 * 4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (k < p.Ktot) {
+                    const float* ptr = p.w + (long long)k * p.Cout + n;
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (n + e < p.Cout) v[e] = ptr[e];
                 }
+                rb[i] = v;
             }
-            rb[i] = v;
         }
     };
     auto store_tiles = [&]() {
@@ -187,9 +211,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
     store_tiles();
     __syncthreads();
     for (int ks = ks_begin; ks < ks_end; ++ks) {
-#ifndef ABL_NOGLOBAL
         if (ks + 1 < ks_end) load_tiles(ks + 1);
-#endif
 #pragma unroll
         for (int t4 = 0; t4 < 4; ++t4) {
             f32x4 av[TM];
@@ -209,15 +231,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b], acc[a][b], 0, 0, 0);
             }
         }
-#ifndef ABL_NOBAR
         __syncthreads();
-#endif
-#ifndef ABL_NOSTORE
         if (ks + 1 < ks_end) {
             store_tiles();
             __syncthreads();
         }
-#endif
     }
 
     // ---- epilogue: bias, frozen-BN affine, residual, activation ---------------------------------
@@ -242,6 +260,132 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
     if constexpr (TM >= 1 && TN >= 2) conv_epilogue_tile(p, acc[0][1], mw0, nw0 + 32);
     if constexpr (TM >= 2 && TN >= 1) conv_epilogue_tile(p, acc[1][0], mw0 + 32, nw0);
     if constexpr (TM >= 2 && TN >= 2) conv_epilogue_tile(p, acc[1][1], mw0 + 32, nw0 + 32);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the 128x128 tile for the large layers (no split-K, Cin % 32 == 0, Cout % 128 == 0):
+// tiles go global -> LDS with `global_load_lds_dwordx4` (no staging VGPRs, no ds_write), double buffered,
+// K-step 16, one barrier per step.  The DMA writes LDS lane-linearly (wave base + 16 B * lane), so
+//   A [128 rows][16 k] is stored row-major with 64-byte rows and its four 16-byte chunks XOR-swizzled on the
+//     SOURCE side (lane (r, c) fetches logical chunk c ^ ((r >> 2) & 3)); the MFMA operand read
+//     (ds_read_b128 of logical chunk q of row r at physical chunk q ^ ((r >> 2) & 3)) is then conflict-free
+//     for the ds_read_b128 lane groups;
+//   B [16 k][128 n] is stored as is (512-byte rows) and read with conflict-free ds_read_b32 (lane = n).
+// Padding taps / rows past M fetch from a zero page.
+__device__ __attribute__((aligned(64))) float g_conv_zero_page[16];
+
+__device__ __forceinline__ void conv_glds16(const float* gsrc, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvArgs p) {
+    constexpr int BM = 128, BN = 128, BK = 16, TM = 2, TN = 2;
+    constexpr int AF = BM * BK, BF = BK * BN;                  // floats per tile (8 KiB each)
+    __shared__ __attribute__((aligned(16))) float lds[2 * (AF + BF)];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.Cout / BN;
+    const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x % ntiles;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int ohw = p.OH * p.OW;
+
+    // this wave stages A pieces {wave, wave+4} (16 rows each) and B pieces {wave, wave+4} (2 k-rows each)
+    const float* a_ptr[2];
+    unsigned long long a_mask[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int r = (wave + jj * 4) * 16 + (lane >> 2);
+        const int cl = (lane & 3) ^ ((r >> 2) & 3);
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / ohw, rem = mm - n * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
+        a_ptr[jj] = p.x + (long long)n * p.H * p.W * p.Cin + ((long long)ih0 * p.W + iw0) * p.Cin + cl * 4;
+        unsigned long long mk = 0ull;
+        if (ok)
+            for (int t = 0; t < p.KH * p.KW; ++t) {
+                const int th = t / p.KW, tw = t - th * p.KW;
+                if ((unsigned)(ih0 + th) < (unsigned)p.H && (unsigned)(iw0 + tw) < (unsigned)p.W) mk |= 1ull << t;
+            }
+        a_mask[jj] = mk;
+    }
+    const float* b_ptr[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj)
+        b_ptr[jj] = p.w + (long long)((wave + jj * 4) * 2 + (lane >> 5)) * p.Cout + n0 + (lane & 31) * 4;
+
+    int kh = 0, kw = 0, ci0 = 0, tap = 0;
+    auto stage = [&](int buf, int ks) {
+        float* ab = lds + buf * (AF + BF);
+        float* bb = ab + AF;
+        const long long aoff = ((long long)kh * p.W + kw) * p.Cin + ci0;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const bool v = (a_mask[jj] >> tap) & 1ull;
+            conv_glds16(v ? a_ptr[jj] + aoff : g_conv_zero_page, ab + (wave + jj * 4) * 256);
+        }
+        // K is walked channel-chunk outer / filter-tap inner: the KH*KW shifted reads of one 64-byte
+        // channel chunk follow each other in time, so all but the first hit L2 (the weights just follow)
+        const long long boff = ((long long)tap * p.Cin + ci0) * p.Cout;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) conv_glds16(b_ptr[jj] + boff, bb + (wave + jj * 4) * 256);
+        ++tap;
+        if (++kw == p.KW) { kw = 0; if (++kh == p.KH) { kh = 0; tap = 0; ci0 += BK; } }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    const int nk = p.Ktot / BK;
+    stage(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+#ifndef ABL_NOSTAGE
+        if (ks + 1 < nk) stage(cur ^ 1, ks + 1);
+#endif
+        const float* ab = lds + cur * (AF + BF);
+        const float* bb = ab + AF;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {              // logical chunk 2*lh + q of this half-wave's 8 k values
+            f32x4 av[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int row = wm * 64 + a * 32 + li;
+                av[a] = *(const f32x4*)&ab[row * BK + (((2 * lh + q) ^ ((row >> 2) & 3)) << 2)];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = lh * 8 + q * 4 + e;
+                float bv[TN];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bv[b] = bb[k * BN + wn * 64 + b * 32 + li];
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b], acc[a][b], 0, 0, 0);
+            }
+        }
+#ifndef ABL_NOBAR
+        __syncthreads();
+#endif
+        cur ^= 1;
+    }
+    const int mw0 = m0 + wm * 64 + 4 * lh, nw0 = n0 + wn * 64 + li;
+    conv_epilogue_tile(p, acc[0][0], mw0, nw0);
+    conv_epilogue_tile(p, acc[0][1], mw0, nw0 + 32);
+    conv_epilogue_tile(p, acc[1][0], mw0 + 32, nw0);
+    conv_epilogue_tile(p, acc[1][1], mw0 + 32, nw0 + 32);
 }
 
 // Second pass of split-K: sum the slabs in a fixed order, then the ordinary epilogue.
@@ -283,7 +427,10 @@ __global__ void conv_splitk_epilogue_kernel(const ConvArgs p) {
 template <int BM, int BN, int WM, int WN>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
     const int mt = (a.M + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);
+    if (a.fastA && a.vecB)
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);
+    else
+        hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);
     if (a.ksplit > 1) {
         const long long n = (long long)a.M * a.Cout;
         hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, a);
@@ -362,7 +509,7 @@ extern "C" int mrcnn_conv2d_fwd_ws(const mrcnn_conv_desc* d, const float* x, con
     a.act = d->act; a.res_mode = d->res_mode; a.out_mode = d->out_mode; a.cmod = d->cmod;
     a.ons = d->out_n_stride; a.ohs = d->out_h_stride; a.ows = d->out_w_stride;
     a.M = (int)M; a.Ktot = d->KH * d->KW * d->Cin; a.nk = (a.Ktot + 31) / 32;
-    a.fastA = (d->Cin % 32 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    a.fastA = (d->Cin % 32 == 0) && (d->KH * d->KW <= 64) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     a.vecB = (d->Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
     a.dense = d->out_mode == MRCNN_OUT_NHWC && d->out_w_stride == d->Cout &&
               d->out_h_stride == (int64_t)d->OW * d->Cout && d->out_n_stride == (int64_t)d->OH * d->OW * d->Cout;
@@ -375,6 +522,11 @@ extern "C" int mrcnn_conv2d_fwd_ws(const mrcnn_conv_desc* d, const float* x, con
         pl.ksteps = a.nk;
     }
     a.ksplit = pl.ksplit; a.ksteps = pl.ksteps; a.slab = (float*)workspace;
+    if (pl.bm == 128 && pl.bn == 128 && pl.ksplit == 1 && a.fastA && a.vecB && d->Cout % 128 == 0) {
+        const int mt = (a.M + 127) / 128, nt = a.Cout / 128;
+        hipLaunchKernelGGL(conv_fwd_glds_kernel, dim3((unsigned)(mt * nt)), dim3(256), 0, s, a);
+        return mrcnn_launch_status();
+    }
     if (pl.bn == 32) return pl.bm == 128 ? launch_conv<128, 32, 4, 1>(a, s) : launch_conv<64, 32, 2, 1>(a, s);
     if (pl.bn == 64) return pl.bm == 128 ? launch_conv<128, 64, 2, 2>(a, s) : launch_conv<64, 64, 2, 2>(a, s);
     return pl.bm == 128 ? launch_conv<128, 128, 2, 2>(a, s) : launch_conv<64, 128, 2, 2>(a, s);
