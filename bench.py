@@ -207,7 +207,10 @@ def main():
                                     "tests/test_engine_gpu.py::test_sparse_mask_backward_equals_dense); product default",
             "losses_last_step": [round(v, 5) for v in final_losses],
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4), "traffic": None,
+                         "frac": round(achieved / peak, 4),
+                         # HBM-side bytes per launch from rocprofv3 PMC passes on this shape (B = 2):
+                         # 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_conv_traffic.md (not re-measured per run)
+                         "traffic": 0.976e9 if M_rois == 1024 else None,
                          "kernel": "conv_fwd_kernel<128,128,2,2> (mask-head 3x3 conv, M=%d N=256 K=2304, "
                                    "%.1f GFLOP/launch, %.3f ms/launch)" % (M_rois * 196, flops / 1e9, k_ms)},
         }
