@@ -81,10 +81,9 @@ _SIGNATURES = {
     "mrcnn_detection_fwd": (C.c_int, [C.POINTER(DetectionDesc)] + [_P] * 6 + [C.c_size_t, _P]),
     "mrcnn_losses_workspace": (C.c_size_t, [C.POINTER(LossDesc)]),
     "mrcnn_losses_fwd_bwd": (C.c_int, [C.POINTER(LossDesc)] + [_P] * 18 + [C.c_size_t, _P]),
-    "mrcnn_grad_prepare": (C.c_int, [_P, _P, C.c_float, _P, _P, _P, _P, C.c_int, C.c_int64, _P]),
+    "mrcnn_grad_prepare": (C.c_int, [_P, _P, C.c_float, _P, C.c_int64, _P, _P]),
     "mrcnn_sumsq": (C.c_int, [_P, C.c_int64, _P, _P]),
-    "mrcnn_sgd_momentum": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float,
-                                      _P, _P, _P, C.c_int, C.c_int64, _P]),
+    "mrcnn_sgd_momentum": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, C.c_int64, _P]),
     "mrcnn_hip_version": (C.c_char_p, []),
 }
 

@@ -199,13 +199,25 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const PropArgs p) {
             keep[pos] = i;
         }
         // OR the rows of the kept boxes into the removed bitmap (only words > c matter)
+        // rows are fetched eight at a time so their (independent) loads overlap instead of paying one
+        // L2 round trip per kept box
         unsigned long long k2 = kept;
+        const bool w0 = lane > c && lane < nw, w1 = lane + 64 > c && lane + 64 < nw;
         while (k2) {
-            int t = __ffsll((long long)k2) - 1;
-            k2 &= k2 - 1ull;
-            const unsigned long long* row = mask + (int64_t)(c * 64 + t) * nw;
-            if (lane > c && lane < nw) rem0 |= row[lane];
-            if (lane + 64 > c && lane + 64 < nw) rem1 |= row[lane + 64];
+            unsigned long long v0[8], v1[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                v0[u] = 0ull; v1[u] = 0ull;
+                if (k2) {
+                    const int t = __ffsll((long long)k2) - 1;
+                    k2 &= k2 - 1ull;
+                    const unsigned long long* row = mask + (int64_t)(c * 64 + t) * nw;
+                    if (w0) v0[u] = row[lane];
+                    if (w1) v1[u] = row[lane + 64];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { rem0 |= v0[u]; rem1 |= v1[u]; }
         }
     }
     __syncthreads();

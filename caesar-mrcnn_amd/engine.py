@@ -15,7 +15,7 @@ import torch
 
 from . import ops
 from ._hip import ACT_NONE, ACT_RELU, ACT_SIGMOID, RES_NONE, RES_SAME, RES_UP2
-from .params import ParamLayout, deconv_gemm_to_keras, deconv_keras_to_gemm, init_weights
+from .params import ParamLayout, deconv_gemm_to_keras, deconv_keras_to_gemm, granule_coefficients, init_weights
 
 LOSS_NAMES = ("rpn_class_loss", "rpn_bbox_loss", "mrcnn_class_loss", "mrcnn_bbox_loss", "mrcnn_mask_loss")
 
@@ -139,8 +139,6 @@ class MaskRCNNEngine(object):
         c = max(L.bn_channels, 64)
         self.bn_mean, self.bn_var = torch.zeros(c, **f), torch.ones(c, **f)
         self.bn_scale, self.bn_shift, self.bn_rstd = torch.empty(c, **f), torch.empty(c, **f), torch.empty(c, **f)
-        self.seg_offset = torch.tensor([s[1] for s in L.segments], dtype=torch.int64, device=device)
-        self.seg_numel = torch.tensor([s[2] for s in L.segments], dtype=torch.int64, device=device)
         self.sumsq = torch.zeros(1, **f)
         self._ops = {}
         for l in L.layers:
@@ -216,9 +214,8 @@ class MaskRCNNEngine(object):
     def set_trainable(self, layer_regex):
         mask = self.layout.trainable_mask(layer_regex)
         self.trainable_host = mask
-        self.trainable = torch.tensor(mask, dtype=torch.uint8, device=self.dev)
-        self.seg_l2 = torch.tensor(self.layout.l2_coefficients(self.cfg.WEIGHT_DECAY, mask), dtype=torch.float32,
-                                   device=self.dev)
+        self.gran_coef = torch.tensor(granule_coefficients(self.layout, self.cfg.WEIGHT_DECAY, mask),
+                                      dtype=torch.float32, device=self.dev)
 
     # ---- anchors -------------------------------------------------------------------------------
     def anchors(self, image_shape):
@@ -546,9 +543,7 @@ class MaskRCNNEngine(object):
     def apply_gradients(self, learning_rate, momentum, world_size=1):
         """grads (already summed over ranks) -> /world, + L2 term, global-norm clip, SGD-momentum."""
         cfg = self.cfg
-        ops.grad_prepare(self.grads, self.params, 1.0 / world_size, self.trainable, self.seg_offset, self.seg_numel,
-                         self.seg_l2)
-        ops.sumsq(self.grads, self.sumsq)
+        ops.grad_prepare(self.grads, self.params, 1.0 / world_size, self.gran_coef, self.sumsq)
         ops.sgd_momentum(self.params, self.momentum, self.grads, self.sumsq, cfg.GRADIENT_CLIP_NORM, learning_rate,
-                         momentum, self.trainable, self.seg_offset, self.seg_numel)
+                         momentum, self.gran_coef)
         self.fold_bn()

@@ -333,11 +333,10 @@ def losses_fwd_bwd(rpn_match, rpn_bbox_t, rpn_logits, rpn_bbox, tcls, tbbox, tma
     return (losses,) + tuple(g)
 
 
-def grad_prepare(grads, params, grad_scale, trainable, seg_offset, seg_numel, seg_l2):
-    _need_cuda(grads, params, trainable, seg_offset, seg_numel, seg_l2)
-    check(_hip.lib().mrcnn_grad_prepare(ptr(grads), ptr(params), float(grad_scale), ptr(trainable), ptr(seg_offset),
-                                        ptr(seg_numel), ptr(seg_l2), seg_offset.numel(), grads.numel(),
-                                        current_stream()), "mrcnn_grad_prepare")
+def grad_prepare(grads, params, grad_scale, gran_coef, sumsq_out):
+    _need_cuda(grads, params, gran_coef, sumsq_out)
+    check(_hip.lib().mrcnn_grad_prepare(ptr(grads), ptr(params), float(grad_scale), ptr(gran_coef), grads.numel(),
+                                        ptr(sumsq_out), current_stream()), "mrcnn_grad_prepare")
 
 
 def sumsq(g, out):
@@ -345,11 +344,11 @@ def sumsq(g, out):
     check(_hip.lib().mrcnn_sumsq(ptr(g), g.numel(), ptr(out), current_stream()), "mrcnn_sumsq")
 
 
-def sgd_momentum(params, mom, grads, sumsq_t, clipnorm, lr, momentum, trainable, seg_offset, seg_numel):
-    _need_cuda(params, mom, grads, sumsq_t, trainable, seg_offset, seg_numel)
+def sgd_momentum(params, mom, grads, sumsq_t, clipnorm, lr, momentum, gran_coef):
+    _need_cuda(params, mom, grads, sumsq_t, gran_coef)
     check(_hip.lib().mrcnn_sgd_momentum(ptr(params), ptr(mom), ptr(grads), ptr(sumsq_t), float(clipnorm), float(lr),
-                                        float(momentum), 1.0, ptr(trainable), ptr(seg_offset), ptr(seg_numel),
-                                        seg_offset.numel(), params.numel(), current_stream()), "mrcnn_sgd_momentum")
+                                        float(momentum), ptr(gran_coef), params.numel(), current_stream()),
+          "mrcnn_sgd_momentum")
 
 
 def pixel_unshuffle2(src, out=None):

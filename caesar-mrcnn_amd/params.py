@@ -155,6 +155,17 @@ class ParamLayout(object):
         return out
 
 
+def granule_coefficients(layout, weight_decay, mask):
+    """Per-64-float-granule table for the optimiser kernels: L2 gradient coefficient of the tensor the
+    granule belongs to if it is trainable, -1 for frozen tensors and alignment padding."""
+    g = np.full(layout.total // ALIGN, -1.0, dtype=np.float32)
+    l2 = layout.l2_coefficients(weight_decay, mask)
+    for i, (name, off, n, _, _) in enumerate(layout.segments):
+        if mask[i]:
+            g[off // ALIGN:(off + n + ALIGN - 1) // ALIGN] = l2[i]
+    return g
+
+
 def glorot_uniform(rng, shape, fan_in, fan_out):
     lim = np.sqrt(6.0 / (fan_in + fan_out))
     return rng.uniform(-lim, lim, size=shape).astype(np.float32)

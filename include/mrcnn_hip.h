@@ -199,18 +199,19 @@ int mrcnn_losses_fwd_bwd(const mrcnn_loss_desc* d, const int32_t* rpn_match, con
                          float* d_mrcnn_mask, void* workspace, size_t workspace_bytes, void* stream);
 
 /* keras.optimizers.SGD(lr, momentum, clipnorm) + L2/numel regulariser (mrcnn/model.py:2255-2291) on
- * flat buffers.  seg_* describe the parameter tensors inside the flat buffer: offset, numel and the
- * per-tensor L2 coefficient (2*WEIGHT_DECAY/numel, or 0 for gamma/beta).                             */
-/* grads = (trainable ? grads*grad_scale + seg_l2*params : 0): averages the data-parallel gradient
- * sum (grad_scale = 1/world) and adds the regulariser term before the global norm is taken. */
-int mrcnn_grad_prepare(float* grads, const float* params, float grad_scale,
-                       const uint8_t* trainable_mask_per_seg, const int64_t* seg_offset,
-                       const int64_t* seg_numel, const float* seg_l2, int num_seg, int64_t n, void* stream);
+ * flat buffers of n floats (n % 64 == 0).  gran_coef[n/64] describes each 64-float granule (every
+ * tensor starts on a granule): >= 0 trainable with that L2 gradient coefficient (2*WEIGHT_DECAY/numel,
+ * 0 for gamma/beta); < 0 frozen tensor or alignment padding (gradient forced to 0, parameter kept).
+ *   mrcnn_grad_prepare: grads = grads*grad_scale + coef*params (grad_scale = 1/world averages the
+ *     data-parallel sum) and *sumsq_out = sum(grads^2), reduced in a fixed order so that every rank
+ *     derives the same clip factor;
+ *   mrcnn_sgd_momentum: g *= clipnorm/norm if norm >= clipnorm; v = momentum*v - lr*g; w += v.       */
+int mrcnn_grad_prepare(float* grads, const float* params, float grad_scale, const float* gran_coef,
+                       int64_t n, float* sumsq_out, void* stream);
 int mrcnn_sumsq(const float* g, int64_t n, float* out_scalar, void* stream);
-int mrcnn_sgd_momentum(float* params, float* momentum_buf, const float* grads,
-                       const float* sumsq, float clipnorm, float lr, float momentum, float grad_scale,
-                       const uint8_t* trainable_mask_per_seg, const int64_t* seg_offset,
-                       const int64_t* seg_numel, int num_seg, int64_t n, void* stream);
+int mrcnn_sgd_momentum(float* params, float* momentum_buf, const float* grads, const float* sumsq,
+                       float clipnorm, float lr, float momentum, const float* gran_coef, int64_t n,
+                       void* stream);
 
 const char* mrcnn_hip_version(void);
 

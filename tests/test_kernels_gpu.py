@@ -401,7 +401,7 @@ def test_losses(dev, dice):
 def test_sgd_step(dev):
     ops = _ops()
     rng = np.random.default_rng(51)
-    sizes = [1000, 64, 4097, 3]
+    sizes = [1000, 64, 4097, 3, 200]                 # the last tensor is frozen
     offs, off = [], 0
     for n in sizes:
         offs.append(off); off += (n + 63) // 64 * 64
@@ -411,21 +411,29 @@ def test_sgd_step(dev):
     for i, (o, n) in enumerate(zip(offs, sizes)):
         params[i], grads[i], vel[i] = _rand(rng, n), _rand(rng, n, scale=3.0), _rand(rng, n, scale=0.1)
         P[o:o + n], G[o:o + n], V[o:o + n] = params[i], grads[i], vel[i]
-    l2 = np.array([2e-4 / 1000, 0, 2e-4 / 4097, 0], np.float32)
+    l2 = np.array([2e-4 / 1000, 0, 2e-4 / 4097, 0, -1], np.float32)
+    gran = np.full(total // 64, -1, np.float32)
+    for i, (o, n) in enumerate(zip(offs, sizes)):
+        gran[o // 64:(o + n + 63) // 64] = l2[i]
     world = 2
+    frozen_p, frozen_v = params.pop(4).copy(), vel.pop(4).copy()
+    grads.pop(4)
     for i in params:
         grads[i] = grads[i] * np.float32(1.0 / world) + l2[i] * params[i]
-    Pd, Gd, Vd = (torch.tensor(a, device=dev) for a in (P, G, V))
-    so, sn = torch.tensor(offs, dtype=torch.int64, device=dev), torch.tensor(sizes, dtype=torch.int64, device=dev)
-    tr = torch.ones(4, dtype=torch.uint8, device=dev)
-    ss = torch.zeros(1, device=dev)
-    ops.grad_prepare(Gd, Pd, 1.0 / world, tr, so, sn, torch.tensor(l2, device=dev))
-    ops.sumsq(Gd, ss)
-    ops.sgd_momentum(Pd, Vd, Gd, ss, 5.0, 0.01, 0.9, tr, so, sn)
+    Pd, Gd, Vd, gd = (torch.tensor(a, device=dev) for a in (P, G, V, gran))
+    ss = torch.zeros(1, device=dev); ss2 = torch.zeros(1, device=dev)
+    ops.grad_prepare(Gd, Pd, 1.0 / world, gd, ss)
+    ops.sumsq(Gd, ss2)
+    ops.sgd_momentum(Pd, Vd, Gd, ss, 5.0, 0.01, 0.9, gd)
     torch.cuda.synchronize()
     norm = orc.sgd_step(params, grads, vel, 0.01, 0.9, 5.0)
     assert norm > 5.0
     np.testing.assert_allclose(float(ss.sqrt()), norm, rtol=1e-5)
+    np.testing.assert_allclose(float(ss2), float(ss), rtol=1e-6)
     for i, (o, n) in enumerate(zip(offs, sizes)):
+        if i == 4:
+            assert np.array_equal(Pd[o:o + n].cpu().numpy(), frozen_p) and np.array_equal(Vd[o:o + n].cpu().numpy(), frozen_v)
+            assert float(Gd[o:o + n].abs().max()) == 0.0
+            continue
         np.testing.assert_allclose(Pd[o:o + n].cpu().numpy(), params[i], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(Vd[o:o + n].cpu().numpy(), vel[i], rtol=1e-5, atol=1e-6)
