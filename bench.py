@@ -166,6 +166,14 @@ def main():
         for _ in range(args.detect_iters):
             eng.infer(x1, win)
         torch.cuda.synchronize()
+        detect_eager_ms = (time.time() - t1) / args.detect_iters * 1e3
+        for _ in range(2):
+            eng.infer_graphed(x1, win)                      # captures on first use
+        torch.cuda.synchronize()
+        t1 = time.time()
+        for _ in range(args.detect_iters):
+            eng.infer_graphed(x1, win)
+        torch.cuda.synchronize()
         detect_ms = (time.time() - t1) / args.detect_iters * 1e3
         eng.cfg = cfg
 
@@ -200,7 +208,7 @@ def main():
                                                                        "+RCCL all-reduce" if world > 1 else ""),
                        "global_batch": args.nimg * world, "parallelism": "dp%d" % world,
                        "weights": "random init (Keras defaults)"},
-            "detect_ms_per_image": round(detect_ms, 3),
+            "detect_ms_per_image": round(detect_ms, 3), "detect_ms_per_image_eager": round(detect_eager_ms, 3),
             "value_exact_zero_skip": round(args.nimg * world * args.steps / dt_sparse, 3),
             "note_exact_zero_skip": "same step with the mask-head backward restricted to the <=168 positive ROI rows "
                                     "per image (all other rows have exactly-zero gradient; results identical, "

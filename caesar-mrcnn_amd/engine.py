@@ -151,6 +151,7 @@ class MaskRCNNEngine(object):
         self.set_trainable("all")
         self.set_weights(weights if weights is not None else init_weights(L, seed))
         self._anchor_cache = {}
+        self._infer_graphs = {}
         # contiguous gradient ranges in the order the backward pass finalises them (for overlapped
         # data-parallel reduction): heads+RPN+FPN kernels, then res5..res2, then conv1 + BatchNorm blocks
         first = lambda prefix: min(o for n_, (o, _, _) in L.offsets.items() if n_.startswith(prefix) and "/kernel" in n_)
@@ -335,6 +336,34 @@ class MaskRCNNEngine(object):
         masks, _ = self._mask_head_fwd(det_boxes, pyr[:4], area, False)
         return {"detections": det, "mrcnn_class": probs, "mrcnn_bbox": bbox, "mrcnn_mask": masks, "rpn_rois": rois,
                 "rpn_class": rpn_probs, "rpn_bbox": rpn_bbox, "pyramid": pyr}
+
+    def infer_graphed(self, images, windows_norm):
+        """infer() replayed from a HIP graph (one capture per input shape): the ~450 launches of a
+        batch-1 detect pass are host-bound when issued one by one.  `images` / `windows_norm` may be host
+        or device tensors; they are copied into the graph's static input buffers."""
+        key = (tuple(images.shape), tuple(windows_norm.shape), id(self.cfg))
+        entry = self._infer_graphs.get(key)
+        if entry is None:
+            sx = torch.empty(tuple(images.shape), dtype=torch.float32, device=self.dev)
+            sw = torch.empty(tuple(windows_norm.shape), dtype=torch.float32, device=self.dev)
+            sx.copy_(images)
+            sw.copy_(windows_norm)
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                for _ in range(2):                      # sizes every workspace / caches the anchors
+                    self.infer(sx, sw)
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.infer(sx, sw)
+            entry = (graph, sx, sw, out)
+            self._infer_graphs[key] = entry
+        graph, sx, sw, out = entry
+        sx.copy_(images, non_blocking=True)
+        sw.copy_(windows_norm, non_blocking=True)
+        graph.replay()
+        return out
 
     # =========================================================================================
     #  training step: forward + backward (gradients left in self.grads)

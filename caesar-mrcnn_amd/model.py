@@ -56,6 +56,7 @@ class MaskRCNN(object):
         self.engine = self.build(mode=mode, config=config, device=device, weights=weights, seed=seed)
         self.keras_model = _GraphHandle(self)
         self._lr, self._momentum = config.LEARNING_RATE, config.LEARNING_MOMENTUM
+        self.use_hip_graph = True       # detect(): replay the inference graph instead of ~450 eager launches
 
     def print_model(self):
         print(self.keras_model.summary())
@@ -287,12 +288,16 @@ class MaskRCNN(object):
         """The seven outputs of the inference graph as host arrays (model.py:2156-2159)."""
         import torch
         eng = self.engine
-        x = torch.from_numpy(np.ascontiguousarray(molded_images, dtype=np.float32)).to(eng.dev)
+        x = torch.from_numpy(np.ascontiguousarray(molded_images, dtype=np.float32))
         meta = np.asarray(image_metas)
         shape = meta[0, 4:6].astype(np.float32)          # image_shape of the first image (model.py:891-893)
         win = (meta[:, 7:11].astype(np.float32) - np.array([0., 0., 1., 1.], np.float32)) / \
               (np.array([shape[0], shape[1], shape[0], shape[1]], np.float32) - np.float32(1.0))
-        out = eng.infer(x, torch.from_numpy(np.ascontiguousarray(win, dtype=np.float32)).to(eng.dev))
+        wt = torch.from_numpy(np.ascontiguousarray(win, dtype=np.float32))
+        if self.use_hip_graph:
+            out = eng.infer_graphed(x, wt)
+        else:
+            out = eng.infer(x.to(eng.dev), wt.to(eng.dev))
         torch.cuda.synchronize(eng.dev)
         return [out[k].cpu().numpy() for k in ("detections", "mrcnn_class", "mrcnn_bbox", "mrcnn_mask", "rpn_rois",
                                                "rpn_class", "rpn_bbox")]

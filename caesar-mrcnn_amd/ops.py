@@ -97,6 +97,7 @@ def deconv2x2(x, w_gemm, bias, act=ACT_RELU, out=None):
 
 
 _ws_cache = {}
+_ws_retired = []
 
 
 def workspace(nbytes, device, tag="default"):
@@ -104,6 +105,8 @@ def workspace(nbytes, device, tag="default"):
     key = (str(device), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _ws_retired.append(buf)     # captured HIP graphs may still point at it: never hand it back
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
