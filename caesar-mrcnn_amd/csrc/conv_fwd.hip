@@ -149,8 +149,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
             if (ci0 >= p.Cin) { ci0 = 0; ++tap; if (++kw == p.KW) { kw = 0; ++kh; } }
             const long long boff = (long long)ks * 32 * p.Cout;
 #pragma unroll
-            for (int i = 0; i < BV; ++i)
-                rb[i] = b_ok[i] ? *(const f32x4*)(b_ptr[i] + boff) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < BV; ++i) {
+                if (p.vecB) {
+                    rb[i] = b_ok[i] ? *(const f32x4*)(b_ptr[i] + boff) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                } else {                 // ragged Cout (RPN heads: 6 / 12 columns): scalar weight loads
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    const int nb = n0 + ((tid + i * NT) % (BN / 4)) * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (nb + e < p.Cout) v[e] = b_ptr[i][boff + e];
+                    rb[i] = v;
+                }
+            }
         } else {
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
@@ -423,7 +433,7 @@ __global__ void conv_splitk_epilogue_kernel(const ConvArgs p) {
 template <int BM, int BN, int WM, int WN>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
     const int mt = (a.M + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
-    if (a.fastA && a.vecB)
+    if (a.fastA)
         hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);
     else
         hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);

@@ -278,3 +278,34 @@ def test_grad_reducer_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_keras_h5_weights_roundtrip_and_by_name_semantics(tmp_path):
+    """Minimal HDF5 writer/reader (h5py absent): Keras save_weights layout, nested rpn_model group,
+    TimeDistributed names, Conv2DTranspose kernel in the Keras (2,2,out,in) layout."""
+    from caesar_mrcnn_amd import hdf5_min, weights_io
+    from caesar_mrcnn_amd.config import run_py_config
+    from caesar_mrcnn_amd.params import ParamLayout, init_weights, deconv_gemm_to_keras
+    L = ParamLayout(run_py_config(backbone="custom"))
+    w = init_weights(L, seed=4, perturb_bn=True)
+    w["mrcnn_mask_deconv/kernel"] = deconv_gemm_to_keras(w["mrcnn_mask_deconv/kernel"])
+    p = str(tmp_path / "rg-dataset20200127T1200" / "mask_rcnn_rg-dataset_0003.h5")
+    weights_io.save(p, w, L)
+    assert open(p, "rb").read(8) == b"\x89HDF\r\n\x1a\n"
+    back = weights_io.load(p)
+    assert set(back) == set(w) and all(np.array_equal(back[k], w[k]) and back[k].dtype == np.float32 for k in w)
+    f = hdf5_min.H5File(p)
+    assert "rpn_model" in f.root.children and "rpn_conv_shared" not in f.root.children
+    names = [n.decode() for n in f.root.attrs["layer_names"]]
+    assert "conv1" in names and "mrcnn_mask_deconv" in names and "rpn_model" in names
+    wn = [n.decode() for n in f.get(f.root, "mrcnn_class_bn1").attrs["weight_names"]]
+    assert wn == ["mrcnn_class_bn1/gamma:0", "mrcnn_class_bn1/beta:0", "mrcnn_class_bn1/moving_mean:0",
+                  "mrcnn_class_bn1/moving_variance:0"]
+    assert f.read(f.get(f.root, "conv1/conv1/kernel:0")).shape == (7, 7, 3, 16)
+    assert f.read(f.get(f.root, "mrcnn_mask_deconv/mrcnn_mask_deconv/kernel:0")).shape == (2, 2, 256, 256)
+    with pytest.raises(KeyError):
+        f.get(f.root, "no_such_layer")
+    bad = tmp_path / "bad.h5"
+    bad.write_bytes(b"not an hdf5 file at all")
+    with pytest.raises(ValueError):
+        hdf5_min.H5File(str(bad))
