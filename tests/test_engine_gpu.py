@@ -293,3 +293,78 @@ def test_detect_on_reference_fits_cutout_and_graph_replay(dev):
     assert res["masks"].shape[:2] == (132, 132) and res["rois"].dtype == np.int32
     assert res["rois"].shape[0] == res["class_ids"].shape[0] == res["scores"].shape[0] == res["masks"].shape[2]
     assert res["rois"].shape[0] > 0 and res["rois"].max() <= 132 and (res["class_ids"] > 0).all()
+
+
+def _full_cfg(backbone, size, mode="training", nimg=2):
+    from caesar_mrcnn_amd.config import run_py_config
+    return run_py_config(backbone=backbone, imgsize=size, mode=mode, images_per_gpu=nimg)
+
+
+def test_cfg2_full_size_training_step_r50_256(dev):
+    """BASELINE configs[1] at its real sizes: ResNet-50+FPN 256x256, 3 classes + bg, nimg_per_gpu=2, 512 train
+    ROIs, 2000 proposals, 300 GT slots -- losses and every parameter gradient against the oracle's autograd."""
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _full_cfg("resnet50", 256)
+    B = 2
+    w = _weights(cfg, 29)
+    model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+    inputs, keys = _train_inputs(cfg, B, 41)
+    losses = model.train_on_batch(inputs, rand_keys=keys, apply=False, keep_outputs=True)
+    torch.cuda.synchronize()
+    eng = model.engine
+    last = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in eng.last.items() if k != "pyramid"}
+    assert int(last["counts"][:, 0].sum()) > 0
+    images, meta, rpn_match, rpn_bbox_t, gt_cls, gt_boxes, gt_masks = inputs
+    o = orc.OracleMaskRCNN(cfg, w, requires_grad=True)
+    forced = {k: last[k] for k in ("rois", "target_class_ids", "target_bbox", "target_mask")}
+    ref = o.forward_training(images, rpn_match, rpn_bbox_t.astype(np.float32), gt_cls, gt_boxes, gt_masks,
+                             meta[:, 12:].astype(np.int32), orc.get_anchors(cfg, images.shape[1:]), keys, forced=forced)
+    np.testing.assert_allclose(losses.cpu().numpy(), [float(l.detach()) for l in ref["losses"]], rtol=2e-3, atol=1e-5)
+    o.total_loss(ref["losses"]).backward()
+    eng.apply_gradients(0.0, 0.0, world_size=1)
+    torch.cuda.synchronize()
+    g = eng.get_weights(grads=True)
+    bad = []
+    for name in eng.layout.offsets:
+        rg = o.w[name].grad.numpy()
+        scale = max(float(np.abs(rg).max()), 1e-8)
+        err = float(np.abs(g[name] - rg).max()) / scale
+        if err > 5e-3:
+            bad.append((name, err, scale))
+    assert not bad, bad[:8]
+
+
+def test_cfg4_r101_1024_tile_inference_staged(dev):
+    """BASELINE configs[3]: ResNet-101, 1024x1024 tile, 261 888 anchors -> top-6000 -> NMS -> 1000 proposals,
+    ROIAlign over a 256x256 P2: RPN outputs vs the oracle, proposal layer and detection layer index-exact on
+    the GPU's own inputs."""
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _full_cfg("resnet101", 1024, mode="inference")
+    w = _weights(cfg, 31)
+    model = MaskRCNN("inference", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+    rng = np.random.default_rng(5)
+    img = (rng.normal(0, 20, (1, 1024, 1024, 3)) + 60).astype(np.float32)
+    win = torch.tensor([[0.0, 0.0, 1.0, 1.0]], device=dev)
+    out = model.engine.infer(torch.tensor(img, device=dev), win)
+    torch.cuda.synchronize()
+    assert out["rpn_class"].shape == (1, 261888, 2)
+    o = orc.OracleMaskRCNN(cfg, w)
+    with torch.no_grad():
+        pyr = o.fpn(*o.backbone(torch.tensor(img)))
+        _, rp, rb = o.rpn(pyr)
+    _close(out["rpn_class"].cpu(), rp, 2e-3, "rpn_class")
+    _close(out["rpn_bbox"].cpu(), rb, 2e-3, "rpn_bbox")
+    anchors = orc.get_anchors(cfg, (1024, 1024, 3))
+    rois_ref, det = o.proposal_layer(out["rpn_class"].cpu(), out["rpn_bbox"].cpu(), anchors, 1000, detail=True)
+    rois = out["rpn_rois"].cpu().numpy()
+    same = np.mean(np.all(np.abs(rois - rois_ref) < 1e-5, axis=-1))
+    assert same >= 0.98, same
+    gp = [p.cpu() for p in out["pyramid"][:4]]
+    with torch.no_grad():
+        _, probs, bbox = o.classifier_head(rois, gp, float(1024 * 1024))
+    _close(out["mrcnn_class"].cpu(), probs, 2e-3, "mrcnn_class")
+    det_ref = o.refine_detections(rois[0], out["mrcnn_class"][0].cpu().numpy(), out["mrcnn_bbox"][0].cpu().numpy(),
+                                  np.array([0, 0, 1, 1], np.float32))
+    d = out["detections"][0].cpu().numpy()
+    np.testing.assert_array_equal(d[:, 4:], det_ref[:, 4:])
+    np.testing.assert_allclose(d[:, :4], det_ref[:, :4], atol=2e-6)
