@@ -68,6 +68,7 @@ _SIGNATURES = {
     "mrcnn_subsample2_bwd_acc": (C.c_int, [_P, _P] + [C.c_int] * 4 + [_P]),
     "mrcnn_upsample2_bwd": (C.c_int, [_P, _P] + [C.c_int] * 5 + [_P]),
     "mrcnn_pixel_unshuffle2": (C.c_int, [_P, _P] + [C.c_int] * 4 + [_P]),
+    "mrcnn_mask_out_bwd": (C.c_int, [_P] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_copy2d": (C.c_int, [_P, C.c_size_t, _P, C.c_size_t, C.c_size_t, C.c_size_t, _P]),
     "mrcnn_fill_zero": (C.c_int, [_P, C.c_size_t, _P]),
     "mrcnn_add_inplace": (C.c_int, [_P, _P, C.c_int64, _P]),

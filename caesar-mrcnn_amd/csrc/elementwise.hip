@@ -350,6 +350,70 @@ extern "C" int mrcnn_pixel_unshuffle2(const float* src, float* dst, int N, int H
     return mrcnn_launch_status();
 }
 
+// Fused backward of the mask-head output stage (build_fpn_mask_graph, mrcnn/model.py:1087-1090):
+//   mask = sigmoid(conv1x1(up) + b_m),  up = relu(deconv2x2(x) + b_d)
+// given dL/dmask.  One pass over `up` (the only large tensor) produces
+//   dzg   [M, H/2, W/2, 4*Cd]  gradient w.r.t. the deconv GEMM output, ReLU-masked and regrouped to GEMM columns
+//   dWm   [Cd, C]  += up^T . dz          dbm [C] += sum dz          dbd [Cd] += sum dzu
+// instead of five passes (sigmoid epilogue, 1x1 wgrad, 1x1 dgrad, ReLU epilogue, pixel unshuffle).
+// One thread per deconv channel, a workgroup walks `ppb` consecutive pixels of the [M, H, W] output grid.
+#define MOB_MAXC 16
+__global__ void mask_out_bwd_kernel(const float* __restrict__ dmask, const float* __restrict__ mask,
+                                    const float* __restrict__ up, const float* __restrict__ wm, float* dzg, float* dWm,
+                                    float* dbm, float* dbd, int64_t npix, int H, int W, int Cd, int C, int ppb) {
+    const int ci = threadIdx.x;
+    float wrow[MOB_MAXC], aw[MOB_MAXC];
+#pragma unroll
+    for (int c = 0; c < MOB_MAXC; ++c) { wrow[c] = c < C ? wm[(int64_t)ci * C + c] : 0.f; aw[c] = 0.f; }
+    float abd = 0.f, abm = 0.f;
+    const int64_t p0 = (int64_t)blockIdx.x * ppb;
+    int64_t p1 = p0 + ppb;
+    if (p1 > npix) p1 = npix;
+    const int hw = H * W, W2 = W >> 1, H2 = H >> 1;
+    for (int64_t pix = p0; pix < p1; ++pix) {
+        float dz[MOB_MAXC];
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < MOB_MAXC; ++c) {
+            if (c < C) {
+                const float g = dmask[pix * C + c], q = mask[pix * C + c];
+                dz[c] = g * q * (1.f - q);
+                d += dz[c] * wrow[c];
+            } else {
+                dz[c] = 0.f;
+            }
+        }
+        const float u = up[pix * Cd + ci];
+#pragma unroll
+        for (int c = 0; c < MOB_MAXC; ++c) aw[c] += u * dz[c];
+        if (ci < C) abm += dz[ci];
+        const float dzu = u > 0.f ? d : 0.f;
+        abd += dzu;
+        const int64_t n = pix / hw;
+        const int rem = (int)(pix - n * hw);
+        const int y = rem / W, x = rem - y * W;
+        dzg[(((n * H2 + (y >> 1)) * W2 + (x >> 1)) * 4 + ((y & 1) * 2 + (x & 1))) * Cd + ci] = dzu;
+    }
+#pragma unroll
+    for (int c = 0; c < MOB_MAXC; ++c)
+        if (c < C) atomicAdd(&dWm[(int64_t)ci * C + c], aw[c]);
+    atomicAdd(&dbd[ci], abd);
+    if (ci < C) atomicAdd(&dbm[ci], abm);
+}
+
+extern "C" int mrcnn_mask_out_bwd(const float* d_mask_out, const float* mask_out, const float* up, const float* w_mask,
+                                  float* dzg, float* dw_mask, float* db_mask, float* db_deconv, int64_t M, int H, int W,
+                                  int Cd, int C, void* stream) {
+    if (!d_mask_out || !mask_out || !up || !w_mask || !dzg || !dw_mask || !db_mask || !db_deconv) return MRCNN_ERR_ARG;
+    if (M <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cd < 64 || Cd > 1024 || (Cd & 63) || C < 1 || C > MOB_MAXC)
+        return MRCNN_ERR_ARG;
+    const int64_t npix = M * H * W;
+    int ppb = 128;
+    hipLaunchKernelGGL(mask_out_bwd_kernel, dim3((unsigned)cdiv64(npix, ppb)), dim3(Cd), 0, (hipStream_t)stream,
+                       d_mask_out, mask_out, up, w_mask, dzg, dw_mask, db_mask, db_deconv, npix, H, W, Cd, C, ppb);
+    return mrcnn_launch_status();
+}
+
 // Strided row copy on the DMA path (no kernel): `rows` rows of `row_bytes` bytes.
 extern "C" int mrcnn_copy2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t row_bytes,
                             size_t rows, void* stream) {

@@ -160,6 +160,7 @@ class MaskRCNNEngine(object):
                             "head": (0, s2), "bn": (L.gamma_offset, L.total)}
         self.grad_ready = None          # callable(start, end) or None
         self.sparse_mask_bwd = True     # skip the exactly-zero rows of the mask-head backward
+        self.fused_mask_out_bwd = True  # single-pass backward of the mask-head output stage
 
     def op(self, name):
         return self._ops[name]
@@ -437,14 +438,21 @@ class MaskRCNNEngine(object):
         cfg = self.cfg
         c1, c2, c3, c4, cdec, cm = ctxs
         mop, dc = self.op("mrcnn_mask"), self.op("mrcnn_mask_deconv")
-        dz, _ = mop.epilogue_bwd(g, cm)
-        mop.wgrad(dz, cm, accumulate=acc)
-        d_up = mop.dgrad(dz, cm)                                    # [M,28,28,256]
-        # deconv: relu mask + bias, regroup to GEMM columns, then the two GEMM adjoints
         x_in, _, up, _ = cdec
-        dzu = torch.empty_like(d_up)
-        ops.epilogue_bwd(d_up, up, None, None, None, None, None, dzu, None, None, dc.db, ACT_RELU)
-        dzg = ops.pixel_unshuffle2(dzu)                             # [M,14,14,1024]
+        C_ = cm[2].shape[-1]
+        if self.fused_mask_out_bwd and C_ <= 16 and up.shape[-1] % 64 == 0 and up.shape[-1] <= 1024:
+            # one pass over `up`: sigmoid', 1x1 conv wgrad/dgrad/bias, ReLU mask, deconv bias, GEMM regrouping
+            # (dw accumulates: the flat gradient buffer was zeroed at the start of the step)
+            dzg = ops.mask_out_bwd(g, cm[2], up, mop.w.view(mop.wshape[2], mop.wshape[3]),
+                                   mop.dw.view(mop.wshape[2], mop.wshape[3]), mop.db, dc.db)
+        else:
+            dz, _ = mop.epilogue_bwd(g, cm)
+            mop.wgrad(dz, cm, accumulate=acc)
+            d_up = mop.dgrad(dz, cm)                                    # [M,28,28,256]
+            # deconv: relu mask + bias, regroup to GEMM columns, then the two GEMM adjoints
+            dzu = torch.empty_like(d_up)
+            ops.epilogue_bwd(d_up, up, None, None, None, None, None, dzu, None, None, dc.db, ACT_RELU)
+            dzg = ops.pixel_unshuffle2(dzu)                             # [M,14,14,1024]
         ops.conv2d_wgrad(x_in, dzg, dc.wshape, 1, "valid", dw=dc.dw, accumulate=acc)
         ops.weight_flip_transpose(dc.w, dc.wt)
         d = ops.conv2d(dzg, dc.wt, stride=1, padding="valid")

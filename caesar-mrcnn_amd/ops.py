@@ -373,3 +373,16 @@ def copy2d(dst_ptr, dst_pitch, src_ptr, src_pitch, row_bytes, rows):
 def fill_zero(t):
     _need_cuda(t)
     check(_hip.lib().mrcnn_fill_zero(ptr(t), t.numel() * t.element_size(), current_stream()), "mrcnn_fill_zero")
+
+
+def mask_out_bwd(d_mask, mask, up, w_mask, dw_mask, db_mask, db_deconv):
+    """Fused backward of sigmoid(conv1x1(relu(deconv))) -> dzg [M, H/2, W/2, 4*Cd]; the three small
+    gradients accumulate in place."""
+    _need_cuda(d_mask, mask, up, w_mask, dw_mask, db_mask, db_deconv)
+    M, H, W, Cd = up.shape
+    C_ = mask.shape[-1]
+    dzg = torch.empty((M, H // 2, W // 2, 4 * Cd), dtype=torch.float32, device=up.device)
+    check(_hip.lib().mrcnn_mask_out_bwd(ptr(d_mask), ptr(mask), ptr(up), ptr(w_mask), ptr(dzg), ptr(dw_mask),
+                                        ptr(db_mask), ptr(db_deconv), M, H, W, Cd, C_, current_stream()),
+          "mrcnn_mask_out_bwd")
+    return dzg

@@ -112,6 +112,13 @@ int mrcnn_upsample2_bwd(const float* dout, float* dsrc, int N, int H, int W, int
 
 /* dst[n,h,w,(a*2+b)*C+c] = src[n,2h+a,2w+b,c] (gradient regrouping for Conv2DTranspose 2x2/s2). */
 int mrcnn_pixel_unshuffle2(const float* src, float* dst, int N, int H, int W, int C, void* stream);
+/* Fused backward of the mask-head output stage (mrcnn/model.py:1087-1090): given dL/dmask [M,H,W,C] (after
+ * the sigmoid), mask [M,H,W,C], up = relu(deconv) [M,H,W,Cd] and the 1x1 kernel w_mask [Cd,C]:
+ * dzg [M,H/2,W/2,4*Cd] = ReLU-masked gradient of the deconv GEMM output (columns (a*2+b)*Cd+co);
+ * dw_mask [Cd,C], db_mask [C], db_deconv [Cd] accumulate (float atomics).  C <= 16, Cd % 64 == 0.     */
+int mrcnn_mask_out_bwd(const float* d_mask_out, const float* mask_out, const float* up, const float* w_mask,
+                       float* dzg, float* dw_mask, float* db_mask, float* db_deconv, int64_t M, int H, int W,
+                       int Cd, int C, void* stream);
 /* DMA helpers (hipMemcpy2DAsync / hipMemsetAsync on `stream`), device to device. */
 int mrcnn_copy2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t row_bytes,
                  size_t rows, void* stream);

@@ -368,3 +368,20 @@ def test_cfg4_r101_1024_tile_inference_staged(dev):
     d = out["detections"][0].cpu().numpy()
     np.testing.assert_array_equal(d[:, 4:], det_ref[:, 4:])
     np.testing.assert_allclose(d[:, :4], det_ref[:, :4], atol=2e-6)
+
+
+def test_fused_mask_output_backward_equals_unfused(dev):
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _small_cfg("custom", 128)
+    w = _weights(cfg, 37)
+    inputs, keys = _train_inputs(cfg, 2, 43)
+    grads = []
+    for fused in (True, False):
+        model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+        model.engine.fused_mask_out_bwd = fused
+        model.engine.sparse_mask_bwd = False
+        model.train_on_batch(inputs, rand_keys=keys, apply=False)
+        torch.cuda.synchronize()
+        grads.append(model.engine.grads.cpu().numpy().copy())
+    scale = np.abs(grads[1]).max()
+    assert np.abs(grads[0] - grads[1]).max() <= 2e-5 * scale
