@@ -358,47 +358,59 @@ extern "C" int mrcnn_pixel_unshuffle2(const float* src, float* dst, int N, int H
 // instead of five passes (sigmoid epilogue, 1x1 wgrad, 1x1 dgrad, ReLU epilogue, pixel unshuffle).
 // One thread per deconv channel, a workgroup walks `ppb` consecutive pixels of the [M, H, W] output grid.
 #define MOB_MAXC 16
+#define MOB_PPB 128
+template <int CP>      // CP = C rounded up to 4 / 8 / 16
 __global__ void mask_out_bwd_kernel(const float* __restrict__ dmask, const float* __restrict__ mask,
                                     const float* __restrict__ up, const float* __restrict__ wm, float* dzg, float* dWm,
-                                    float* dbm, float* dbd, int64_t npix, int H, int W, int Cd, int C, int ppb) {
+                                    float* dbm, float* dbd, int64_t npix, int H, int W, int Cd, int C) {
+    __shared__ __attribute__((aligned(16))) float sdz[MOB_PPB * CP];
     const int ci = threadIdx.x;
-    float wrow[MOB_MAXC], aw[MOB_MAXC];
+    const int64_t p0 = (int64_t)blockIdx.x * MOB_PPB;
+    const int np = (int)((npix - p0) < MOB_PPB ? (npix - p0) : MOB_PPB);
+    // dz = dL/dmask * sigmoid' for this workgroup's pixels, once, into LDS
+    for (int i = ci; i < MOB_PPB * CP; i += blockDim.x) {
+        const int pl = i / CP, c = i - pl * CP;
+        float v = 0.f;
+        if (pl < np && c < C) {
+            const float g = dmask[(p0 + pl) * C + c], q = mask[(p0 + pl) * C + c];
+            v = g * q * (1.f - q);
+        }
+        sdz[i] = v;
+    }
+    float wrow[CP], aw[CP];
 #pragma unroll
-    for (int c = 0; c < MOB_MAXC; ++c) { wrow[c] = c < C ? wm[(int64_t)ci * C + c] : 0.f; aw[c] = 0.f; }
-    float abd = 0.f, abm = 0.f;
-    const int64_t p0 = (int64_t)blockIdx.x * ppb;
-    int64_t p1 = p0 + ppb;
-    if (p1 > npix) p1 = npix;
+    for (int c = 0; c < CP; ++c) { wrow[c] = c < C ? wm[(int64_t)ci * C + c] : 0.f; aw[c] = 0.f; }
+    float abd = 0.f;
+    __syncthreads();
     const int hw = H * W, W2 = W >> 1, H2 = H >> 1;
-    for (int64_t pix = p0; pix < p1; ++pix) {
-        float dz[MOB_MAXC];
+    const float* upp = up + p0 * Cd + ci;
+#pragma unroll 4
+    for (int pl = 0; pl < np; ++pl) {
+        const float u = upp[(int64_t)pl * Cd];
         float d = 0.f;
 #pragma unroll
-        for (int c = 0; c < MOB_MAXC; ++c) {
-            if (c < C) {
-                const float g = dmask[pix * C + c], q = mask[pix * C + c];
-                dz[c] = g * q * (1.f - q);
-                d += dz[c] * wrow[c];
-            } else {
-                dz[c] = 0.f;
-            }
-        }
-        const float u = up[pix * Cd + ci];
+        for (int c4 = 0; c4 < CP; c4 += 4) {
+            const f32x4 z = *(const f32x4*)&sdz[pl * CP + c4];          // LDS broadcast
 #pragma unroll
-        for (int c = 0; c < MOB_MAXC; ++c) aw[c] += u * dz[c];
-        if (ci < C) abm += dz[ci];
+            for (int e = 0; e < 4; ++e) { d += z[e] * wrow[c4 + e]; aw[c4 + e] += u * z[e]; }
+        }
         const float dzu = u > 0.f ? d : 0.f;
         abd += dzu;
+        const int64_t pix = p0 + pl;
         const int64_t n = pix / hw;
         const int rem = (int)(pix - n * hw);
         const int y = rem / W, x = rem - y * W;
         dzg[(((n * H2 + (y >> 1)) * W2 + (x >> 1)) * 4 + ((y & 1) * 2 + (x & 1))) * Cd + ci] = dzu;
     }
 #pragma unroll
-    for (int c = 0; c < MOB_MAXC; ++c)
+    for (int c = 0; c < CP; ++c)
         if (c < C) atomicAdd(&dWm[(int64_t)ci * C + c], aw[c]);
     atomicAdd(&dbd[ci], abd);
-    if (ci < C) atomicAdd(&dbm[ci], abm);
+    if (ci < C) {
+        float s_ = 0.f;
+        for (int pl = 0; pl < np; ++pl) s_ += sdz[pl * CP + ci];
+        atomicAdd(&dbm[ci], s_);
+    }
 }
 
 extern "C" int mrcnn_mask_out_bwd(const float* d_mask_out, const float* mask_out, const float* up, const float* w_mask,
@@ -408,9 +420,17 @@ extern "C" int mrcnn_mask_out_bwd(const float* d_mask_out, const float* mask_out
     if (M <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cd < 64 || Cd > 1024 || (Cd & 63) || C < 1 || C > MOB_MAXC)
         return MRCNN_ERR_ARG;
     const int64_t npix = M * H * W;
-    int ppb = 128;
-    hipLaunchKernelGGL(mask_out_bwd_kernel, dim3((unsigned)cdiv64(npix, ppb)), dim3(Cd), 0, (hipStream_t)stream,
-                       d_mask_out, mask_out, up, w_mask, dzg, dw_mask, db_mask, db_deconv, npix, H, W, Cd, C, ppb);
+    const dim3 grid((unsigned)cdiv64(npix, MOB_PPB)), block(Cd);
+    hipStream_t s = (hipStream_t)stream;
+    if (C <= 4)
+        hipLaunchKernelGGL(mask_out_bwd_kernel<4>, grid, block, 0, s, d_mask_out, mask_out, up, w_mask, dzg, dw_mask,
+                           db_mask, db_deconv, npix, H, W, Cd, C);
+    else if (C <= 8)
+        hipLaunchKernelGGL(mask_out_bwd_kernel<8>, grid, block, 0, s, d_mask_out, mask_out, up, w_mask, dzg, dw_mask,
+                           db_mask, db_deconv, npix, H, W, Cd, C);
+    else
+        hipLaunchKernelGGL(mask_out_bwd_kernel<16>, grid, block, 0, s, d_mask_out, mask_out, up, w_mask, dzg, dw_mask,
+                           db_mask, db_deconv, npix, H, W, Cd, C);
     return mrcnn_launch_status();
 }
 

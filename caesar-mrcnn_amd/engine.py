@@ -156,8 +156,9 @@ class MaskRCNNEngine(object):
         # data-parallel reduction): heads+RPN+FPN kernels, then res5..res2, then conv1 + BatchNorm blocks
         first = lambda prefix: min(o for n_, (o, _, _) in L.offsets.items() if n_.startswith(prefix) and "/kernel" in n_)
         s2, s3, s4, s5, fp = first("res2"), first("res3"), first("res4"), first("res5"), first("fpn_")
-        self.grad_ranges = {"tail": (fp, L.gamma_offset), 5: (s5, fp), 4: (s4, s5), 3: (s3, s4), 2: (s2, s3),
-                            "head": (0, s2), "bn": (L.gamma_offset, L.total)}
+        hd = first("mrcnn_")
+        self.grad_ranges = {"heads": (hd, L.gamma_offset), "tail": (fp, hd), 5: (s5, fp), 4: (s4, s5), 3: (s3, s4),
+                            2: (s2, s3), "head": (0, s2), "bn": (L.gamma_offset, L.total)}
         self.grad_ready = None          # callable(start, end) or None
         self.sparse_mask_bwd = True     # skip the exactly-zero rows of the mask-head backward
         self.fused_mask_out_bwd = True  # single-pass backward of the mask-head output stage
@@ -405,6 +406,8 @@ class MaskRCNNEngine(object):
             ops.fill_zero(t)
         self._mask_head_bwd(d_mmask, ctx_mask, rois, dP, area)
         self._class_head_bwd(d_logits, d_mbbox, ctx_cls, rois, dP, area)
+        if self.grad_ready:                      # ~2/3 of the gradient bytes (FC1 alone is 51 MB) are final here,
+            self.grad_ready(*self.grad_ranges["heads"])     # with the whole RPN/FPN/backbone backward left to hide them
         dP6 = self._rpn_bwd(d_rpn_logits, d_rpn_bbox, rpn_tape, dP)
         self._trunk_bwd(dP, dP6, tape)
         if keep_outputs:
