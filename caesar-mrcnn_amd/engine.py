@@ -25,6 +25,7 @@ class ConvOp(object):
 
     def __init__(self, model, spec):
         L = model.layout
+        self.model = model
         self.spec = spec
         self.name = spec.name
         off, n, shape = L.offsets[spec.name + "/kernel"]
@@ -75,9 +76,7 @@ class ConvOp(object):
         return dz, dy
 
     def wgrad(self, dz, ctx, accumulate=False):
-        x = ctx[0]
-        ops.conv2d_wgrad(x, dz.view(dz.shape[0], dz.shape[1], dz.shape[2], self.wshape[3]), self.wshape, self.stride,
-                         self.padding, dw=self.dw, accumulate=accumulate)
+        self.model.wgrad_async(ctx[0], dz, self.wshape, self.stride, self.padding, self.dw, accumulate)
 
     def dgrad(self, dz, ctx, out=None, accumulate=False):
         """dx = adjoint of the convolution applied to dz.  `out` (shape of x) receives the result;
@@ -162,9 +161,32 @@ class MaskRCNNEngine(object):
         self.grad_ready = None          # callable(start, end) or None
         self.sparse_mask_bwd = True     # skip the exactly-zero rows of the mask-head backward
         self.fused_mask_out_bwd = True  # single-pass backward of the mask-head output stage
+        self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
 
     def op(self, name):
         return self._ops[name]
+
+    # ---- weight gradients on a second stream -------------------------------------------------------
+    def wgrad_async(self, x, dz, wshape, stride, padding, dw, accumulate):
+        """A layer's weight gradient depends only on (x, dz); nothing in the backward chain reads it.  It is
+        launched on a side stream so that it overlaps the data-gradient convolution of the same layer: the
+        partial last round of one grid (and the small grids of the backbone) fill the CUs the other leaves
+        idle.  All weight gradients share that one stream (and its slab workspace), in program order."""
+        ws = self.wgrad_stream
+        if ws is None:
+            ops.conv2d_wgrad(x, dz, wshape, stride, padding, dw=dw, accumulate=accumulate)
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(ws):
+            ws.wait_event(ev)
+            ops.conv2d_wgrad(x, dz, wshape, stride, padding, dw=dw, accumulate=accumulate)
+        dz.record_stream(ws)
+        x.record_stream(ws)
+
+    def join_wgrad(self):
+        if self.wgrad_stream is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.wgrad_stream)
 
     # ---- weights in / out (Keras layouts at this boundary) --------------------------------------
     def set_weights(self, weights, strict=True):
@@ -407,6 +429,7 @@ class MaskRCNNEngine(object):
         self._mask_head_bwd(d_mmask, ctx_mask, rois, dP, area)
         self._class_head_bwd(d_logits, d_mbbox, ctx_cls, rois, dP, area)
         if self.grad_ready:                      # ~2/3 of the gradient bytes (FC1 alone is 51 MB) are final here,
+            self.join_wgrad()
             self.grad_ready(*self.grad_ranges["heads"])     # with the whole RPN/FPN/backbone backward left to hide them
         dP6 = self._rpn_bwd(d_rpn_logits, d_rpn_bbox, rpn_tape, dP)
         self._trunk_bwd(dP, dP6, tape)
@@ -456,7 +479,7 @@ class MaskRCNNEngine(object):
             dzu = torch.empty_like(d_up)
             ops.epilogue_bwd(d_up, up, None, None, None, None, None, dzu, None, None, dc.db, ACT_RELU)
             dzg = ops.pixel_unshuffle2(dzu)                             # [M,14,14,1024]
-        ops.conv2d_wgrad(x_in, dzg, dc.wshape, 1, "valid", dw=dc.dw, accumulate=acc)
+        self.wgrad_async(x_in, dzg, dc.wshape, 1, "valid", dc.dw, acc)
         ops.weight_flip_transpose(dc.w, dc.wt)
         d = ops.conv2d(dzg, dc.wt, stride=1, padding="valid")
         for i, c in ((4, c4), (3, c3), (2, c2), (1, c1)):
@@ -536,6 +559,7 @@ class MaskRCNNEngine(object):
             op.wgrad(dz, c)
             dC.append(op.dgrad(dz, c))
         if self.grad_ready:
+            self.join_wgrad()
             self.grad_ready(*self.grad_ranges["tail"])
         d_out = dC[3]                                   # gradient w.r.t. C5
         for si in (3, 2, 1, 0):
@@ -546,12 +570,14 @@ class MaskRCNNEngine(object):
                 acc_buf = dC[si - 1] if (bi == 0 and si > 0) else None
                 d_out = self._block_bwd(blk, d_out, tape[id(blk)], acc_buf)
             if self.grad_ready:
+                self.join_wgrad()
                 self.grad_ready(*self.grad_ranges[si + 2])
         am, pre_shape = tape["pool"]
         d_relu = ops.maxpool3x3s2_bwd(d_out, am, pre_shape)
         c1 = self.op("conv1")
         dz, _ = c1.epilogue_bwd(d_relu, tape["conv1"])
         c1.wgrad(dz, tape["conv1"])
+        self.join_wgrad()
         if self.grad_ready:
             self.grad_ready(*self.grad_ranges["head"])
             self.grad_ready(*self.grad_ranges["bn"])
