@@ -162,6 +162,7 @@ class MaskRCNNEngine(object):
         self.sparse_mask_bwd = True     # skip the exactly-zero rows of the mask-head backward
         self.fused_mask_out_bwd = True  # single-pass backward of the mask-head output stage
         self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self.aux_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
 
     def op(self, name):
         return self._ops[name]
@@ -415,8 +416,23 @@ class MaskRCNNEngine(object):
         rois, tcls, tbbox, tmask, assign, counts = ops.detection_targets(
             rpn_rois, gt_class_ids, gt_boxes_norm, gt_masks, rand_keys, cfg.TRAIN_ROIS_PER_IMAGE,
             cfg.ROI_POSITIVE_RATIO, cfg.BBOX_STD_DEV, cfg.MASK_SHAPE, cfg.USE_MINI_MASK)
-        logits, probs, mbbox, ctx_cls = self._class_head_fwd(rois, pyr[:4], area, True)
-        mmask, ctx_mask = self._mask_head_fwd(rois, pyr[:4], area, True)
+        # the two heads are independent: the (small) class/box head runs on the auxiliary stream beside the
+        # mask head, forward and backward
+        main, aux = torch.cuda.current_stream(self.dev), self.aux_stream
+        if aux is not None:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(aux):
+                aux.wait_event(ev)
+                logits, probs, mbbox, ctx_cls = self._class_head_fwd(rois, pyr[:4], area, True)
+            mmask, ctx_mask = self._mask_head_fwd(rois, pyr[:4], area, True)
+            main.wait_stream(aux)
+            for t in (logits, probs, mbbox):
+                t.record_stream(main)
+            rois.record_stream(aux)
+        else:
+            logits, probs, mbbox, ctx_cls = self._class_head_fwd(rois, pyr[:4], area, True)
+            mmask, ctx_mask = self._mask_head_fwd(rois, pyr[:4], area, True)
         out = ops.losses_fwd_bwd(rpn_match, rpn_bbox_t, rpn_logits, rpn_bbox, tcls, tbbox, tmask, active_class_ids,
                                  logits, mbbox, mmask, self.loss_weights(),
                                  cfg.MASK_LOSS_FUNCTION == "dice_coef_loss")
@@ -426,8 +442,19 @@ class MaskRCNNEngine(object):
         dP = [torch.empty_like(p) for p in pyr[:4]]
         for t in dP:
             ops.fill_zero(t)
-        self._mask_head_bwd(d_mmask, ctx_mask, rois, dP, area)
-        self._class_head_bwd(d_logits, d_mbbox, ctx_cls, rois, dP, area)
+        if aux is not None:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(aux):
+                aux.wait_event(ev)
+                self._class_head_bwd(d_logits, d_mbbox, ctx_cls, rois, dP, area)
+            self._mask_head_bwd(d_mmask, ctx_mask, rois, dP, area)
+            main.wait_stream(aux)
+            d_logits.record_stream(aux)
+            d_mbbox.record_stream(aux)
+        else:
+            self._mask_head_bwd(d_mmask, ctx_mask, rois, dP, area)
+            self._class_head_bwd(d_logits, d_mbbox, ctx_cls, rois, dP, area)
         if self.grad_ready:                      # ~2/3 of the gradient bytes (FC1 alone is 51 MB) are final here,
             self.join_wgrad()
             self.grad_ready(*self.grad_ranges["heads"])     # with the whole RPN/FPN/backbone backward left to hide them

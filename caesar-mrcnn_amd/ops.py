@@ -102,7 +102,7 @@ _ws_retired = []
 
 def workspace(nbytes, device, tag="default"):
     """Grow-only scratch buffer per (device, tag) -- nothing is allocated inside the C-ABI calls."""
-    key = (str(device), tag)
+    key = (str(device), tag, current_stream())        # one scratch buffer per stream: concurrent branches never share
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
