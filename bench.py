@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mask R-CNN training throughput (images/s, whole job) and detect latency on
 synthetic 256x256 3-class radio tiles, float32, on N MI355X of one node (one process per GPU).
+Default workload = the one BASELINE.json's metric is quoted on (ResNet-101 256x256, nimg_per_gpu=4, i.e.
+configs[2] per GPU); at N=1 the line also carries configs[1] (ResNet-50, nimg_per_gpu=2) as a second leg.
 
     python bench.py --gpus N --steps K --warmup W
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
@@ -86,37 +88,24 @@ def cpu_baseline(cfg, weights, batch, cores):
                       "restatement of the reference graph, not TF1), %.1f s" % (n, dt)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--backbone", default="resnet50")
-    ap.add_argument("--imgsize", type=int, default=256)
-    ap.add_argument("--nimg", type=int, default=2, help="images per GPU (IMAGES_PER_GPU)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--detect-iters", type=int, default=10)
-    ap.add_argument("--dense-only", action="store_true", help="skip the exact-zero-skip timing loop (profiling)")
-    args = ap.parse_args()
+TRAFFIC_PER_LAUNCH = {1024: 0.976e9, 2048: 2.162e9}   # mask-head conv, PMC passes: profiles/r01_pmc_conv_traffic.md
 
+
+def measure(args, backbone, nimg, rank, local_rank, world, full):
+    """Train-step throughput (+ detect latency, roofline, cpu_baseline when ``full``) of one workload."""
     import torch
+    import torch.distributed as dist
     from caesar_mrcnn_amd import ops
     from caesar_mrcnn_amd.config import run_py_config
     from caesar_mrcnn_amd.model import MaskRCNN
-    from caesar_mrcnn_amd.parallel import GradReducer, init_distributed
-    import torch.distributed as dist
+    from caesar_mrcnn_amd.parallel import GradReducer
 
-    rank, local_rank, world = init_distributed()
-    if world != args.gpus:
-        if rank == 0:
-            sys.stderr.write("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n" % (args.gpus, world))
     dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-    cfg = run_py_config(num_classes=4, imgsize=args.imgsize, backbone=args.backbone, images_per_gpu=args.nimg,
+    cfg = run_py_config(num_classes=4, imgsize=args.imgsize, backbone=backbone, images_per_gpu=nimg,
                         gpu_count=world)
     model = MaskRCNN("training", cfg, "/tmp/mrcnn_bench_logs", device=dev, seed=0)
     model.compile(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM)
-    batch = synthetic_batch(cfg, args.nimg, seed=1234 + rank)
+    batch = synthetic_batch(cfg, nimg, seed=1234 + rank)
     dev_inputs = model._to_device(batch)
     eng = model.engine
     reducer = GradReducer(eng.grads, world) if world > 1 else None
@@ -158,87 +147,132 @@ def main():
     else:
         step()
         dt_sparse, _ = timed(args.steps)
-    ms_per_step = dt / args.steps * 1e3
-    images_per_s = args.nimg * world * args.steps / dt
-    final_losses = [float(v) for v in losses.cpu().numpy()]
+    res = {"backbone": backbone, "nimg": nimg, "ms_per_step": dt / args.steps * 1e3,
+           "images_per_s": nimg * world * args.steps / dt,
+           "images_per_s_sparse": None if args.dense_only else nimg * world * args.steps / dt_sparse,
+           "losses": [float(v) for v in losses.cpu().numpy()]}
+    if rank != 0:
+        return res
+
+    # ---- detect latency (inference graph, batch 1), same weights -----------------------------------
+    x1 = dev_inputs[0][:1].contiguous()
+    win = torch.tensor([[0.0, 0.0, 1.0, 1.0]], device=dev)
+    icfg = run_py_config(num_classes=4, imgsize=args.imgsize, backbone=backbone, mode="inference")
+    eng.cfg = icfg
+    for _ in range(2):
+        eng.infer(x1, win)
+    torch.cuda.synchronize()
+    t1 = time.time()
+    for _ in range(args.detect_iters):
+        eng.infer(x1, win)
+    torch.cuda.synchronize()
+    res["detect_eager_ms"] = (time.time() - t1) / args.detect_iters * 1e3
+    for _ in range(2):
+        eng.infer_graphed(x1, win)                      # captures on first use
+    torch.cuda.synchronize()
+    t1 = time.time()
+    for _ in range(args.detect_iters):
+        eng.infer_graphed(x1, win)
+    torch.cuda.synchronize()
+    res["detect_ms"] = (time.time() - t1) / args.detect_iters * 1e3
+    eng.cfg = cfg
+    if not full:
+        return res
+
+    # ---- roofline of the dominant kernel: the mask-head 3x3 convolution (fwd instance) --------------
+    M_rois = nimg * cfg.TRAIN_ROIS_PER_IMAGE
+    xm = torch.randn((M_rois, 14, 14, 256), device=dev)
+    wm = torch.randn((3, 3, 256, 256), device=dev) * 0.02
+    bm = torch.zeros(256, device=dev)
+    sc = torch.ones(256, device=dev)
+    om = torch.empty((M_rois, 14, 14, 256), device=dev)
+    for _ in range(3):
+        ops.conv2d(xm, wm, bm, sc, bm, act=1, out=om)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 20
+    e0.record()                                         # same (current) stream the launches go to
+    for _ in range(reps):
+        ops.conv2d(xm, wm, bm, sc, bm, act=1, out=om)
+    e1.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / reps
+    flops = 2.0 * (M_rois * 196) * 256 * 2304
+    achieved = flops / (k_ms * 1e-3) / 1e12
+    peak = 157.3
+    res["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                       "frac": round(achieved / peak, 4),
+                       # HBM-side bytes per launch from rocprofv3 PMC passes on this shape:
+                       # 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_conv_traffic.md (not re-measured per run)
+                       "traffic": TRAFFIC_PER_LAUNCH.get(M_rois),
+                       "kernel": "conv_fwd_glds_kernel, 128x128 tile (mask-head 3x3 conv, M=%d N=256 K=2304, "
+                                 "%.1f GFLOP/launch, %.3f ms/launch)" % (M_rois * 196, flops / 1e9, k_ms)}
+    del xm, om
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            cores = min(16, len(os.sched_getaffinity(0)))   # the GPU box grants 16 host cores per GPU
+            res["cpu_baseline"] = cpu_baseline(cfg, eng.get_weights(), batch, cores)
+        except Exception as e:          # the baseline is a report, never a reason to lose the GPU number
+            res["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port",
+                                   "sample": "failed: %r" % (e,)}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--backbone", default="resnet101", help="BASELINE.json metric: ResNet-101 256x256")
+    ap.add_argument("--imgsize", type=int, default=256)
+    ap.add_argument("--nimg", type=int, default=4, help="images per GPU (IMAGES_PER_GPU; configs[2]: 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] (ResNet-50, 2 img/GPU) leg")
+    ap.add_argument("--detect-iters", type=int, default=10)
+    ap.add_argument("--dense-only", action="store_true", help="skip the exact-zero-skip timing loop (profiling)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from caesar_mrcnn_amd.parallel import init_distributed
+
+    rank, local_rank, world = init_distributed()
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n" % (args.gpus, world))
+    torch.cuda.set_device(torch.device("cuda", local_rank))
+
+    r = measure(args, args.backbone, args.nimg, rank, local_rank, world, full=True)
+    second = None
+    if world == 1 and not args.no_secondary and (args.backbone, args.nimg) != ("resnet50", 2):
+        torch.cuda.empty_cache()
+        second = measure(args, "resnet50", 2, rank, local_rank, world, full=False)
 
     if rank == 0:
-        # ---- detect latency (inference graph, batch 1), same weights -------------------------------
-        x1 = dev_inputs[0][:1].contiguous()
-        win = torch.tensor([[0.0, 0.0, 1.0, 1.0]], device=dev)
-        icfg = run_py_config(num_classes=4, imgsize=args.imgsize, backbone=args.backbone, mode="inference")
-        eng.cfg = icfg
-        for _ in range(2):
-            eng.infer(x1, win)
-        torch.cuda.synchronize()
-        t1 = time.time()
-        for _ in range(args.detect_iters):
-            eng.infer(x1, win)
-        torch.cuda.synchronize()
-        detect_eager_ms = (time.time() - t1) / args.detect_iters * 1e3
-        for _ in range(2):
-            eng.infer_graphed(x1, win)                      # captures on first use
-        torch.cuda.synchronize()
-        t1 = time.time()
-        for _ in range(args.detect_iters):
-            eng.infer_graphed(x1, win)
-        torch.cuda.synchronize()
-        detect_ms = (time.time() - t1) / args.detect_iters * 1e3
-        eng.cfg = cfg
-
-        # ---- roofline of the dominant kernel: the mask-head 3x3 convolution (fwd instance) ----------
-        M_rois = args.nimg * cfg.TRAIN_ROIS_PER_IMAGE
-        xm = torch.randn((M_rois, 14, 14, 256), device=dev)
-        wm = torch.randn((3, 3, 256, 256), device=dev) * 0.02
-        bm = torch.zeros(256, device=dev)
-        sc = torch.ones(256, device=dev)
-        om = torch.empty((M_rois, 14, 14, 256), device=dev)
-        for _ in range(3):
-            ops.conv2d(xm, wm, bm, sc, bm, act=1, out=om)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 20
-        e0.record()
-        for _ in range(reps):
-            ops.conv2d(xm, wm, bm, sc, bm, act=1, out=om)
-        e1.record()
-        torch.cuda.synchronize()
-        k_ms = e0.elapsed_time(e1) / reps
-        flops = 2.0 * (M_rois * 196) * 256 * 2304
-        achieved = flops / (k_ms * 1e-3) / 1e12
-        peak = 157.3
-
         out = {
             "metric": "train images/sec (whole node) + detect ms/image, ResNet-101 256x256",
-            "value": round(images_per_s, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "value": round(r["images_per_s"], 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(r["ms_per_step"], 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s+FPN %dx%d 3-class (+bg), nimg_per_gpu=%d, train step (fwd+bwd+SGD%s), "
                                    "512 train ROIs, 2000 proposals" % (args.backbone, args.imgsize, args.imgsize, args.nimg,
                                                                        "+RCCL all-reduce" if world > 1 else ""),
                        "global_batch": args.nimg * world, "parallelism": "dp%d" % world,
                        "weights": "random init (Keras defaults)"},
-            "detect_ms_per_image": round(detect_ms, 3), "detect_ms_per_image_eager": round(detect_eager_ms, 3),
-            "value_exact_zero_skip": None if args.dense_only else round(args.nimg * world * args.steps / dt_sparse, 3),
+            "detect_ms_per_image": round(r["detect_ms"], 3), "detect_ms_per_image_eager": round(r["detect_eager_ms"], 3),
+            "value_exact_zero_skip": None if args.dense_only else round(r["images_per_s_sparse"], 3),
             "note_exact_zero_skip": "same step with the mask-head backward restricted to the <=168 positive ROI rows "
                                     "per image (all other rows have exactly-zero gradient; results identical, "
                                     "tests/test_engine_gpu.py::test_sparse_mask_backward_equals_dense); product default",
-            "losses_last_step": [round(v, 5) for v in final_losses],
-            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                         "frac": round(achieved / peak, 4),
-                         # HBM-side bytes per launch from rocprofv3 PMC passes on this shape (B = 2):
-                         # 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_conv_traffic.md (not re-measured per run)
-                         "traffic": 0.976e9 if M_rois == 1024 else None,
-                         "kernel": "conv_fwd_glds_kernel, 128x128 tile (mask-head 3x3 conv, M=%d N=256 K=2304, "
-                                   "%.1f GFLOP/launch, %.3f ms/launch)" % (M_rois * 196, flops / 1e9, k_ms)},
+            "losses_last_step": [round(v, 5) for v in r["losses"]],
+            "roofline": r["roofline"],
         }
-        if not args.no_cpu_baseline and world == 1:
-            try:
-                cores = min(16, len(os.sched_getaffinity(0)))   # the GPU box grants 16 host cores per GPU
-                wts = eng.get_weights()
-                out["cpu_baseline"] = cpu_baseline(cfg, wts, batch, cores)
-            except Exception as e:      # the baseline is a report, never a reason to lose the GPU number
-                out["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port",
-                                       "sample": "failed: %r" % (e,)}
+        if second is not None:
+            out["config1_resnet50_nimg2"] = {
+                "workload": "BASELINE.json configs[1]: resnet50+FPN %dx%d, nimg_per_gpu=2, 1 GPU train + detect" % (args.imgsize, args.imgsize),
+                "value": round(second["images_per_s"], 3), "unit": "images/s", "ms_per_step": round(second["ms_per_step"], 3),
+                "value_exact_zero_skip": None if args.dense_only else round(second["images_per_s_sparse"], 3),
+                "detect_ms_per_image": round(second["detect_ms"], 3)}
+        if "cpu_baseline" in r:
+            out["cpu_baseline"] = r["cpu_baseline"]
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
