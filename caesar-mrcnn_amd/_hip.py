@@ -38,6 +38,11 @@ class DetTargetDesc(C.Structure):
         ("negative_ratio_r", C.c_float), ("bbox_std_dev", C.c_float * 4), ("use_mini_mask", C.c_int32)]
 
 
+class RpnTargetDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("A", C.c_int32), ("G", C.c_int32), ("n_train", C.c_int32),
+                ("bbox_std_dev", C.c_double * 4)]
+
+
 class DetectionDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("R", C.c_int32), ("C", C.c_int32), ("max_instances", C.c_int32),
                 ("min_confidence", C.c_float), ("nms_threshold", C.c_float), ("bbox_std_dev", C.c_float * 4)]
@@ -78,6 +83,8 @@ _SIGNATURES = {
     "mrcnn_proposal_workspace": (C.c_size_t, [C.POINTER(ProposalDesc)]),
     "mrcnn_proposal_fwd": (C.c_int, [C.POINTER(ProposalDesc)] + [_P] * 8 + [C.c_size_t, _P]),
     "mrcnn_detection_targets": (C.c_int, [C.POINTER(DetTargetDesc)] + [_P] * 12),
+    "mrcnn_rpn_targets_workspace": (C.c_size_t, [C.POINTER(RpnTargetDesc)]),
+    "mrcnn_rpn_targets": (C.c_int, [C.POINTER(RpnTargetDesc)] + [_P] * 7 + [C.c_size_t, _P]),
     "mrcnn_detection_workspace": (C.c_size_t, [C.POINTER(DetectionDesc)]),
     "mrcnn_detection_fwd": (C.c_int, [C.POINTER(DetectionDesc)] + [_P] * 6 + [C.c_size_t, _P]),
     "mrcnn_losses_workspace": (C.c_size_t, [C.POINTER(LossDesc)]),

@@ -56,6 +56,9 @@ class Config(object):
     TRAIN_BN = False
     GRADIENT_CLIP_NORM = 5.0
     MASK_LOSS_FUNCTION = 'binary_crossentropy'  # or 'dice_coef_loss'
+    # extension (not in the reference): build rpn_match / rpn_bbox on the GPU (csrc/rpn_targets.hip) instead of in
+    # the NumPy generator; False restores the host path and its np.random.choice stream (model.py:1536-1644)
+    DEVICE_RPN_TARGETS = True
 
     def __init__(self):
         side = self.IMAGE_MIN_DIM if self.IMAGE_RESIZE_MODE == "crop" else self.IMAGE_MAX_DIM

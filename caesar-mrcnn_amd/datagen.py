@@ -95,7 +95,7 @@ def build_rpn_targets(image_shape, anchors, gt_class_ids, gt_boxes, config, rng=
 
 
 def data_generator(dataset, config, shuffle=True, augment=False, augmentation=None, batch_size=1,
-                   no_augmentation_sources=None, rank=0, world_size=1, seed=None):
+                   no_augmentation_sources=None, rank=0, world_size=1, seed=None, device_targets=False):
     """Yields ([images, image_meta, rpn_match, rpn_bbox, gt_class_ids, gt_boxes, gt_masks], []) forever
     (model.py:1721-1904).  With world_size > 1 each rank walks its own stride of the (identically
     shuffled) image list -- the data-parallel replacement of tf.split in parallel_model.py:60-62."""
@@ -125,11 +125,15 @@ def data_generator(dataset, config, shuffle=True, augment=False, augmentation=No
                     use_mini_mask=config.USE_MINI_MASK)
             if not np.any(gt_class_ids > 0):
                 continue
-            rpn_match, rpn_bbox = build_rpn_targets(image.shape, anchors, gt_class_ids, gt_boxes, config)
+            if not device_targets:
+                rpn_match, rpn_bbox = build_rpn_targets(image.shape, anchors, gt_class_ids, gt_boxes, config)
             if b == 0:
                 batch_image_meta = np.zeros((batch_size,) + image_meta.shape, dtype=image_meta.dtype)
-                batch_rpn_match = np.zeros([batch_size, anchors.shape[0], 1], dtype=rpn_match.dtype)
-                batch_rpn_bbox = np.zeros([batch_size, config.RPN_TRAIN_ANCHORS_PER_IMAGE, 4], dtype=rpn_bbox.dtype)
+                if not device_targets:
+                    batch_rpn_match = np.zeros([batch_size, anchors.shape[0], 1], dtype=rpn_match.dtype)
+                    batch_rpn_bbox = np.zeros([batch_size, config.RPN_TRAIN_ANCHORS_PER_IMAGE, 4], dtype=rpn_bbox.dtype)
+                else:
+                    batch_rpn_match = batch_rpn_bbox = None
                 batch_images = np.zeros((batch_size,) + image.shape, dtype=np.float32)
                 batch_gt_class_ids = np.zeros((batch_size, config.MAX_GT_INSTANCES), dtype=np.int32)
                 batch_gt_boxes = np.zeros((batch_size, config.MAX_GT_INSTANCES, 4), dtype=np.int32)
@@ -139,8 +143,9 @@ def data_generator(dataset, config, shuffle=True, augment=False, augmentation=No
                 ids = np.random.choice(np.arange(gt_boxes.shape[0]), config.MAX_GT_INSTANCES, replace=False)
                 gt_class_ids, gt_boxes, gt_masks = gt_class_ids[ids], gt_boxes[ids], gt_masks[:, :, ids]
             batch_image_meta[b] = image_meta
-            batch_rpn_match[b] = rpn_match[:, np.newaxis]
-            batch_rpn_bbox[b] = rpn_bbox
+            if not device_targets:
+                batch_rpn_match[b] = rpn_match[:, np.newaxis]
+                batch_rpn_bbox[b] = rpn_bbox
             batch_images[b] = utils.mold_image(image.astype(np.float32), config)
             batch_gt_class_ids[b, :gt_class_ids.shape[0]] = gt_class_ids
             batch_gt_boxes[b, :gt_boxes.shape[0]] = gt_boxes

@@ -165,20 +165,47 @@ class MaskRCNN(object):
         self.checkpoint_path = self.checkpoint_path.replace("*epoch*", "{epoch:04d}")
 
     # ---- one optimisation step (device) -------------------------------------------------------------
-    def _to_device(self, inputs, rand_keys=None):
+    def _to_device(self, inputs, rand_keys=None, rpn_keys=None):
+        """Generator batch -> device tensors of engine.forward_backward.  With rpn_match / rpn_bbox None the RPN
+        targets are built on the GPU from the GT boxes (``rpn_keys`` [B, A] uniform floats, drawn here when not
+        given).  Only the GT-mask planes of real instances cross PCIe; the MAX_GT_INSTANCES padding is written
+        on the device."""
         import torch
+        from . import ops
         dev = self.engine.dev
         images, image_meta, rpn_match, rpn_bbox, gt_class_ids, gt_boxes, gt_masks = inputs
-        H, W = images.shape[1], images.shape[2]
+        B, H, W = images.shape[0], images.shape[1], images.shape[2]
         t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev, non_blocking=True)
         # norm_boxes_graph (model.py:1971, 3003-3017), float32
         gtn = (gt_boxes.astype(np.float32) - np.array([0., 0., 1., 1.], np.float32)) / \
               (np.array([H, W, H, W], np.float32) - np.float32(1.0))
         active = np.asarray(image_meta)[0, 12:].astype(np.int32)
         if rand_keys is None:
-            rand_keys = np.random.uniform(0, 1, (images.shape[0], self.config.POST_NMS_ROIS_TRAINING))
-        return (t(images, np.float32), t(rpn_match, np.int32), t(rpn_bbox, np.float32), t(gt_class_ids, np.int32),
-                t(gtn, np.float32), t(gt_masks, np.uint8), t(active, np.int32), t(rand_keys, np.float32))
+            rand_keys = np.random.uniform(0, 1, (B, self.config.POST_NMS_ROIS_TRAINING))
+        cls_d = t(gt_class_ids, np.int32)
+        if rpn_match is None:
+            self.get_anchors((H, W, 3))                                    # sets self.anchors (pixels, float64)
+            if getattr(self, "_anchors_px_dev_key", None) != (H, W):
+                self._anchors_px_dev = t(self.anchors, np.float64)
+                self._anchors_px_dev_key = (H, W)
+            A = self._anchors_px_dev.shape[0]
+            keys_d = t(rpn_keys, np.float32) if rpn_keys is not None else torch.rand((B, A), device=dev)
+            rpn_match_d, rpn_bbox_d = ops.rpn_targets(self._anchors_px_dev, cls_d, t(gt_boxes, np.int32), keys_d,
+                                                      self.config.RPN_TRAIN_ANCHORS_PER_IMAGE,
+                                                      self.config.RPN_BBOX_STD_DEV)
+        else:
+            rpn_match_d, rpn_bbox_d = t(rpn_match, np.int32), t(rpn_bbox, np.float32)
+        G = gt_masks.shape[-1]
+        used = np.flatnonzero(np.any(np.asarray(gt_class_ids) != 0, axis=0))
+        n_used = int(used[-1]) + 1 if used.size else 0
+        if n_used < G and not gt_masks[..., n_used:].any():
+            masks_d = torch.zeros(gt_masks.shape, dtype=torch.uint8, device=dev)
+            if n_used:
+                masks_d[..., :n_used] = t(gt_masks[..., :n_used], np.uint8)
+        else:
+            masks_d = t(gt_masks, np.uint8)
+        return (t(images, np.float32), rpn_match_d, rpn_bbox_d, cls_d, t(gtn, np.float32), masks_d,
+                t(active, np.int32), t(rand_keys, np.float32))
 
     def train_on_batch(self, inputs, rand_keys=None, reducer=None, world_size=1, apply=True, keep_outputs=False):
         """Forward + backward + (all-reduce) + SGD step on one generator batch.  Returns the five
@@ -205,9 +232,11 @@ class MaskRCNN(object):
         cfg = self.config
         train_gen = data_generator(train_dataset, cfg, shuffle=True, augmentation=augmentation,
                                    batch_size=cfg.IMAGES_PER_GPU, no_augmentation_sources=no_augmentation_sources,
-                                   rank=rank, world_size=world, seed=1234)
+                                   rank=rank, world_size=world, seed=1234,
+                                   device_targets=bool(getattr(cfg, "DEVICE_RPN_TARGETS", False)))
         val_gen = data_generator(val_dataset, cfg, shuffle=True, batch_size=cfg.IMAGES_PER_GPU, rank=rank,
-                                 world_size=world, seed=4321)
+                                 world_size=world, seed=4321,
+                                 device_targets=bool(getattr(cfg, "DEVICE_RPN_TARGETS", False)))
         if rank == 0 and not os.path.exists(self.log_dir):
             os.makedirs(self.log_dir)
         log("\nStarting at epoch {}. LR={}\n".format(self.epoch, learning_rate))

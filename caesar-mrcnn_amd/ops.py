@@ -294,6 +294,30 @@ def detection_targets(proposals_, gt_class_ids, gt_boxes, gt_masks, rand_keys, t
     return rois, tcls, tbbox, tmask, assign, counts
 
 
+def rpn_targets(anchors_px, gt_class_ids, gt_boxes_px, rand_keys, n_train, bbox_std_dev):
+    """build_rpn_targets (mrcnn/model.py:1536-1644) for a batch: anchors_px [A,4] float64 pixels,
+    gt_class_ids [B,G] int32, gt_boxes_px [B,G,4] int32, rand_keys [B,A] float32 ->
+    rpn_match [B,A,1] int32, rpn_bbox [B,n_train,4] float32."""
+    _need_cuda(anchors_px, gt_class_ids, gt_boxes_px, rand_keys)
+    assert anchors_px.dtype == torch.float64 and gt_boxes_px.dtype == torch.int32 and gt_class_ids.dtype == torch.int32
+    assert rand_keys.dtype == torch.float32
+    B, G = gt_class_ids.shape
+    A = anchors_px.shape[0]
+    assert rand_keys.shape == (B, A) and gt_boxes_px.shape == (B, G, 4)
+    d = _hip.RpnTargetDesc()
+    d.B, d.A, d.G, d.n_train = B, A, G, int(n_train)
+    for i in range(4):
+        d.bbox_std_dev[i] = float(bbox_std_dev[i])
+    dev = anchors_px.device
+    match = torch.empty((B, A, 1), dtype=torch.int32, device=dev)
+    bbox = torch.empty((B, int(n_train), 4), dtype=torch.float32, device=dev)
+    nbytes = _hip.lib().mrcnn_rpn_targets_workspace(C.byref(d))
+    ws = workspace(nbytes, dev, "rpn_targets")
+    check(_hip.lib().mrcnn_rpn_targets(C.byref(d), ptr(anchors_px), ptr(gt_class_ids), ptr(gt_boxes_px), ptr(rand_keys),
+                                       ptr(match), ptr(bbox), ptr(ws), nbytes, current_stream()), "mrcnn_rpn_targets")
+    return match, bbox
+
+
 def detections(rois, probs, deltas, windows, max_instances, min_confidence, nms_threshold, bbox_std_dev):
     _need_cuda(rois, probs, deltas, windows)
     B, R, C_ = probs.shape

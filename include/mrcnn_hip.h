@@ -176,6 +176,23 @@ int mrcnn_detection_targets(const mrcnn_dettarget_desc* d, const float* proposal
                             int32_t* target_class_ids, float* target_bbox, float* target_mask,
                             int32_t* roi_gt_assignment, int32_t* counts, void* stream);
 
+/* build_rpn_targets (mrcnn/model.py:1536-1644), the per-image RPN target builder of the CPU input
+ * pipeline, for one batch on the device.  anchors [A,4] float64 pixels (utils.generate_pyramid_anchors);
+ * gt_class_ids [B,G] (>0 instance, <0 crowd, 0 padding); gt_boxes [B,G,4] int32 pixels; rand_keys [B,A]
+ * uniform floats replace the two np.random.choice draws: when more than n_train/2 positives (or more than
+ * n_train - positives negatives) exist, the surplus with the SMALLEST keys is reset to neutral (ties ->
+ * lower anchor index).  Outputs: rpn_match [B,A] in {-1,0,1}; rpn_bbox [B,n_train,4] = deltas of the
+ * positives in ascending anchor order / bbox_std_dev, zero padded.  IoUs are float64 in the reference's
+ * operation order, so rpn_match is bit-exact.  G <= 512.                                              */
+typedef struct mrcnn_rpntarget_desc {
+    int32_t B, A, G, n_train;    /* n_train = RPN_TRAIN_ANCHORS_PER_IMAGE */
+    double bbox_std_dev[4];      /* RPN_BBOX_STD_DEV (float64 in the reference) */
+} mrcnn_rpntarget_desc;
+size_t mrcnn_rpn_targets_workspace(const mrcnn_rpntarget_desc* d);
+int mrcnn_rpn_targets(const mrcnn_rpntarget_desc* d, const double* anchors, const int32_t* gt_class_ids,
+                      const int32_t* gt_boxes, const float* rand_keys, int32_t* rpn_match, float* rpn_bbox,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* DetectionLayer / refine_detections_graph (mrcnn/model.py:770-909): detections [B, max_inst, 6]. */
 typedef struct mrcnn_detection_desc {
     int32_t B, R, C, max_instances;

@@ -240,6 +240,22 @@ def build_rpn_targets(anchors, gt_class_ids, gt_boxes, rpn_train_anchors, rpn_bb
     return rpn_match, rpn_bbox
 
 
+class KeyedChoice(object):
+    """Stand-in for the ``rng`` of build_rpn_targets: ``choice(ids, n, replace=False)`` returns the n members
+    of ids with the smallest injected keys (ties -> lower id).  This is the rule of the device kernel
+    (csrc/rpn_targets.hip), which replaces the two np.random.choice draws of model.py:1588-1601 the same
+    way rand_keys replace tf.random_shuffle in the detection targets."""
+
+    def __init__(self, keys):
+        self.keys = np.asarray(keys, dtype=np.float32)
+
+    def choice(self, ids, n, replace=False):
+        assert not replace
+        ids = np.asarray(ids)
+        order = np.lexsort((ids, self.keys[ids]))
+        return ids[order[:n]]
+
+
 # =============================================================================================
 #  Restated TensorFlow / Keras op semantics ([3P], parity unpinned)
 # =============================================================================================

@@ -385,3 +385,40 @@ def test_fused_mask_output_backward_equals_unfused(dev):
         grads.append(model.engine.grads.cpu().numpy().copy())
     scale = np.abs(grads[1]).max()
     assert np.abs(grads[0] - grads[1]).max() <= 2e-5 * scale
+
+
+def test_device_rpn_targets_in_training_step(dev):
+    """A step fed with rpn_match / rpn_bbox = None (targets built on the GPU, only the used GT-mask planes
+    uploaded) equals the step fed with the oracle's host-built targets for the same draw keys."""
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _small_cfg("custom", 128)
+    w = _weights(cfg, 23)
+    inputs, keys = _train_inputs(cfg, 2, 25)
+    images, meta, _, _, gt_cls, gt_boxes, gt_masks = inputs
+    anchors_px = orc.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS,
+                                              orc.compute_backbone_shapes(cfg.BACKBONE_STRIDES, cfg.IMAGE_SHAPE),
+                                              cfg.BACKBONE_STRIDES, cfg.RPN_ANCHOR_STRIDE)
+    rpn_keys = np.random.default_rng(5).uniform(0, 1, (2, anchors_px.shape[0])).astype(np.float32)
+    rpn_match = np.zeros((2, anchors_px.shape[0], 1), np.int32)
+    rpn_bbox = np.zeros((2, cfg.RPN_TRAIN_ANCHORS_PER_IMAGE, 4), np.float32)
+    for b in range(2):
+        n = int((gt_cls[b] > 0).sum())
+        m, bb = orc.build_rpn_targets(anchors_px, gt_cls[b, :n], gt_boxes[b, :n], cfg.RPN_TRAIN_ANCHORS_PER_IMAGE,
+                                      cfg.RPN_BBOX_STD_DEV, orc.KeyedChoice(rpn_keys[b]))
+        rpn_match[b, :, 0], rpn_bbox[b] = m, bb
+    res = []
+    for device_side in (False, True):
+        model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+        batch = [images, meta, None if device_side else rpn_match, None if device_side else rpn_bbox,
+                 gt_cls, gt_boxes, gt_masks]
+        dev_inputs = model._to_device(batch, keys, rpn_keys=rpn_keys)
+        if device_side:
+            np.testing.assert_array_equal(dev_inputs[1].cpu().numpy(), rpn_match)
+            np.testing.assert_allclose(dev_inputs[2].cpu().numpy(), rpn_bbox, rtol=2e-6, atol=1e-6)
+            np.testing.assert_array_equal(dev_inputs[5].cpu().numpy(), gt_masks.astype(np.uint8))
+        losses = model.engine.forward_backward(*dev_inputs)
+        torch.cuda.synchronize()
+        res.append((losses.cpu().numpy(), model.engine.grads.cpu().numpy().copy()))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5)
+    assert np.abs(res[0][1] - res[1][1]).max() <= 1e-5 * np.abs(res[0][1]).max()
+    assert (rpn_match == 1).sum() > 0

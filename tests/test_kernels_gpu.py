@@ -366,6 +366,67 @@ def test_detection_targets(dev):
         assert r_m.sum() > 0
 
 
+@pytest.mark.parametrize("case", ["golden", "crowded", "big_image", "no_overlap_gt"])
+def test_rpn_targets_device(dev, case):
+    """mrcnn_rpn_targets vs the oracle's build_rpn_targets (model.py:1536-1644) with the keyed draw:
+    rpn_match bit-exact (float64 IoUs in the reference's operation order), box deltas to float32 rounding."""
+    import os
+    ops = _ops()
+    cfg = _cfg()
+    rng = np.random.default_rng({"golden": 3, "crowded": 5, "big_image": 8, "no_overlap_gt": 13}[case])
+    S = 1024 if case == "big_image" else 256
+    anchors = orc.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS,
+                                           orc.compute_backbone_shapes(cfg.BACKBONE_STRIDES, (S, S)),
+                                           cfg.BACKBONE_STRIDES, cfg.RPN_ANCHOR_STRIDE)
+    assert anchors.dtype == np.float64
+    A, G, NT = anchors.shape[0], cfg.MAX_GT_INSTANCES, cfg.RPN_TRAIN_ANCHORS_PER_IMAGE
+    B = 3
+    gt_cls = np.zeros((B, G), np.int32); gt_boxes = np.zeros((B, G, 4), np.int32)
+    if case == "golden":
+        gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_numpy_helpers.npz"))
+        n = gold["rpn_gt_ids"].shape[0]
+        gt_cls[0, :n], gt_boxes[0, :n] = gold["rpn_gt_ids"], gold["rpn_gt_boxes"]
+        gt_cls[1, :n], gt_boxes[1, :n] = gold["rpn_gt_ids_crowd"], gold["rpn_gt_boxes"]
+        gt_cls[2, 5:5 + n], gt_boxes[2, 5:5 + n] = gold["rpn_gt_ids"], gold["rpn_gt_boxes"]     # padding rows first
+    else:
+        for b in range(B):
+            n = {"crowded": (150, 300, 40), "big_image": (6, 1, 30), "no_overlap_gt": (4, 9, 2)}[case][b]
+            for g in range(n):
+                h, w = rng.integers(2, 90 if case != "crowded" else 40, 2)
+                y1, x1 = rng.integers(0, S - h), rng.integers(0, S - w)
+                gt_boxes[b, g] = (y1, x1, y1 + h, x1 + w)
+                gt_cls[b, g] = rng.integers(1, cfg.NUM_CLASSES)
+            if case == "crowded" and b == 0:
+                gt_cls[b, 3] = -2; gt_cls[b, 77] = -1
+            if case == "no_overlap_gt":
+                gt_boxes[b, 0] = (10, 10, 10, 30)        # zero-area GT: column of zero IoUs (reference quirk: every
+                                                         # zero-overlap anchor ties for "best" and turns positive)
+    keys = rng.uniform(0, 1, (B, A)).astype(np.float32)
+    keys[0, :200] = keys[0, 200]                         # exercise the tie rule
+    std = np.asarray(cfg.RPN_BBOX_STD_DEV, np.float64)
+    match, bbox = ops.rpn_targets(torch.tensor(anchors, device=dev), torch.tensor(gt_cls, device=dev),
+                                  torch.tensor(gt_boxes, device=dev), torch.tensor(keys, device=dev), NT, std)
+    torch.cuda.synchronize()
+    match, bbox = match.cpu().numpy(), bbox.cpu().numpy()
+    assert match.shape == (B, A, 1) and bbox.shape == (B, NT, 4)
+    seen_pos_cap = False
+    for b in range(B):
+        nz = gt_cls[b] != 0
+        rm, rb = orc.build_rpn_targets(anchors, gt_cls[b][nz], gt_boxes[b][nz], NT, std, rng=orc.KeyedChoice(keys[b]))
+        np.testing.assert_array_equal(match[b, :, 0], rm)
+        np.testing.assert_allclose(bbox[b], rb.astype(np.float32), rtol=2e-6, atol=1e-6)
+        assert (rm == 1).sum() > 0 and (rm == 1).sum() + (rm == -1).sum() <= NT
+        seen_pos_cap |= (rm == 1).sum() == NT // 2
+    if case in ("crowded", "no_overlap_gt"):
+        assert seen_pos_cap                               # the positive cap (and its keyed draw) was exercised
+    if case == "golden":                                  # no positive surplus there: positives / deltas == the reference's own
+        assert np.array_equal(match[0, :, 0] == 1, gold["rpn_match"] == 1)
+        assert (match[0, :, 0] == -1).sum() == (gold["rpn_match"] == -1).sum()
+        np.testing.assert_allclose(bbox[0], gold["rpn_bbox"].astype(np.float32), rtol=2e-6, atol=1e-6)
+        assert np.array_equal(match[1, :, 0] == 1, gold["rpn_match_crowd"] == 1)
+        np.testing.assert_array_equal(bbox[2], bbox[0])
+
+
 @pytest.mark.parametrize("dice", [False, True])
 def test_losses(dev, dice):
     ops = _ops()
