@@ -7,9 +7,10 @@
 
 Same flag names and defaults; the model behind them is caesar_mrcnn_amd.model.MaskRCNN (MI355X).
 Multi-GPU training: ``torchrun --nproc-per-node NGPU scripts/run.py train --ngpu NGPU ...``.
-`test` reports completeness / reliability per class from mask-IoU matching and `detect` writes the
-detected objects to JSON; the reference's richer Analyzer post-processing (connected-mask merging,
-DS9 regions, plots; mrcnn/analyze.py) is outside the hot path.
+`test` reports completeness / reliability per class from mask-IoU matching; `detect` runs the Analyzer
+post-processing (caesar_mrcnn_amd/analyze.py: score filter, connected-mask merging, best-of-overlapping
+selection) on every tile and writes the objects as JSON (`out_<image>.json`: image_id, objs[name, x1, x2,
+y1, y2, class_id, class_name, score, pixels, vertexes, edge]) and DS9 regions.  Plots are not produced.
 """
 import argparse
 import json
@@ -233,7 +234,12 @@ def detect(args, model, cfg):
         y0, y1 = (args.ymin, args.ymax) if args.ymin >= 0 and args.ymax >= 0 else (0, ny - 1)
         tiles = fits.generate_tiles(x0, x1, y0, y1, cfg.TILE_XSIZE, cfg.TILE_YSIZE, cfg.TILE_XSTEP, cfg.TILE_YSTEP) or tiles
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    sources = []
+    from caesar_mrcnn_amd.analyze import Analyzer
+    base = os.path.splitext(os.path.basename(args.image))[0]
+    analyzer = Analyzer(model, cfg)
+    analyzer.score_thr, analyzer.iou_thr = args.scoreThr, args.iouThr
+    analyzer.write_to_json = analyzer.write_to_ds9 = False          # one file for all tiles, written below
+    objs, regions = [], []
     for t, (xmin, xmax, ymin, ymax) in enumerate(tiles):
         if t % world != rank:            # tiles are independent: replicas only (sfinder.py:1235-1251 round-robin)
             continue
@@ -243,21 +249,21 @@ def detect(args, model, cfg):
                              contrast=cfg.IMG_CONTRAST)
         if res is None:
             return -1
-        image, _ = res
-        r = model.detect([image], verbose=0)[0]
-        ox, oy = max(xmin, 0), max(ymin, 0)
-        for i in range(r["rois"].shape[0]):
-            if r["scores"][i] < cfg.SCORE_THR:
-                continue
-            y1, x1, y2, x2 = [int(v) for v in r["rois"][i]]
-            ys, xs = np.nonzero(r["masks"][:, :, i])
-            sources.append({"name": "S%d" % (len(sources) + 1), "x1": x1 + ox, "x2": x2 + ox, "y1": y1 + oy, "y2": y2 + oy,
-                            "class_id": int(r["class_ids"][i]), "class_name": cfg.CLASS_NAMES[int(r["class_ids"][i])],
-                            "score": float(r["scores"][i]), "pixels": [[int(x + ox), int(y + oy)] for x, y in zip(xs, ys)]})
-    out = args.detect_outfile_json or ("out_%s_rank%d.json" % (os.path.splitext(os.path.basename(args.image))[0], rank))
-    with open(out, "w") as f:
-        json.dump({"image": args.image, "sources": sources}, f)
-    print("%d sources written to %s" % (len(sources), out))
+        image, header = res
+        analyzer.obj_name_tag = "t%d" % t if len(tiles) > 1 else ""
+        if analyzer.predict(image, image_id=base, header=header, xmin=max(xmin, 0), ymin=max(ymin, 0)) < 0:
+            logger.error("Failed to run model prediction on image %s!" % args.image)
+            return -1
+        if analyzer.results:
+            objs.extend(analyzer.results["objs"])
+            regions.extend(analyzer.obj_regions)
+    suffix = "" if world == 1 else "_rank%d" % rank
+    out = args.detect_outfile_json or ("out_%s%s.json" % (base, suffix))
+    analyzer.results = {"image_id": base, "objs": objs}
+    analyzer.write_json_results(out)
+    analyzer.obj_regions = regions
+    analyzer.write_ds9_regions(os.path.splitext(out)[0] + ".reg")
+    print("%d sources written to %s" % (len(objs), out))
     return 0
 
 

@@ -59,8 +59,10 @@ def test_train_test_detect_cli(dev, tmp_path):
     out = _run(["detect"] + common + ["--weights", ckpts[0], "--image", os.path.join(d, "img0.fits"), "--scoreThr", "0.0",
                                       "--detect_outfile_json", outjson], d)
     res = json.load(open(outjson))
-    assert res["image"].endswith("img0.fits") and isinstance(res["sources"], list)
-    for s in res["sources"][:3]:
-        assert {"name", "x1", "x2", "y1", "y2", "class_id", "class_name", "score", "pixels"} <= set(s)
+    assert res["image_id"] == "img0" and isinstance(res["objs"], list)        # the reference's out_<id>.json layout
+    for s in res["objs"][:3]:
+        assert {"name", "x1", "x2", "y1", "y2", "class_id", "class_name", "score", "pixels", "vertexes", "edge"} == set(s)
+    if res["objs"]:
+        assert open(os.path.join(d, "det.reg")).read().splitlines()[2] == "image"
     # resume naming: the checkpoint path carries the epoch the reference parses back (model.py:2375-2383)
     assert "Re-starting from epoch 1" in out
