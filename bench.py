@@ -204,7 +204,7 @@ def measure(args, backbone, nimg, rank, local_rank, world, full):
                        # HBM-side bytes per launch from rocprofv3 PMC passes on this shape:
                        # 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_conv_traffic.md (not re-measured per run)
                        "traffic": TRAFFIC_PER_LAUNCH.get(M_rois),
-                       "kernel": "conv_fwd_glds_kernel, 128x128 tile (mask-head 3x3 conv, M=%d N=256 K=2304, "
+                       "kernel": "conv_fwd_blds_kernel, 128x128 tile (mask-head 3x3 conv, M=%d N=256 K=2304, "
                                  "%.1f GFLOP/launch, %.3f ms/launch)" % (M_rois * 196, flops / 1e9, k_ms)}
     del xm, om
     if not args.no_cpu_baseline and world == 1:

@@ -394,6 +394,137 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvArgs p)
     conv_epilogue_tile(p, acc[1][1], mw0 + 32, nw0 + 32);
 }
 
+// Same tile, buffer addressing (the default; the kernel above stays for inputs >= 2 GiB): the per-step
+// address arithmetic of the flat variant (64-bit pointer adds, zero-page selects, M0 through a VGPR) costs
+// ~1.5 vector instructions per MFMA, and those do not overlap the matrix pipe of the same SIMD (PMC:
+// SQ_VALU_MFMA_COEXEC_CYCLES = 0).  Here every lane keeps ONE 32-bit byte offset per piece for the whole
+// loop; the filter-tap / channel-chunk displacement is the instruction's scalar offset; a padded tap sets
+// the lane's offset out of range and the hardware range check of the buffer descriptor writes zeros into
+// LDS (no zero page); the base pointer is moved back by the largest negative tap displacement so that lane
+// offsets are never negative; the loop is unrolled over the two LDS buffers so that every LDS address is
+// base register + immediate.  Left per step: 3-4 vector instructions per A piece (tap-mask test), none for B.
+typedef __attribute__((address_space(3))) void* conv_lds_ptr;
+#define CONV_OOB_OFFSET 0xFFFFFFF0u
+
+__global__ __launch_bounds__(256, 2) void conv_fwd_blds_kernel(const ConvArgs p, const unsigned x_shift, const unsigned x_records) {
+    constexpr int BM = 128, BN = 128, BK = 16, TM = 2, TN = 2;
+    constexpr int AF = BM * BK, BF = BK * BN;                  // floats per tile (8 KiB each)
+    __shared__ __attribute__((aligned(16))) float lds[2 * (AF + BF)];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.Cout / BN;
+    const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x % ntiles;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int ohw = p.OH * p.OW;
+
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - x_shift), 0, x_records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + n0), 0, (unsigned)(((long long)p.Ktot * p.Cout - n0) * 4), 0x00020000);
+
+    unsigned a_voff[2];
+    unsigned long long a_mask[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int r = (wave + jj * 4) * 16 + (lane >> 2);
+        const int cl = (lane & 3) ^ ((r >> 2) & 3);
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / ohw, rem = mm - n * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
+        const long long off = ((long long)n * p.H * p.W * p.Cin + ((long long)ih0 * p.W + iw0) * p.Cin + cl * 4) * 4 + x_shift;
+        a_voff[jj] = (unsigned)off;
+        unsigned long long mk = 0ull;
+        if (ok)
+            for (int t = 0; t < p.KH * p.KW; ++t) {
+                const int th = t / p.KW, tw = t - th * p.KW;
+                if ((unsigned)(ih0 + th) < (unsigned)p.H && (unsigned)(iw0 + tw) < (unsigned)p.W) mk |= 1ull << t;
+            }
+        a_mask[jj] = mk;
+    }
+    unsigned b_voff[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) b_voff[jj] = (unsigned)((((wave + jj * 4) * 2 + (lane >> 5)) * p.Cout + (lane & 31) * 4) * 4);
+
+    int kh = 0, kw = 0, ci0 = 0, tap = 0;
+    auto stage = [&](float* ab) {                               // ab: LDS buffer (A tile, then B tile)
+        float* bb = ab + AF;
+        const unsigned soff_a = (unsigned)(((kh * p.W + kw) * p.Cin + ci0) * 4);
+        const unsigned soff_b = (unsigned)((tap * p.Cin + ci0) * p.Cout * 4);
+        const unsigned long long bit = 1ull << tap;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const unsigned vo = (a_mask[jj] & bit) ? a_voff[jj] : CONV_OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (conv_lds_ptr)(ab + (wave + jj * 4) * 256), 16, vo, soff_a, 0, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (conv_lds_ptr)(bb + (wave + jj * 4) * 256), 16, b_voff[jj], soff_b, 0, 0);
+        // K is walked channel-chunk outer / filter-tap inner (see the flat variant)
+        ++tap;
+        if (++kw == p.KW) { kw = 0; if (++kh == p.KH) { kh = 0; tap = 0; ci0 += BK; } }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    // per-lane LDS read bases (floats): A chunk q of row (wm*64 + li) [+32 rows = +512 floats], B column
+    const int row0 = wm * 64 + li;
+    const float* a_rd0 = lds + row0 * BK + (((2 * lh + 0) ^ ((row0 >> 2) & 3)) << 2);
+    const float* a_rd1 = lds + row0 * BK + (((2 * lh + 1) ^ ((row0 >> 2) & 3)) << 2);
+    const float* b_rd = lds + AF + lh * 8 * BN + wn * 64 + li;
+
+    auto compute = [&](auto curc) {
+        constexpr int CUR = decltype(curc)::value;
+        constexpr int BO = CUR * (AF + BF);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 av[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) av[a] = *(const f32x4*)((q ? a_rd1 : a_rd0) + BO + a * 32 * BK);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float bv[TN];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bv[b] = b_rd[BO + (q * 4 + e) * BN + b * 32];
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    };
+
+    const int nk = p.Ktot / BK;
+    stage(lds);
+    __syncthreads();
+    for (int ks = 0; ks < nk; ks += 2) {
+        if (ks + 1 < nk) stage(lds + (AF + BF));
+        compute(std::integral_constant<int, 0>{});
+        __syncthreads();
+        if (ks + 1 < nk) {
+            if (ks + 2 < nk) stage(lds);
+            compute(std::integral_constant<int, 1>{});
+            __syncthreads();
+        }
+    }
+    const int mw0 = m0 + wm * 64 + 4 * lh, nw0 = n0 + wn * 64 + li;
+    conv_epilogue_tile(p, acc[0][0], mw0, nw0);
+    conv_epilogue_tile(p, acc[0][1], mw0, nw0 + 32);
+    conv_epilogue_tile(p, acc[1][0], mw0 + 32, nw0);
+    conv_epilogue_tile(p, acc[1][1], mw0 + 32, nw0 + 32);
+}
+
 // Second pass of split-K: sum the slabs in a fixed order, then the ordinary epilogue.
 __global__ void conv_splitk_epilogue_kernel(const ConvArgs p) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -530,7 +661,15 @@ extern "C" int mrcnn_conv2d_fwd_ws(const mrcnn_conv_desc* d, const float* x, con
     a.ksplit = pl.ksplit; a.ksteps = pl.ksteps; a.slab = (float*)workspace;
     if (pl.bm == 128 && pl.bn == 128 && pl.ksplit == 1 && a.fastA && a.vecB && d->Cout % 128 == 0) {
         const int mt = (a.M + 127) / 128, nt = a.Cout / 128;
-        hipLaunchKernelGGL(conv_fwd_glds_kernel, dim3((unsigned)(mt * nt)), dim3(256), 0, s, a);
+        // buffer-addressed variant when the input (plus the padding shift) fits a 32-bit descriptor range
+        const long long xbytes = (long long)d->N * d->H * d->W * d->Cin * 4;
+        const long long shift = ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
+        const long long wbytes = (long long)a.Ktot * d->Cout * 4;
+        if (xbytes + shift < 0x7FFFFFF0LL && wbytes < 0x7FFFFFF0LL && !getenv("MRCNN_CONV_FLAT_GLDS"))
+            hipLaunchKernelGGL(conv_fwd_blds_kernel, dim3((unsigned)(mt * nt)), dim3(256), 0, s, a, (unsigned)shift,
+                               (unsigned)(xbytes + shift));
+        else
+            hipLaunchKernelGGL(conv_fwd_glds_kernel, dim3((unsigned)(mt * nt)), dim3(256), 0, s, a);
         return mrcnn_launch_status();
     }
     if (pl.bn == 32) return pl.bm == 128 ? launch_conv<128, 32, 4, 1>(a, s) : launch_conv<64, 32, 2, 1>(a, s);

@@ -8,6 +8,8 @@
 // (lane = channel, k = pixel): every LDS read is a conflict-free ds_read_b32.  Splits write partial
 // slabs that a second kernel sums in a fixed order, so dW is bitwise reproducible.
 #include "common.h"
+#include <type_traits>
+#include <cstdlib>
 
 struct WgradArgs {
     const float* x; const float* dy; float* out;   // out: dw (splits==1) or slabs
@@ -286,6 +288,136 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_glds_kernel(const WgradArgs
     if constexpr (TM >= 2 && TN >= 2) store_tile(acc[1][1], ib + 32, nb + 32);
 }
 
+// Same tile with buffer addressing (default; the flat variant above stays for tensors >= 2 GiB).  The flat
+// variant spends ~3 vector instructions per MFMA on per-lane pixel decomposition (two divisions), bounds
+// tests and 64-bit pointers, and vector instructions do not overlap the matrix pipe of their SIMD.  Here a
+// 1 KiB piece = two pixel rows, so the pixel -> (n, oh, ow) decomposition is wave-uniform and runs on the
+// SCALAR unit; a lane only selects one of the two row offsets and adds its channel offset (3 vector
+// instructions per X piece, none per dY piece); padded taps and rows past the tensor take an out-of-range
+// offset and the buffer range check writes zeros; the dY descriptor is rebuilt per piece (scalar) with the
+// rows left in this split as its size, so the pixel tail needs no per-lane test either.  The loop is
+// unrolled over the two LDS buffers: every LDS read is base register + immediate.
+typedef __attribute__((address_space(3))) void* wgrad_lds_ptr;
+#define WGRAD_OOB_OFFSET 0x80000000u
+
+template <int BP>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_blds_kernel(const WgradArgs p, const unsigned x_shift, const unsigned x_records) {
+    constexpr int BI = 128, BN = 128, TM = 2, TN = 2;
+    constexpr int XF = BP * BI, YF = BP * BN;
+    constexpr int NP = XF / 256;                              // 1 KiB pieces per tile (two pixel rows each)
+    __shared__ __attribute__((aligned(16))) float lds[2 * (XF + YF)];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.Cout / BN, itiles = p.Ktot / BI;
+    int bid = blockIdx.x;
+    const int ntile = bid % ntiles; bid /= ntiles;
+    const int itile = bid % itiles;
+    const int split = bid / itiles;
+    const int i0 = itile * BI, n0 = ntile * BN;
+    const int m_begin = split * p.chunk;
+    const int m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
+    const int tap = i0 / p.Cin, ci0 = i0 - tap * p.Cin;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int ohw = p.OH * p.OW;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - x_shift), 0, x_records, 0x00020000);
+    const unsigned lane_chan = (unsigned)(lane & 31) * 16u;
+    const bool upper = lane >= 32;
+    const unsigned y_voff = (unsigned)(((lane >> 5) * p.Cout + (lane & 31) * 4) * 4);
+
+    auto stage = [&](float* xb, int mb) {
+        float* yb = xb + XF;
+#pragma unroll
+        for (int jj = 0; jj < NP / 4; ++jj) {
+            const int j = wave + jj * 4;
+            unsigned off[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {                       // wave-uniform: scalar unit
+                const int m = mb + j * 2 + h;
+                const int n = (int)fast_div((unsigned)m, p.d_ohw), rem = m - n * ohw;
+                const int oh = (int)fast_div((unsigned)rem, p.d_ow), ow = rem - oh * p.OW;
+                const int ih = oh * p.stride - p.pad_t + kh, iw = ow * p.stride - p.pad_l + kw;
+                const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                off[h] = ok ? (unsigned)((((n * p.H + ih) * p.W + iw) * p.Cin + ci0) * 4) + x_shift : WGRAD_OOB_OFFSET;
+            }
+            const unsigned vo = (upper ? off[1] : off[0]) + lane_chan;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (wgrad_lds_ptr)(xb + j * 256), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < NP / 4; ++jj) {
+            const int j = wave + jj * 4;
+            const int row0 = mb + j * 2;
+            const int left = m_end - row0;                      // rows of this split from row0 on
+            const unsigned rec = left > 0 ? (unsigned)(((left - 1) * p.Cout + BN) * 4) : 0u;
+            const __amdgpu_buffer_rsrc_t rsrc_y =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(p.dy + (long long)row0 * p.Cout + n0), 0, rec, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (wgrad_lds_ptr)(yb + j * 256), 16, y_voff, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    const float* x_rd = lds + lh * (BP / 2) * BI + wm * TM * 32 + li;
+    const float* y_rd = lds + XF + lh * (BP / 2) * BN + wn * TN * 32 + li;
+    auto compute = [&](auto curc) {
+        constexpr int BO = decltype(curc)::value * (XF + YF);
+#pragma unroll
+        for (int t = 0; t < BP / 2; ++t) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) av[a] = x_rd[BO + t * BI + a * 32];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bv[b] = y_rd[BO + t * BN + b * 32];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+    };
+
+    if (m_begin < m_end) {
+        stage(lds, m_begin);
+        __syncthreads();
+        for (int mb = m_begin; mb < m_end; mb += 2 * BP) {
+            if (mb + BP < m_end) stage(lds + (XF + YF), mb + BP);
+            compute(std::integral_constant<int, 0>{});
+            __syncthreads();
+            if (mb + BP < m_end) {
+                if (mb + 2 * BP < m_end) stage(lds, mb + 2 * BP);
+                compute(std::integral_constant<int, 1>{});
+                __syncthreads();
+            }
+        }
+    }
+
+    float* dst = p.out + (p.splits > 1 ? (long long)split * p.Ktot * p.Cout : 0LL);
+    const bool accumulate = p.splits == 1 && p.acc;
+    auto store_tile = [&](const f32x16& c, int ibase, int n) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = ibase + (r & 3) + 8 * (r >> 2);
+            float* q = dst + (long long)i * p.Cout + n;
+            *q = accumulate ? *q + c[r] : c[r];
+        }
+    };
+    const int ib = i0 + wm * TM * 32 + 4 * lh, nb = n0 + wn * TN * 32 + li;
+    store_tile(acc[0][0], ib, nb);
+    store_tile(acc[0][1], ib, nb + 32);
+    store_tile(acc[1][0], ib + 32, nb);
+    store_tile(acc[1][1], ib + 32, nb + 32);
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* dw, long long n, int splits, int acc) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -352,7 +484,15 @@ extern "C" int mrcnn_conv2d_wgrad(const mrcnn_conv_desc* d, const float* x, cons
     hipStream_t s = (hipStream_t)stream;
     if (pl.fast && pl.bi == 128 && pl.bn == 128 && d->Cout % 128 == 0 && a.Ktot % 128 == 0) {
         const int blocks = (a.Ktot / 128) * (a.Cout / 128) * a.splits;
-        hipLaunchKernelGGL((conv_wgrad_glds_kernel<128, 128, WGRAD_BP>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+        const long long xbytes = (long long)d->N * d->H * d->W * d->Cin * 4;
+        const long long shift = ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
+        const long long ybytes = M * d->Cout * 4;
+        // + 16 pixel rows: offsets of rows past the tensor must not wrap before the range check sees them
+        if (xbytes + shift + 16LL * d->H * d->W * d->Cin * 4 < 0x7FFFFFF0LL && ybytes < 0x7FFFFFF0LL && !getenv("MRCNN_CONV_FLAT_GLDS"))
+            hipLaunchKernelGGL((conv_wgrad_blds_kernel<WGRAD_BP>), dim3((unsigned)blocks), dim3(256), 0, s, a, (unsigned)shift,
+                               (unsigned)(xbytes + shift));
+        else
+            hipLaunchKernelGGL((conv_wgrad_glds_kernel<128, 128, WGRAD_BP>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     } else if (pl.bi == 128) {
         if (pl.bn == 128) launch_wgrad<128, 128, 2, 2>(a, s);
         else if (pl.bn == 64) launch_wgrad<128, 64, 2, 2>(a, s);
