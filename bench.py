@@ -88,7 +88,7 @@ def cpu_baseline(cfg, weights, batch, cores):
                       "restatement of the reference graph, not TF1), %.1f s" % (n, dt)}
 
 
-TRAFFIC_PER_LAUNCH = {1024: 0.976e9, 2048: 2.162e9}   # mask-head conv, PMC passes: profiles/r01_pmc_conv_traffic.md
+TRAFFIC_PER_LAUNCH = {1024: None, 2048: 1.810e9}   # mask-head conv, PMC passes: profiles/r01_pmc_conv_traffic.md
 
 
 def measure(args, backbone, nimg, rank, local_rank, world, full):

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "mrcnn_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, C.c_size_t, C.c_int, _P]),
     "mrcnn_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "mrcnn_weight_flip_transpose": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mrcnn_weight_flip_transpose_batched": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "mrcnn_bn_fold": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, _P, _P, C.c_int64, _P]),
     "mrcnn_epilogue_bwd": (C.c_int, [_P] * 11 + [C.c_int64, C.c_int, C.c_int, _P]),
     "mrcnn_maxpool3x3s2_fwd": (C.c_int, [_P, _P, _P] + [C.c_int] * 8 + [_P]),

@@ -535,3 +535,45 @@ extern "C" int mrcnn_weight_flip_transpose(const float* w, float* w_t, int KH, i
     hipLaunchKernelGGL(flip_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, w_t, KH, KW, Cin, Cout);
     return mrcnn_launch_status();
 }
+
+// All layers of a flat parameter buffer in one launch: table[l] = {offset (floats, same in w and w_t), KH, KW,
+// Cin, Cout, first_tile}; a tile is 32 ci x 32 co of one tap.  The weights change once per optimiser step, so
+// the data-gradient operands of every layer are refreshed by one HBM-bound pass instead of one launch per layer.
+struct FlipEntry { long long off; int KH, KW, Cin, Cout, first_tile, pad; };
+
+__global__ void flip_transpose_batched_kernel(const float* __restrict__ w, float* wt, const FlipEntry* __restrict__ table, int n) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n - 1;                         // last entry with first_tile <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first_tile <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const FlipEntry e = table[lo];
+    int t = blockIdx.x - e.first_tile;
+    const int cot = (e.Cout + 31) / 32, cit = (e.Cin + 31) / 32;
+    const int co0 = (t % cot) * 32; t /= cot;
+    const int ci0 = (t % cit) * 32;
+    const int tap = t / cit;
+    const int kh = tap / e.KW, kw = tap % e.KW;
+    const int tap_t = (e.KH - 1 - kh) * e.KW + (e.KW - 1 - kw);
+    const float* src = w + e.off;
+    float* dst = wt + e.off;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        tile[r][tx] = (ci < e.Cin && co < e.Cout) ? src[((long long)tap * e.Cin + ci) * e.Cout + co] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int co = co0 + r, ci = ci0 + tx;
+        if (co < e.Cout && ci < e.Cin) dst[((long long)tap_t * e.Cout + co) * e.Cin + ci] = tile[tx][r];
+    }
+}
+
+extern "C" int mrcnn_weight_flip_transpose_batched(const float* params, float* params_t, const void* table, int n_layers,
+                                                   int total_tiles, void* stream) {
+    if (!params || !params_t || !table || n_layers <= 0 || total_tiles <= 0) return MRCNN_ERR_ARG;
+    hipLaunchKernelGGL(flip_transpose_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, params,
+                       params_t, (const FlipEntry*)table, n_layers);
+    return mrcnn_launch_status();
+}

@@ -84,7 +84,8 @@ class ConvOp(object):
         x = ctx[0]
         kh, kw, cin, cout = self.wshape
         N, H, W, _ = x.shape
-        if not (self.padding == "valid" and kh > 1):
+        fresh = self.model.wt_valid                     # refreshed for all layers at once (refresh_wt)
+        if not fresh and not (self.padding == "valid" and kh > 1):
             ops.weight_flip_transpose(self.w, self.wt)
         res = out if accumulate else None
         rm = RES_SAME if accumulate else RES_NONE
@@ -108,7 +109,8 @@ class ConvOp(object):
             if out is None:
                 out = torch.empty_like(x)
             wt2 = self.wt.view(1, 1, cout, kh * kw * cin)
-            ops.weight_flip_transpose(self.w.view(1, 1, kh * kw * cin, cout), wt2)
+            if not fresh:
+                ops.weight_flip_transpose(self.w.view(1, 1, kh * kw * cin, cout), wt2)
             ops.conv2d(dz.view(N, 1, 1, cout), wt2, res=None if res is None else res.view(N, 1, 1, -1), stride=1,
                        padding="valid", res_mode=rm, out=out.view(N, 1, 1, kh * kw * cin))
         else:
@@ -147,6 +149,18 @@ class MaskRCNNEngine(object):
         letters = {2: "abc", 3: "abcd", 4: "a" + "".join(chr(98 + i) for i in range(n4)), 5: "abc"}
         self.stages = [[Block(self, s, b, i == 0, 2 if (i == 0 and s > 2) else 1) for i, b in enumerate(letters[s])]
                        for s in (2, 3, 4, 5)]
+        # data-gradient operands (flipped / transposed kernels) of all layers: one table-driven launch per step
+        entries = []
+        for l in L.layers:
+            o = self._ops[l.name]
+            kh, kw, cin, cout = o.wshape
+            off = L.offsets[l.name + "/kernel"][0]
+            if o.padding == "valid" and kh > 1:                    # FC as VALID conv: plain [K, Cout] transpose
+                entries.append((off, 1, 1, kh * kw * cin, cout))
+            else:
+                entries.append((off, kh, kw, cin, cout))
+        self._flip_table = ops.flip_table(entries, device) if torch.device(device).type == "cuda" else None
+        self.wt_valid = False
         self.set_trainable("all")
         self.set_weights(weights if weights is not None else init_weights(L, seed))
         self._anchor_cache = {}
@@ -190,8 +204,14 @@ class MaskRCNNEngine(object):
             torch.cuda.current_stream(self.dev).wait_stream(self.wgrad_stream)
 
     # ---- weights in / out (Keras layouts at this boundary) --------------------------------------
+    def refresh_wt(self):
+        """Flipped / transposed kernels of every layer from the current parameters (one launch)."""
+        ops.weight_flip_transpose_batched(self.params, self.wt, self._flip_table)
+        self.wt_valid = True
+
     def set_weights(self, weights, strict=True):
         L = self.layout
+        self.wt_valid = False
         for name, (off, n, shape) in L.offsets.items():
             if name not in weights:
                 if strict:
@@ -408,6 +428,8 @@ class MaskRCNNEngine(object):
         B, H, W = images.shape[0], images.shape[1], images.shape[2]
         area = float(H * W)
         ops.fill_zero(self.grads)
+        if not self.wt_valid:
+            self.refresh_wt()
         pyr, tape = self._trunk_fwd(images, True)
         rpn_logits, rpn_probs, rpn_bbox, rpn_tape = self._rpn_fwd(pyr, True)
         anchors = self.anchors((H, W, images.shape[3]))
@@ -507,7 +529,8 @@ class MaskRCNNEngine(object):
             ops.epilogue_bwd(d_up, up, None, None, None, None, None, dzu, None, None, dc.db, ACT_RELU)
             dzg = ops.pixel_unshuffle2(dzu)                             # [M,14,14,1024]
         self.wgrad_async(x_in, dzg, dc.wshape, 1, "valid", dc.dw, acc)
-        ops.weight_flip_transpose(dc.w, dc.wt)
+        if not self.wt_valid:
+            ops.weight_flip_transpose(dc.w, dc.wt)
         d = ops.conv2d(dzg, dc.wt, stride=1, padding="valid")
         for i, c in ((4, c4), (3, c3), (2, c2), (1, c1)):
             op = self.op("mrcnn_mask_conv%d" % i)
@@ -639,4 +662,5 @@ class MaskRCNNEngine(object):
         ops.grad_prepare(self.grads, self.params, 1.0 / world_size, self.gran_coef, self.sumsq)
         ops.sgd_momentum(self.params, self.momentum, self.grads, self.sumsq, cfg.GRADIENT_CLIP_NORM, learning_rate,
                          momentum, self.gran_coef)
+        self.wt_valid = False
         self.fold_bn()

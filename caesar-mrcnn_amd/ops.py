@@ -124,6 +124,26 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, padding="same", dw=None, accumulate=F
     return dw
 
 
+def flip_table(entries, device):
+    """entries: [(offset_floats, KH, KW, Cin, Cout)] -> (device table, n_layers, total_tiles) for
+    weight_flip_transpose_batched."""
+    import numpy as np
+    rec = np.zeros(len(entries), dtype=[("off", "<i8"), ("KH", "<i4"), ("KW", "<i4"), ("Cin", "<i4"), ("Cout", "<i4"),
+                                        ("first", "<i4"), ("pad", "<i4")])
+    tiles = 0
+    for i, (off, kh, kw, cin, cout) in enumerate(entries):
+        rec[i] = (off, kh, kw, cin, cout, tiles, 0)
+        tiles += kh * kw * ((cin + 31) // 32) * ((cout + 31) // 32)
+    t = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
+    return t, len(entries), tiles
+
+
+def weight_flip_transpose_batched(params, params_t, table):
+    _need_cuda(params, params_t, table[0])
+    check(_hip.lib().mrcnn_weight_flip_transpose_batched(ptr(params), ptr(params_t), ptr(table[0]), table[1], table[2],
+                                                         current_stream()), "mrcnn_weight_flip_transpose_batched")
+
+
 def weight_flip_transpose(w, out=None):
     _need_cuda(w, out)
     KH, KW, Cin, Cout = w.shape

@@ -76,6 +76,12 @@ size_t mrcnn_conv2d_wgrad_workspace(const mrcnn_conv_desc* d);
 /* w_t[(KH-1-kh, KW-1-kw, co), ci] = w[(kh,kw,ci), co]: the weights of the data-gradient convolution. */
 int mrcnn_weight_flip_transpose(const float* w, float* w_t, int KH, int KW, int Cin, int Cout,
                                 void* stream);
+/* The same for every layer of a flat parameter buffer in one launch.  table (device): n_layers records of
+ * { int64 offset (floats; same in params and params_t), int32 KH, KW, Cin, Cout, first_tile, pad } sorted by
+ * first_tile, a tile being 32 x 32 (ci, co) of one tap; total_tiles = sum over layers of
+ * KH*KW*ceil(Cin/32)*ceil(Cout/32).                                                                     */
+int mrcnn_weight_flip_transpose_batched(const float* params, float* params_t, const void* table, int n_layers,
+                                        int total_tiles, void* stream);
 
 /* Frozen BatchNorm (KL.BatchNormalization with training=False, mrcnn/model.py:57-72; eps = Keras
  * default 1e-3):  scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, for n channels.          */
