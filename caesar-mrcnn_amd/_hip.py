@@ -131,6 +131,21 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_dev_index = None
+
+
+def set_device_index(index):
+    """Device whose current stream the launches go to (set by the engine; default: torch's current device
+    at the first launch)."""
+    global _dev_index
+    _dev_index = int(index)
+
+
 def current_stream():
+    """Raw hipStream_t of torch's current stream on the engine's device (the C-level getter: the Python
+    `torch.cuda.current_stream()` object costs ~7 us per call, two per launch)."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    global _dev_index
+    if _dev_index is None:
+        _dev_index = torch.cuda.current_device()
+    return torch._C._cuda_getCurrentRawStream(_dev_index)

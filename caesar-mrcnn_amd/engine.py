@@ -54,9 +54,9 @@ class ConvOp(object):
     def forward(self, x, act=ACT_NONE, res=None, res_mode=RES_NONE, train=False):
         z = None
         d = ops.conv_desc(tuple(x.shape), self.wshape, self.stride, self.padding, act, res_mode)
-        out = torch.empty((d.N, d.OH, d.OW, d.Cout), dtype=torch.float32, device=x.device)
+        out = ops.empty((d.N, d.OH, d.OW, d.Cout), torch.float32, x.device)
         if train and self.bn:
-            z = torch.empty_like(out)
+            z = ops.empty_like(out)
         ops.conv2d(x, self.w, self.b, self.scale, self.shift, res, out=out, z_out=z, desc=d)
         ctx = (x, z, out, act) if train else None
         return out, ctx
@@ -69,8 +69,8 @@ class ConvOp(object):
         if self.bn is None and act == ACT_NONE:
             ops.epilogue_bwd(dout, dbias=self.db)
             return dout, dout
-        dz = torch.empty_like(dout)
-        dy = torch.empty_like(dout) if want_dy else None
+        dz = ops.empty_like(dout)
+        dy = ops.empty_like(dout) if want_dy else None
         ops.epilogue_bwd(dout, out if act != ACT_NONE else None, z, self.scale, self.mean, self.rstd, dy, dz,
                          self.dgamma, self.dbeta, self.db, act)
         return dz, dy
@@ -91,15 +91,15 @@ class ConvOp(object):
         rm = RES_SAME if accumulate else RES_NONE
         if self.stride == 1 and self.padding == "same":
             if out is None:
-                out = torch.empty_like(x)
+                out = ops.empty_like(x)
             ops.conv2d(dz, self.wt, res=res, stride=1, padding=((kh - 1) // 2, (kw - 1) // 2), res_mode=rm, out=out)
         elif kh == 1 and kw == 1 and self.stride == 1:
             if out is None:
-                out = torch.empty_like(x)
+                out = ops.empty_like(x)
             ops.conv2d(dz, self.wt, res=res, stride=1, padding="valid", res_mode=rm, out=out)
         elif kh == 1 and kw == 1 and self.stride == 2:
             if out is None:
-                out = torch.empty_like(x)
+                out = ops.empty_like(x)
                 ops.fill_zero(out)
             d = ops.conv_desc(tuple(dz.shape), (1, 1, cout, cin), 1, "valid", ACT_NONE, rm)
             d.out_w_stride, d.out_h_stride, d.out_n_stride = 2 * cin, 2 * W * cin, H * W * cin
@@ -107,7 +107,7 @@ class ConvOp(object):
         elif self.padding == "valid" and x.shape[1] == kh and x.shape[2] == kw:
             # "FC as VALID conv" (mrcnn_class_conv1): dx[M, (kh,kw,ci)] = dz[M, Cout] . W^T
             if out is None:
-                out = torch.empty_like(x)
+                out = ops.empty_like(x)
             wt2 = self.wt.view(1, 1, cout, kh * kw * cin)
             if not fresh:
                 ops.weight_flip_transpose(self.w.view(1, 1, kh * kw * cin, cout), wt2)
@@ -160,6 +160,11 @@ class MaskRCNNEngine(object):
             else:
                 entries.append((off, kh, kw, cin, cout))
         self._flip_table = ops.flip_table(entries, device) if torch.device(device).type == "cuda" else None
+        self.arena = ops.StepArena()               # tensors of a training step, reused step after step
+        if torch.device(device).type == "cuda":
+            from . import _hip
+            _hip.set_device_index(torch.device(device).index if torch.device(device).index is not None
+                                  else torch.cuda.current_device())
         self.wt_valid = False
         self.set_trainable("all")
         self.set_weights(weights if weights is not None else init_weights(L, seed))
@@ -316,8 +321,8 @@ class MaskRCNNEngine(object):
         B = pyramid[0].shape[0]
         na = len(self.cfg.RPN_ANCHOR_RATIOS)
         A = sum(p.shape[1] * p.shape[2] * na for p in pyramid)
-        logits = torch.empty((B, A, 2), dtype=torch.float32, device=self.dev)
-        bbox = torch.empty((B, A, 4), dtype=torch.float32, device=self.dev)
+        logits = ops.empty((B, A, 2), torch.float32, self.dev)
+        bbox = ops.empty((B, A, 4), torch.float32, self.dev)
         shared, cls, box = self.op("rpn_conv_shared"), self.op("rpn_class_raw"), self.op("rpn_bbox_pred")
         tape, off = [], 0
         for p in pyramid:
@@ -376,7 +381,7 @@ class MaskRCNNEngine(object):
         det = ops.detections(rois, probs, bbox, windows_norm, cfg.DETECTION_MAX_INSTANCES,
                              cfg.DETECTION_MIN_CONFIDENCE, cfg.DETECTION_NMS_THRESHOLD,
                              np.asarray(cfg.BBOX_STD_DEV, np.float32))
-        det_boxes = torch.empty((B, cfg.DETECTION_MAX_INSTANCES, 4), dtype=torch.float32, device=self.dev)
+        det_boxes = ops.empty((B, cfg.DETECTION_MAX_INSTANCES, 4), torch.float32, self.dev)
         ops.copy2d(det_boxes.data_ptr(), 16, det.data_ptr(), 24, 16, B * cfg.DETECTION_MAX_INSTANCES)
         masks, _ = self._mask_head_fwd(det_boxes, pyr[:4], area, False)
         return {"detections": det, "mrcnn_class": probs, "mrcnn_bbox": bbox, "mrcnn_mask": masks, "rpn_rois": rois,
@@ -389,8 +394,8 @@ class MaskRCNNEngine(object):
         key = (tuple(images.shape), tuple(windows_norm.shape), id(self.cfg))
         entry = self._infer_graphs.get(key)
         if entry is None:
-            sx = torch.empty(tuple(images.shape), dtype=torch.float32, device=self.dev)
-            sw = torch.empty(tuple(windows_norm.shape), dtype=torch.float32, device=self.dev)
+            sx = ops.empty(tuple(images.shape), torch.float32, self.dev)
+            sw = ops.empty(tuple(windows_norm.shape), torch.float32, self.dev)
             sx.copy_(images)
             sw.copy_(windows_norm)
             side = torch.cuda.Stream(device=self.dev)
@@ -417,8 +422,19 @@ class MaskRCNNEngine(object):
         cfg = self.cfg
         return [float(cfg.LOSS_WEIGHTS.get(n, 1.)) if cfg.USE_LOSSES.get(n, True) else 0.0 for n in LOSS_NAMES]
 
-    def forward_backward(self, images, rpn_match, rpn_bbox_t, gt_class_ids, gt_boxes_norm, gt_masks, active_class_ids,
-                         rand_keys, keep_outputs=False):
+    def forward_backward(self, *args, **kwargs):
+        """forward_backward_impl with the step arena active: every tensor the step allocates is the one the
+        previous step used at the same point (ops.StepArena).  Tensors of `self.last` (keep_outputs) are
+        therefore valid until the next step."""
+        ops.set_arena(self.arena)
+        self.arena.begin()
+        try:
+            return self._forward_backward(*args, **kwargs)
+        finally:
+            self.arena.end()
+
+    def _forward_backward(self, images, rpn_match, rpn_bbox_t, gt_class_ids, gt_boxes_norm, gt_masks, active_class_ids,
+                          rand_keys, keep_outputs=False):
         """One training forward/backward on this rank's batch.  All arguments are device tensors:
         images [B,H,W,3] f32, rpn_match [B,A,1] i32, rpn_bbox_t [B,Np,4] f32, gt_class_ids [B,G] i32,
         gt_boxes_norm [B,G,4] f32 (norm_boxes_graph applied), gt_masks [B,H,W,G] u8,
@@ -461,7 +477,7 @@ class MaskRCNNEngine(object):
         losses, d_rpn_logits, d_rpn_bbox, d_logits, d_mbbox, d_mmask = out
 
         # ---- pyramid gradient accumulators ------------------------------------------------------
-        dP = [torch.empty_like(p) for p in pyr[:4]]
+        dP = [ops.empty_like(p) for p in pyr[:4]]
         for t in dP:
             ops.fill_zero(t)
         if aux is not None:
@@ -525,7 +541,7 @@ class MaskRCNNEngine(object):
             mop.wgrad(dz, cm, accumulate=acc)
             d_up = mop.dgrad(dz, cm)                                    # [M,28,28,256]
             # deconv: relu mask + bias, regroup to GEMM columns, then the two GEMM adjoints
-            dzu = torch.empty_like(d_up)
+            dzu = ops.empty_like(d_up)
             ops.epilogue_bwd(d_up, up, None, None, None, None, None, dzu, None, None, dc.db, ACT_RELU)
             dzg = ops.pixel_unshuffle2(dzu)                             # [M,14,14,1024]
         self.wgrad_async(x_in, dzg, dc.wshape, 1, "valid", dc.dw, acc)
@@ -569,8 +585,8 @@ class MaskRCNNEngine(object):
         shared, cls, box = self.op("rpn_conv_shared"), self.op("rpn_class_raw"), self.op("rpn_bbox_pred")
         dP6 = None
         for lvl, (cs, chead, off, H, W) in enumerate(rpn_tape):
-            gl = torch.empty((B, H, W, 2 * na), dtype=torch.float32, device=self.dev)
-            gb = torch.empty((B, H, W, 4 * na), dtype=torch.float32, device=self.dev)
+            gl = ops.empty((B, H, W, 2 * na), torch.float32, self.dev)
+            gb = ops.empty((B, H, W, 4 * na), torch.float32, self.dev)
             ops.copy2d(gl.data_ptr(), H * W * 2 * na * 4, d_logits.data_ptr() + off * 2 * 4, A * 2 * 4, H * W * 2 * na * 4, B)
             ops.copy2d(gb.data_ptr(), H * W * 4 * na * 4, d_bbox.data_ptr() + off * 4 * 4, A * 4 * 4, H * W * 4 * na * 4, B)
             acc = lvl > 0                                            # weights shared by the 5 levels
