@@ -140,7 +140,7 @@ def measure(args, backbone, nimg, rank, local_rank, world, full):
     for _ in range(args.warmup):
         step()
     dt, losses = timed(args.steps)
-    # product default: rows of the mask-head backward whose gradient is exactly zero are skipped
+    # product default: the mask head runs on the positive quota of each image only (rows the loss can read)
     eng.sparse_mask_bwd = True
     if args.dense_only:
         dt_sparse = float("nan")
@@ -259,9 +259,11 @@ def main():
                        "weights": "random init (Keras defaults)"},
             "detect_ms_per_image": round(r["detect_ms"], 3), "detect_ms_per_image_eager": round(r["detect_eager_ms"], 3),
             "value_exact_zero_skip": None if args.dense_only else round(r["images_per_s_sparse"], 3),
-            "note_exact_zero_skip": "same step with the mask-head backward restricted to the <=168 positive ROI rows "
-                                    "per image (all other rows have exactly-zero gradient; results identical, "
-                                    "tests/test_engine_gpu.py::test_sparse_mask_backward_equals_dense); product default",
+            "note_exact_zero_skip": "same step with the mask head (forward and backward) run on the <=168 positive-quota ROI "
+                                    "rows per image only: the other rows are never read by the loss and carry exactly-zero "
+                                    "gradient (identical losses and gradients, "
+                                    "tests/test_engine_gpu.py::test_sparse_mask_backward_equals_dense); product default, "
+                                    "never the headline value",
             "losses_last_step": [round(v, 5) for v in r["losses"]],
             "roofline": r["roofline"],
         }

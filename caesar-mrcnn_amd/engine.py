@@ -457,20 +457,40 @@ class MaskRCNNEngine(object):
         # the two heads are independent: the (small) class/box head runs on the auxiliary stream beside the
         # mask head, forward and backward
         main, aux = torch.cuda.current_stream(self.dev), self.aux_stream
+        # The mask loss only sees positive ROIs (mrcnn_mask_loss_graph, model.py:1250-1257) and
+        # DetectionTargetLayer puts them first (model.py:696), at most int(T * ROI_POSITIVE_RATIO) per image:
+        # the mask-head outputs of every other row are never read and their gradient rows are exactly zero.
+        # With ``sparse_mask_bwd`` (default) the mask head -- forward and backward -- therefore runs on rows
+        # [0, quota) of each image only: same losses, same gradients, ~1/3 of the mask-head FLOPs, no host
+        # synchronisation.  ``sparse_mask_bwd = False`` computes (and multiplies the zeros of) all rows like TF.
+        T = rois.shape[1]
+        quota = min(T, int(T * cfg.ROI_POSITIVE_RATIO))
+        sparse = self.sparse_mask_bwd and 0 < quota < T
+        if sparse:
+            rois_m = ops.empty((B, quota, 4), torch.float32, self.dev)
+            ops.copy2d(rois_m.data_ptr(), quota * 16, rois.data_ptr(), T * 16, quota * 16, B)
+        else:
+            rois_m = rois
         if aux is not None:
             ev = torch.cuda.Event()
             ev.record(main)
             with torch.cuda.stream(aux):
                 aux.wait_event(ev)
                 logits, probs, mbbox, ctx_cls = self._class_head_fwd(rois, pyr[:4], area, True)
-            mmask, ctx_mask = self._mask_head_fwd(rois, pyr[:4], area, True)
+            mmask, ctx_mask = self._mask_head_fwd(rois_m, pyr[:4], area, True)
             main.wait_stream(aux)
             for t in (logits, probs, mbbox):
                 t.record_stream(main)
             rois.record_stream(aux)
         else:
             logits, probs, mbbox, ctx_cls = self._class_head_fwd(rois, pyr[:4], area, True)
-            mmask, ctx_mask = self._mask_head_fwd(rois, pyr[:4], area, True)
+            mmask, ctx_mask = self._mask_head_fwd(rois_m, pyr[:4], area, True)
+        if sparse:                                   # rows [quota, T) of the loss input: zeros, never read as positives
+            row = int(np.prod(mmask.shape[2:])) * 4
+            full = ops.empty((B, T) + tuple(mmask.shape[2:]), torch.float32, self.dev)
+            ops.fill_zero(full)
+            ops.copy2d(full.data_ptr(), T * row, mmask.data_ptr(), quota * row, quota * row, B)
+            mmask = full
         out = ops.losses_fwd_bwd(rpn_match, rpn_bbox_t, rpn_logits, rpn_bbox, tcls, tbbox, tmask, active_class_ids,
                                  logits, mbbox, mmask, self.loss_weights(),
                                  cfg.MASK_LOSS_FUNCTION == "dice_coef_loss")
@@ -486,12 +506,12 @@ class MaskRCNNEngine(object):
             with torch.cuda.stream(aux):
                 aux.wait_event(ev)
                 self._class_head_bwd(d_logits, d_mbbox, ctx_cls, rois, dP, area)
-            self._mask_head_bwd(d_mmask, ctx_mask, rois, dP, area)
+            self._mask_head_bwd(d_mmask, ctx_mask, rois_m, dP, area)
             main.wait_stream(aux)
             d_logits.record_stream(aux)
             d_mbbox.record_stream(aux)
         else:
-            self._mask_head_bwd(d_mmask, ctx_mask, rois, dP, area)
+            self._mask_head_bwd(d_mmask, ctx_mask, rois_m, dP, area)
             self._class_head_bwd(d_logits, d_mbbox, ctx_cls, rois, dP, area)
         if self.grad_ready:                      # ~2/3 of the gradient bytes (FC1 alone is 51 MB) are final here,
             self.join_wgrad()
@@ -507,23 +527,16 @@ class MaskRCNNEngine(object):
 
     # ---- head backward --------------------------------------------------------------------------
     def _mask_head_bwd(self, d_mmask, ctxs, rois, dP, area):
-        """Backward of build_fpn_mask_graph.  The mask loss only sees positive ROIs
-        (mrcnn_mask_loss_graph, model.py:1250-1257) and DetectionTargetLayer puts them first
-        (model.py:696), at most int(T*ROI_POSITIVE_RATIO) per image: every other row of d_mmask is
-        exactly zero and contributes exact zeros to every gradient.  With ``sparse_mask_bwd`` (default)
-        the backward therefore runs on rows [0, quota) of each image only -- same results, ~1/3 of the
-        mask-head backward FLOPs.  ``sparse_mask_bwd = False`` multiplies the zeros like TF does."""
-        B, T = rois.shape[0], rois.shape[1]
-        quota = min(T, int(T * self.cfg.ROI_POSITIVE_RATIO))
-        if not self.sparse_mask_bwd or quota == T or quota == 0:
-            self._mask_head_bwd_rows(d_mmask.view((B * T,) + tuple(d_mmask.shape[2:])), ctxs, rois, dP, area, False)
-            return
-        for b in range(B):
-            def sl(t):
-                return t.view((B, T) + tuple(t.shape[1:]))[b, :quota] if torch.is_tensor(t) else t
-            ctx_b = [tuple(sl(t) for t in c) for c in ctxs]
-            self._mask_head_bwd_rows(d_mmask[b, :quota], ctx_b, rois[b:b + 1, :quota], [p_[b:b + 1] for p_ in dP], area,
-                                     b > 0)
+        """Backward of build_fpn_mask_graph on the rows the forward ran on: ``rois`` is [B, R, 4] with R = T
+        (all train ROIs) or the positive quota (see forward_backward); d_mmask is always [B, T, ...]."""
+        B, T, R = d_mmask.shape[0], d_mmask.shape[1], rois.shape[1]
+        if R == T:
+            g = d_mmask
+        else:
+            row = int(np.prod(d_mmask.shape[2:])) * 4
+            g = ops.empty((B, R) + tuple(d_mmask.shape[2:]), torch.float32, self.dev)
+            ops.copy2d(g.data_ptr(), R * row, d_mmask.data_ptr(), T * row, R * row, B)
+        self._mask_head_bwd_rows(g.view((B * R,) + tuple(g.shape[2:])), ctxs, rois, dP, area, False)
 
     def _mask_head_bwd_rows(self, g, ctxs, rois, dP, area, acc):
         cfg = self.cfg

@@ -177,7 +177,11 @@ def test_training_step_staged(dev, backbone, size, dice):
                              meta[:, 12:].astype(np.int32), anchors, keys, forced=forced)
     _close(last["rpn_class_logits"], ref["rpn_class_logits"].detach(), 1e-3, "rpn_class_logits")
     _close(last["mrcnn_class_logits"], ref["mrcnn_class_logits"].detach(), 1e-3, "mrcnn_class_logits")
-    _close(last["mrcnn_mask"], ref["mrcnn_mask"].detach(), 1e-3, "mrcnn_mask")
+    # product default: the mask head runs on the positive quota of each image only (rows the loss can read)
+    quota = int(cfg.TRAIN_ROIS_PER_IMAGE * cfg.ROI_POSITIVE_RATIO)
+    assert eng.sparse_mask_bwd and 0 < quota < cfg.TRAIN_ROIS_PER_IMAGE
+    _close(last["mrcnn_mask"][:, :quota], ref["mrcnn_mask"].detach().numpy()[:, :quota], 1e-3, "mrcnn_mask")
+    assert not last["mrcnn_mask"][:, quota:].any()
     np.testing.assert_allclose(losses.cpu().numpy(), [float(l.detach()) for l in ref["losses"]], rtol=2e-3, atol=1e-5)
     total = o.total_loss(ref["losses"])
     total.backward()
@@ -252,7 +256,8 @@ def test_frozen_layers_and_heads_preset(dev):
 
 
 def test_sparse_mask_backward_equals_dense(dev):
-    """Skipping the exactly-zero (non-positive) rows of the mask-head backward changes nothing."""
+    """Running the mask head (forward and backward) on the positive quota only changes neither the losses
+    nor the gradients: the skipped rows are never read by the loss and carry exactly-zero gradient."""
     from caesar_mrcnn_amd.model import MaskRCNN
     cfg = _small_cfg("custom", 128)
     w = _weights(cfg, 19)
@@ -261,10 +266,14 @@ def test_sparse_mask_backward_equals_dense(dev):
     for sparse in (True, False):
         model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
         model.engine.sparse_mask_bwd = sparse
-        losses = model.train_on_batch(inputs, rand_keys=keys, apply=False)
+        losses = model.train_on_batch(inputs, rand_keys=keys, apply=False, keep_outputs=True)
         torch.cuda.synchronize()
-        grads.append((losses.cpu().numpy(), model.engine.grads.cpu().numpy().copy()))
-    np.testing.assert_array_equal(grads[0][0], grads[1][0])
+        grads.append((losses.cpu().numpy(), model.engine.grads.cpu().numpy().copy(),
+                      model.engine.last["mrcnn_mask"].cpu().numpy().copy()))
+    quota = int(cfg.TRAIN_ROIS_PER_IMAGE * cfg.ROI_POSITIVE_RATIO)
+    np.testing.assert_allclose(grads[0][2][:, :quota], grads[1][2][:, :quota], rtol=1e-5, atol=1e-6)
+    assert not grads[0][2][:, quota:].any() and grads[1][2][:, quota:].any()       # dense computes every row
+    np.testing.assert_allclose(grads[0][0], grads[1][0], rtol=1e-6)
     scale = np.abs(grads[1][1]).max()
     assert np.abs(grads[0][1] - grads[1][1]).max() <= 2e-5 * scale
     assert np.abs(grads[1][1]).sum() > 0
