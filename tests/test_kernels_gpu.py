@@ -42,6 +42,9 @@ CONV_CASES = [
     (16, 64, 64, 256, 12, 1, 1, "valid", 0, False, 0),   # 128x32 tiles, ragged Cout
     (1, 8, 8, 512, 6, 1, 1, "valid", 0, False, 0),       # 64x32 tiles, scalar B loads
     (4, 28, 28, 256, 4, 1, 1, "valid", 2, False, 0),     # mask logits + sigmoid
+    (64, 14, 14, 256, 256, 3, 1, "same", 1, True, 1),    # LDS-DMA 128x128 kernel: padded taps, residual
+    (90, 13, 11, 128, 256, 3, 1, "same", 1, False, 0),   # LDS-DMA kernel, ragged M (12870 = 100 x 128 + 70), odd H/W
+    (3, 64, 64, 256, 128, 1, 1, "valid", 0, False, 0),   # LDS-DMA kernel, 1x1, one N tile
 ]
 
 
@@ -132,6 +135,8 @@ WGRAD_CASES = [
     (3, 9, 9, 128, 64, 1, 1, "valid"),
     (2, 16, 16, 1024, 512, 1, 2, "valid"),      # strided-scatter dgrad through the split-K path
     (2, 8, 8, 2048, 512, 1, 1, "valid"),
+    (3, 13, 11, 128, 256, 3, 1, "same"),        # LDS-DMA wgrad: M = 429 (pixel tail inside a 16-row piece), odd H/W
+    (90, 13, 11, 128, 256, 3, 1, "same"),       # LDS-DMA wgrad + LDS-DMA dgrad, ragged M
 ]
 
 
