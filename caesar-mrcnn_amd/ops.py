@@ -479,3 +479,48 @@ def mask_out_bwd(d_mask, mask, up, w_mask, dw_mask, db_mask, db_deconv):
                                         ptr(db_mask), ptr(db_deconv), M, H, W, Cd, C_, current_stream()),
           "mrcnn_mask_out_bwd")
     return dzg
+
+
+# ---- 16-bit matrix-core path (configs[4], stage 1: ROI-head convolutions) ---------------------------------------
+_H16 = {torch.float16: 0, torch.bfloat16: 1}
+
+
+def weights_to_h16(w, dtype=torch.float16, want_dgrad=True):
+    """float32 HWIO kernel -> (W^T [Cout, KH*KW*Cin], data-gradient image [Cin, KH*KW*Cout]) in `dtype`."""
+    _need_cuda(w)
+    KH, KW, Cin, Cout = w.shape
+    wf = torch.empty((Cout, KH * KW * Cin), dtype=dtype, device=w.device)
+    wd = torch.empty((Cin, KH * KW * Cout), dtype=dtype, device=w.device) if want_dgrad else None
+    check(_hip.lib().mrcnn_weights_to_h16(ptr(w), ptr(wf), ptr(wd), KH, KW, Cin, Cout, _H16[dtype], current_stream()),
+          "mrcnn_weights_to_h16")
+    return wf, wd
+
+
+def conv2d_h16(x, w_t, kshape, bias=None, scale=None, shift=None, stride=1, padding="same", act=ACT_NONE, z_out=None,
+               out=None):
+    """16-bit convolution: x [N,H,W,Cin] half/bfloat16, w_t = W^T [Cout, KH*KW*Cin]; kshape = (KH, KW, Cin, Cout)."""
+    _need_cuda(x, w_t, bias, scale, shift, z_out, out)
+    assert x.dtype in _H16 and w_t.dtype == x.dtype
+    d = conv_desc(tuple(x.shape), tuple(kshape), stride, padding, act, RES_NONE)
+    if out is None:
+        out = empty((d.N, d.OH, d.OW, d.Cout), x.dtype, x.device)
+    check(_hip.lib().mrcnn_conv2d_fwd_h16(C.byref(d), _H16[x.dtype], ptr(x), ptr(w_t), ptr(bias), ptr(scale), ptr(shift),
+                                          ptr(out), ptr(z_out), current_stream()), "mrcnn_conv2d_fwd_h16")
+    return out
+
+
+def cast_to_h16(src, dtype=torch.float16, out=None):
+    _need_cuda(src, out)
+    if out is None:
+        out = empty(src.shape, dtype, src.device)
+    check(_hip.lib().mrcnn_cast_to_h16(ptr(src), ptr(out), src.numel(), _H16[dtype], current_stream()), "mrcnn_cast_to_h16")
+    return out
+
+
+def cast_from_h16(src, multiplier=1.0, out=None):
+    _need_cuda(src, out)
+    if out is None:
+        out = empty(src.shape, torch.float32, src.device)
+    check(_hip.lib().mrcnn_cast_from_h16(ptr(src), ptr(out), src.numel(), _H16[src.dtype], float(multiplier),
+                                         current_stream()), "mrcnn_cast_from_h16")
+    return out

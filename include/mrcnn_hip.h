@@ -182,6 +182,21 @@ int mrcnn_detection_targets(const mrcnn_dettarget_desc* d, const float* proposal
                             int32_t* target_class_ids, float* target_bbox, float* target_mask,
                             int32_t* roi_gt_assignment, int32_t* counts, void* stream);
 
+/* ---- 16-bit matrix-core path (BASELINE.json configs[4]; stage 1: the convolutions of the ROI heads) ------------
+ * Operands float16 / bfloat16, accumulation + bias + frozen-BN affine + activation float32, one rounding of the
+ * result.  Shapes: Cin % 32 == 0, Cout % 128 == 0, dense NHWC output, no residual (the mask / class head layers).
+ * w_t is the transposed weight image [Cout][KH*KW*Cin] written by mrcnn_weights_to_h16 (wt_fwd); its second
+ * output wt_dgrad [Cin][KH*KW*Cout] (taps rotated by 180 degrees) is the operand of the data gradient, which is
+ * the same convolution applied to dz with Cin/Cout swapped and padding (k-1)/2.  Either output may be NULL.   */
+#define MRCNN_DTYPE_F16 0
+#define MRCNN_DTYPE_BF16 1
+int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const void* x, const void* w_t, const float* bias,
+                         const float* scale, const float* shift, void* out, void* z_out, void* stream);
+int mrcnn_weights_to_h16(const float* w_hwio, void* wt_fwd, void* wt_dgrad, int KH, int KW, int Cin, int Cout,
+                         int dtype, void* stream);
+int mrcnn_cast_to_h16(const float* src, void* dst, int64_t n, int dtype, void* stream);
+int mrcnn_cast_from_h16(const void* src, float* dst, int64_t n, int dtype, float multiplier, void* stream);
+
 /* build_rpn_targets (mrcnn/model.py:1536-1644), the per-image RPN target builder of the CPU input
  * pipeline, for one batch on the device.  anchors [A,4] float64 pixels (utils.generate_pyramid_anchors);
  * gt_class_ids [B,G] (>0 instance, <0 crowd, 0 padding); gt_boxes [B,G,4] int32 pixels; rand_keys [B,A]

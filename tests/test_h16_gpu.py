@@ -1,0 +1,88 @@
+"""16-bit matrix-core path (BASELINE configs[4], stage 1): float16 / bfloat16 convolutions of the ROI heads
+against the float32 oracle evaluated on the SAME 16-bit-rounded operands.  The kernel multiplies exactly
+(16-bit x 16-bit products are exact in float32) and accumulates in float32, so what is left is summation order
+and the single output rounding: tolerance 2^-10 (f16) / 2^-7 (bf16) of the output magnitude, stated below."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import mrcnn_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float16: 2.0 ** -10, torch.bfloat16: 2.0 ** -7}
+
+
+def _ops():
+    import caesar_mrcnn_amd  # noqa: F401
+    from caesar_mrcnn_amd import ops
+    return ops
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "the -m gpu tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+H16_CASES = [
+    # N, H, W, Cin, Cout, k, padding, act, bn
+    (64, 14, 14, 256, 256, 3, "same", 1, True),      # mask-head conv: padded taps, several 256-row tiles
+    (90, 13, 11, 128, 256, 3, "same", 0, False),     # ragged M (12870), odd H/W
+    (5, 16, 16, 128, 128, 1, "valid", 1, True),      # 1x1, one N tile
+    (300, 7, 7, 256, 1024, 7, "valid", 1, True),     # class-head FC as 7x7 VALID conv (49 taps, 64-bit tap mask)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", H16_CASES)
+def test_conv_fwd_h16(dev, case, dtype):
+    ops = _ops()
+    N, H, W, Cin, Cout, k, padding, act, bn = case
+    rng = np.random.default_rng(sum(case[:6]))
+    x = torch.tensor(rng.standard_normal((N, H, W, Cin)).astype(np.float32)).to(dtype)
+    w = torch.tensor((rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)).to(dtype)
+    b = torch.tensor(rng.standard_normal(Cout).astype(np.float32) * 0.1)
+    z_ref = orc.conv2d_nhwc(x.float(), w.float(), b, 1, padding)
+    y_ref = z_ref
+    scale = shift = None
+    if bn:
+        scale = torch.tensor(rng.uniform(0.5, 1.5, Cout).astype(np.float32))
+        shift = torch.tensor(rng.uniform(-0.2, 0.2, Cout).astype(np.float32))
+        y_ref = z_ref * scale + shift
+    if act == 1:
+        y_ref = torch.relu(y_ref)
+    wf, wd = ops.weights_to_h16(w.float().to(dev), dtype)
+    np.testing.assert_array_equal(wf.float().cpu().numpy(), w.float().permute(3, 0, 1, 2).reshape(Cout, -1).numpy())
+    z = torch.empty((N,) + tuple(z_ref.shape[1:]), dtype=dtype, device=dev)
+    y = ops.conv2d_h16(x.to(dev), wf, (k, k, Cin, Cout), b.to(dev), None if scale is None else scale.to(dev),
+                       None if shift is None else shift.to(dev), 1, padding, act, z_out=z)
+    torch.cuda.synchronize()
+    assert y.dtype == dtype and tuple(y.shape) == tuple(y_ref.shape)
+    for got, ref, name in ((y, y_ref, "out"), (z, z_ref, "z")):
+        err = float((got.float().cpu() - ref).abs().max()) / float(ref.abs().max())
+        assert err <= TOL[dtype], "%s: max error %.3g of max |ref| (allowed %.3g)" % (name, err, TOL[dtype])
+    # data gradient: the same kernel on dz with the rotated weight image
+    if padding == "same" or k == 1:
+        xg = x.float().clone().requires_grad_(True)
+        yy = orc.conv2d_nhwc(xg, w.float(), None, 1, padding)
+        dz = torch.tensor(rng.standard_normal(tuple(yy.shape)).astype(np.float32)).to(dtype)
+        yy.backward(dz.float())
+        pad = ((k - 1) // 2, (k - 1) // 2) if k > 1 else "valid"
+        dx = ops.conv2d_h16(dz.to(dev), wd, (k, k, Cout, Cin), None, None, None, 1, pad, 0)
+        torch.cuda.synchronize()
+        err = float((dx.float().cpu() - xg.grad).abs().max()) / float(xg.grad.abs().max())
+        assert err <= TOL[dtype], "dgrad: max error %.3g (allowed %.3g)" % (err, TOL[dtype])
+
+
+def test_casts(dev):
+    ops = _ops()
+    x = torch.randn(100003, device=dev) * 3
+    for dtype in (torch.float16, torch.bfloat16):
+        h = ops.cast_to_h16(x, dtype)
+        assert torch.equal(h, x.to(dtype))
+        assert torch.equal(ops.cast_from_h16(h, 0.5), h.float() * 0.5)

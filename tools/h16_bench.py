@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Times the 16-bit conv kernels on the mask-head shape (tools only)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import caesar_mrcnn_amd  # noqa
+from caesar_mrcnn_amd import ops
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+dev = torch.device("cuda:0")
+for dtype in (torch.float16, torch.bfloat16):
+    x = torch.randn(N, 14, 14, 256, device=dev).to(dtype)
+    w = torch.randn(3, 3, 256, 256, device=dev) * 0.02
+    wf, wd = ops.weights_to_h16(w, dtype)
+    b = torch.zeros(256, device=dev); sc = torch.ones(256, device=dev)
+    out = torch.empty(N, 14, 14, 256, device=dev, dtype=dtype)
+    for _ in range(3):
+        ops.conv2d_h16(x, wf, (3, 3, 256, 256), b, sc, b, 1, "same", 1, out=out)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        ops.conv2d_h16(x, wf, (3, 3, 256, 256), b, sc, b, 1, "same", 1, out=out)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    fl = 2.0 * N * 196 * 256 * 2304
+    print("%s fwd N=%d: %.3f ms  %.1f TFLOP/s" % (dtype, N, ms, fl / ms / 1e9))
