@@ -28,6 +28,8 @@ template <> struct H16Traits<__bf16> {
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 
+static int h16_dtype_ok(int dtype) { return dtype == MRCNN_DTYPE_F16 || dtype == MRCNN_DTYPE_BF16; }
+
 struct ConvH16Args {
     const void* x; const void* wt; const float* bias; const float* scale; const float* shift; void* out; void* z;
     int N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW, act, M, Ktot;
@@ -223,7 +225,269 @@ __global__ void cast_from_h16_kernel(const T* __restrict__ src, float* dst, long
     for (long long j = i; j < i + 4 && j < n; ++j) dst[j] = (float)src[j] * mul;
 }
 
-static int h16_dtype_ok(int dtype) { return dtype == MRCNN_DTYPE_F16 || dtype == MRCNN_DTYPE_BF16; }
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient in 16 bits: dW[(tap, ci), co] = sum_m X[m, (tap, ci)] * dY[m, co], float32 accumulation and
+// float32 output (slabs per pixel split, summed in fixed order into the float32 gradient buffer).
+// The contraction runs over pixels, but both operands are stored pixel-major, so each MFMA operand (8
+// consecutive pixels of one channel per lane) is a TRANSPOSED read of the LDS tile: ds_read_b64_tr_b16 delivers
+// a 4-pixel x 16-channel block column-major to a 16-lane group.  Tiles: 256 (tap, ci) x 128 co per workgroup,
+// 4 waves of 128 x 64, 32 pixels per step; X [32][256] (512-byte rows) and dY [32][128] (256-byte rows) arrive
+// by buffer-addressed LDS-DMA.  The four pixel rows one transposed read touches are 512 / 256 bytes apart and
+// would share banks: logical 16-byte chunk c of pixel row r is stored at chunk c ^ ((r & 3) << 2) (applied on
+// the SOURCE side of the DMA, and in the read addresses), which makes the reads conflict-free.
+// Per-pixel input offsets and tap-validity masks come from a table built once per geometry
+// (pixel_table_kernel): 16 bytes per pixel, prefetched one step ahead -- no divisions in the loop.
+typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
+typedef __attribute__((address_space(3))) s16x4* h16_tr_ptr;
+#define H16_WG_OOB 0x80000000u
+
+struct PixelEntry { unsigned off, mask_lo, mask_hi, pad; };
+
+__global__ void pixel_table_kernel(PixelEntry* table, int N, int H, int W, int Cin, int KH, int KW, int stride, int pad_t,
+                                   int pad_l, int OH, int OW, int M, int rows, unsigned x_shift) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= rows) return;
+    PixelEntry e;
+    e.off = H16_WG_OOB; e.mask_lo = 0u; e.mask_hi = 0u; e.pad = 0u;
+    if (m < M) {
+        const int ohw = OH * OW;
+        const int n = m / ohw, rem = m - n * ohw;
+        const int oh = rem / OW, ow = rem - oh * OW;
+        const int ih0 = oh * stride - pad_t, iw0 = ow * stride - pad_l;
+        e.off = (unsigned)((((long long)n * H + ih0) * W + iw0) * Cin * 2 + x_shift);
+        unsigned long long mk = 0ull;
+        for (int t = 0; t < KH * KW; ++t) {
+            const int th = t / KW, tw = t - th * KW;
+            if ((unsigned)(ih0 + th) < (unsigned)H && (unsigned)(iw0 + tw) < (unsigned)W) mk |= 1ull << t;
+        }
+        e.mask_lo = (unsigned)mk; e.mask_hi = (unsigned)(mk >> 32);
+    }
+    table[m] = e;
+}
+
+struct WgradH16Args {
+    const void* x; const void* dy; float* out; const PixelEntry* table;
+    int N, H, W, Cin, Cout, KH, KW, OH, OW, M, Ktot, splits, chunk;
+    unsigned x_shift, x_records;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(const WgradH16Args p) {
+    typedef typename H16Traits<T>::v8 v8;
+    constexpr int BI = 256, BN = 128, BP = 32, TM = 4, TN = 2;
+    constexpr int XROW = BI * 2, YROW = BN * 2;                 // bytes per pixel row
+    constexpr int XB = BP * XROW, YB = BP * YROW;               // 16 KiB + 8 KiB per buffer
+    __shared__ __attribute__((aligned(16))) char lds[2 * (XB + YB)];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.Cout / BN, itiles = p.Ktot / BI;
+    int bid = blockIdx.x;
+    const int ntile = bid % ntiles; bid /= ntiles;
+    const int itile = bid % itiles;
+    const int split = bid / itiles;
+    const int i0 = itile * BI, n0 = ntile * BN;
+    const int m_begin = split * p.chunk;
+    const int m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
+    const int tap = i0 / p.Cin, ci0 = i0 - tap * p.Cin;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - p.x_shift), 0, p.x_records, 0x00020000);
+    const unsigned soff_x = (unsigned)(((kh * p.W + kw) * p.Cin + ci0) * 2);
+    const unsigned tapbit = 1u << (tap & 31);
+    const bool tap_hi = tap >= 32;
+
+    // X piece j = rows 2j, 2j+1 (wave: j = wave + 4 jj): lane -> row 2j + (lane>>5), physical chunk lane&31
+    const int xr = (2 * wave + (lane >> 5)) & 3;                // (row & 3), the same for all four pieces of this wave
+    const unsigned x_lane = (unsigned)((((lane & 31) ^ (xr << 2)) & 31) * 16);
+    // dY piece j = rows 4j .. 4j+3 (wave: j = wave + 4 jj): lane -> row 4j + (lane>>4), physical chunk lane&15
+    const int yr = (lane >> 4) & 3;
+    const unsigned y_voff = (unsigned)((lane >> 4) * p.Cout * 2 + (((lane & 15) ^ (yr << 2)) & 15) * 16);
+
+    const PixelEntry* tab = p.table + (lane >> 5);
+    PixelEntry ent[4];
+    auto fetch = [&](int mb) {                                   // table rows exist up to M + BP - 1
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) ent[jj] = tab[mb + 2 * (wave + 4 * jj)];
+    };
+    auto stage = [&](char* xb, int mb) {
+        char* yb = xb + XB;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const unsigned word = tap_hi ? ent[jj].mask_hi : ent[jj].mask_lo;
+            const unsigned vo = ((word & tapbit) ? ent[jj].off : H16_WG_OOB) + x_lane;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (h16_lds_ptr)(xb + (wave + 4 * jj) * 1024), 16, vo, soff_x, 0, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = wave + 4 * jj;
+            const int row0 = mb + 4 * j;
+            const int left = m_end - row0;
+            const unsigned rec = left > 0 ? (unsigned)(((left - 1) * p.Cout + BN) * 2) : 0u;
+            const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)((const char*)p.dy + ((long long)row0 * p.Cout + n0) * 2), 0, rec, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (h16_lds_ptr)(yb + j * 1024), 16, y_voff, 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // transposed-read addresses: lane supplies pixel row 8*(lane>>5) + q (+ 4t + 16kk), q = (lane&15)>>2, and the 8 bytes of
+    // columns 4*(lane&3) .. +3 of its 16-lane group's 16 channels; logical chunk -> physical chunk ^ (q << 2)
+    const int q = (lane & 15) >> 2;
+    const int xcol = wm * 128 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);          // channel (+ a * 32)
+    const int ycol = wn * 64 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const int prow = 8 * (lane >> 5) + q;
+    // a * 32 channels = 4 chunks: the XOR touches chunk bits 2..3 only when q != 0, so "+ a * 64 bytes" is not uniform;
+    // keep one base per a (4) and per b (2) instead of immediates
+    const char* x_rda[TM];
+    const char* y_rdb[TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int c = xcol + a * 32;
+        x_rda[a] = lds + prow * XROW + ((((c >> 3) ^ (q << 2)) & 31) << 4) + (c & 7) * 2;
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int c = ycol + b * 32;
+        y_rdb[b] = lds + XB + prow * YROW + ((((c >> 3) ^ (q << 2)) & 15) << 4) + (c & 7) * 2;
+    }
+
+    auto compute = [&](auto curc) {
+        constexpr int BO = decltype(curc)::value * (XB + YB);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            v8 av[TM], bv[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                union { s16x4 h[2]; v8 v; } u;
+                u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_tr_ptr)(x_rda[a] + BO + kk * 16 * XROW));
+                u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_tr_ptr)(x_rda[a] + BO + kk * 16 * XROW + 4 * XROW));
+                av[a] = u.v;
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                union { s16x4 h[2]; v8 v; } u;
+                u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_tr_ptr)(y_rdb[b] + BO + kk * 16 * YROW));
+                u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_tr_ptr)(y_rdb[b] + BO + kk * 16 * YROW + 4 * YROW));
+                bv[b] = u.v;
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = H16Traits<T>::mfma(av[a], bv[b], acc[a][b]);
+        }
+    };
+
+    if (m_begin < m_end) {
+        fetch(m_begin);
+        stage(lds, m_begin);
+        if (m_begin + BP < m_end) fetch(m_begin + BP);
+        __syncthreads();
+        for (int mb = m_begin; mb < m_end; mb += 2 * BP) {
+            if (mb + BP < m_end) { stage(lds + (XB + YB), mb + BP); if (mb + 2 * BP < m_end) fetch(mb + 2 * BP); }
+            compute(std::integral_constant<int, 0>{});
+            __syncthreads();
+            if (mb + BP < m_end) {
+                if (mb + 2 * BP < m_end) { stage(lds, mb + 2 * BP); if (mb + 3 * BP < m_end) fetch(mb + 3 * BP); }
+                compute(std::integral_constant<int, 1>{});
+                __syncthreads();
+            }
+        }
+    }
+
+    float* dst = p.out + (long long)split * p.Ktot * p.Cout;
+    const int li = lane & 31, lh = lane >> 5;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int ib = i0 + wm * 128 + a * 32 + 4 * lh, n = n0 + wn * 64 + b * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(long long)(ib + (r & 3) + 8 * (r >> 2)) * p.Cout + n] = acc[a][b][r];
+        }
+}
+
+__global__ void wgrad_h16_reduce_kernel(const float* __restrict__ slabs, float* dw, long long n, int splits, int acc, float mul) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
+    s *= mul;
+    dw[i] = acc ? dw[i] + s : s;
+}
+
+struct WgradH16Plan { int splits, chunk; size_t table_bytes, slab_bytes; };
+
+static WgradH16Plan plan_wgrad_h16(const mrcnn_conv_desc* d) {
+    WgradH16Plan pl;
+    const long long M = (long long)d->N * d->OH * d->OW;
+    const long long tiles = (long long)(d->KH * d->KW * d->Cin / 256) * (d->Cout / 128);
+    long long splits = 768 / (tiles > 0 ? tiles : 1);           // 3 workgroups per CU (48 KiB LDS each)
+    const long long max_splits = (M + 511) / 512;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 64) splits = 64;
+    long long chunk = ((M + splits - 1) / splits + 31) / 32 * 32;
+    splits = (M + chunk - 1) / chunk;
+    pl.splits = (int)splits; pl.chunk = (int)chunk;
+    pl.table_bytes = (size_t)(M + 32) * sizeof(PixelEntry);
+    pl.slab_bytes = (size_t)splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
+    return pl;
+}
+
+static int wgrad_h16_shape_ok(const mrcnn_conv_desc* d) {
+    return d && d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0 &&
+           d->OH > 0 && d->OW > 0 && d->KH * d->KW <= 64 && d->Cin % 256 == 0 && d->Cout % 128 == 0;
+}
+
+extern "C" size_t mrcnn_conv2d_wgrad_h16_workspace(const mrcnn_conv_desc* d) {
+    if (!wgrad_h16_shape_ok(d)) return 0;
+    const WgradH16Plan pl = plan_wgrad_h16(d);
+    return pl.table_bytes + pl.slab_bytes + 256;
+}
+
+extern "C" int mrcnn_conv2d_wgrad_h16(const mrcnn_conv_desc* d, int dtype, const void* x, const void* dy, float* dw,
+                                      void* workspace, size_t workspace_bytes, int beta_acc, float multiplier, void* stream) {
+    if (!wgrad_h16_shape_ok(d) || !x || !dy || !dw || !workspace || !h16_dtype_ok(dtype)) return MRCNN_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(dy) & 15)) return MRCNN_ERR_ARG;
+    const long long M = (long long)d->N * d->OH * d->OW;
+    const long long xbytes = (long long)d->N * d->H * d->W * d->Cin * 2;
+    const long long shift_b = ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 2;
+    if (M >= (1LL << 30) || xbytes + shift_b >= 0x7FFFFF00LL || M * d->Cout * 2 >= 0x7FFFFF00LL) return MRCNN_ERR_ARG;
+    const WgradH16Plan pl = plan_wgrad_h16(d);
+    if (workspace_bytes < mrcnn_conv2d_wgrad_h16_workspace(d)) return MRCNN_ERR_WORKSPACE;
+    char* ws = (char*)((reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255);
+    PixelEntry* table = (PixelEntry*)ws;
+    float* slabs = (float*)(ws + ((pl.table_bytes + 255) & ~(size_t)255));
+    hipStream_t s = (hipStream_t)stream;
+    const int rows = (int)M + 32;
+    hipLaunchKernelGGL(pixel_table_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, table, d->N, d->H, d->W, d->Cin,
+                       d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->OH, d->OW, (int)M, rows, (unsigned)shift_b);
+    WgradH16Args a;
+    a.x = x; a.dy = dy; a.out = slabs; a.table = table;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.OH = d->OH; a.OW = d->OW;
+    a.M = (int)M; a.Ktot = d->KH * d->KW * d->Cin; a.splits = pl.splits; a.chunk = pl.chunk;
+    a.x_shift = (unsigned)shift_b; a.x_records = (unsigned)(xbytes + shift_b);
+    const unsigned blocks = (unsigned)((a.Ktot / 256) * (a.Cout / 128) * pl.splits);
+    if (dtype == MRCNN_DTYPE_F16)
+        hipLaunchKernelGGL(conv_wgrad_h16_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(conv_wgrad_h16_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, a);
+    const long long n = (long long)a.Ktot * a.Cout;
+    hipLaunchKernelGGL(wgrad_h16_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, slabs, dw, n, pl.splits, beta_acc,
+                       multiplier);
+    return mrcnn_launch_status();
+}
+
 
 extern "C" int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const void* x, const void* w_t, const float* bias,
                                     const float* scale, const float* shift, void* out, void* z_out, void* stream) {

@@ -509,6 +509,21 @@ def conv2d_h16(x, w_t, kshape, bias=None, scale=None, shift=None, stride=1, padd
     return out
 
 
+def conv2d_wgrad_h16(x, dy, w_shape, stride=1, padding="same", dw=None, accumulate=False, multiplier=1.0):
+    """dw (float32 HWIO) from 16-bit x / dy; multiplier undoes a loss scale."""
+    _need_cuda(x, dy, dw)
+    assert x.dtype in _H16 and dy.dtype == x.dtype
+    d = conv_desc(tuple(x.shape), tuple(w_shape), stride, padding)
+    if dw is None:
+        dw = empty(tuple(w_shape), torch.float32, x.device)
+    nbytes = _hip.lib().mrcnn_conv2d_wgrad_h16_workspace(C.byref(d))
+    ws = workspace(nbytes, x.device, "wgrad_h16")
+    check(_hip.lib().mrcnn_conv2d_wgrad_h16(C.byref(d), _H16[x.dtype], ptr(x), ptr(dy), ptr(dw), ptr(ws), ws.numel(),
+                                            1 if accumulate else 0, float(multiplier), current_stream()),
+          "mrcnn_conv2d_wgrad_h16")
+    return dw
+
+
 def cast_to_h16(src, dtype=torch.float16, out=None):
     _need_cuda(src, out)
     if out is None:

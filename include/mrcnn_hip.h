@@ -194,6 +194,12 @@ int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const void* x, con
                          const float* scale, const float* shift, void* out, void* z_out, void* stream);
 int mrcnn_weights_to_h16(const float* w_hwio, void* wt_fwd, void* wt_dgrad, int KH, int KW, int Cin, int Cout,
                          int dtype, void* stream);
+/* Weight gradient with 16-bit operands x [N,H,W,Cin], dy [N,OH,OW,Cout]: dw (float32, HWIO) = multiplier * sum
+ * (or dw += ... with beta_acc); float32 accumulation, slabs per pixel split summed in a fixed order.
+ * Cin % 256 == 0, Cout % 128 == 0.  The workspace also holds a per-pixel offset / tap-mask table.           */
+size_t mrcnn_conv2d_wgrad_h16_workspace(const mrcnn_conv_desc* d);
+int mrcnn_conv2d_wgrad_h16(const mrcnn_conv_desc* d, int dtype, const void* x, const void* dy, float* dw,
+                           void* workspace, size_t workspace_bytes, int beta_acc, float multiplier, void* stream);
 int mrcnn_cast_to_h16(const float* src, void* dst, int64_t n, int dtype, void* stream);
 int mrcnn_cast_from_h16(const void* src, float* dst, int64_t n, int dtype, float multiplier, void* stream);
 

@@ -79,6 +79,38 @@ def test_conv_fwd_h16(dev, case, dtype):
         assert err <= TOL[dtype], "dgrad: max error %.3g (allowed %.3g)" % (err, TOL[dtype])
 
 
+WGRAD_H16_CASES = [
+    # N, H, W, Cin, Cout, k, padding
+    (64, 14, 14, 256, 256, 3, "same"),       # mask-head conv, several pixel splits
+    (3, 13, 11, 256, 128, 3, "same"),        # M = 429: pixel tail inside a 32-row step, odd H/W
+    (37, 7, 7, 256, 1024, 7, "valid"),       # class-head FC as 7x7 VALID conv: 49 taps, one pixel per ROI
+    (5, 16, 16, 512, 128, 1, "valid"),       # 1x1, two channel tiles in one tap
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", WGRAD_H16_CASES)
+def test_conv_wgrad_h16(dev, case, dtype):
+    """float32 result of exact 16-bit products: only the summation order differs from the oracle (2e-4 of max)."""
+    ops = _ops()
+    N, H, W, Cin, Cout, k, padding = case
+    rng = np.random.default_rng(sum(case[:6]) + 1)
+    x = torch.tensor(rng.standard_normal((N, H, W, Cin)).astype(np.float32)).to(dtype)
+    w = torch.zeros((k, k, Cin, Cout), requires_grad=True)
+    y = orc.conv2d_nhwc(x.float(), w, None, 1, padding)
+    dy = torch.tensor(rng.standard_normal(tuple(y.shape)).astype(np.float32)).to(dtype)
+    y.backward(dy.float())
+    dw = ops.conv2d_wgrad_h16(x.to(dev), dy.to(dev), (k, k, Cin, Cout), 1, padding)
+    torch.cuda.synchronize()
+    ref = w.grad
+    err = float((dw.cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-4, "wgrad: max error %.3g of max |ref|" % err
+    dw2 = ops.conv2d_wgrad_h16(x.to(dev), dy.to(dev), (k, k, Cin, Cout), 1, padding, dw=dw.clone(), accumulate=True, multiplier=0.5)
+    torch.cuda.synchronize()
+    err = float((dw2.cpu() - 1.5 * ref).abs().max()) / float(ref.abs().max())
+    assert err <= 3e-4
+
+
 def test_casts(dev):
     ops = _ops()
     x = torch.randn(100003, device=dev) * 3

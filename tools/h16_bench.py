@@ -23,3 +23,13 @@ for dtype in (torch.float16, torch.bfloat16):
     ms = e0.elapsed_time(e1) / 20
     fl = 2.0 * N * 196 * 256 * 2304
     print("%s fwd N=%d: %.3f ms  %.1f TFLOP/s" % (dtype, N, ms, fl / ms / 1e9))
+    dy = torch.randn(N, 14, 14, 256, device=dev).to(dtype)
+    dw = torch.empty(3, 3, 256, 256, device=dev)
+    for _ in range(3):
+        ops.conv2d_wgrad_h16(x, dy, (3, 3, 256, 256), 1, "same", dw=dw)
+    e0.record()
+    for _ in range(20):
+        ops.conv2d_wgrad_h16(x, dy, (3, 3, 256, 256), 1, "same", dw=dw)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    print("%s wgrad N=%d: %.3f ms  %.1f TFLOP/s (incl. table + slab reduce)" % (dtype, N, ms, fl / ms / 1e9))
