@@ -147,7 +147,18 @@ def measure(args, backbone, nimg, rank, local_rank, world, full):
     else:
         step()
         dt_sparse, _ = timed(args.steps)
+    # configs[4], stage 1 (NOT the headline: reduced precision): the four mask-head convolutions on the fp16 MFMA,
+    # every row computed as in the headline leg
+    dt_h16 = float("nan")
+    if not args.dense_only:
+        import torch as _t
+        eng.sparse_mask_bwd, eng.head_dtype = False, _t.float16
+        step()
+        step()
+        dt_h16, _ = timed(args.steps)
+        eng.sparse_mask_bwd, eng.head_dtype = True, None
     res = {"backbone": backbone, "nimg": nimg, "ms_per_step": dt / args.steps * 1e3,
+           "images_per_s_f16_mask_head": None if args.dense_only else nimg * world * args.steps / dt_h16,
            "images_per_s": nimg * world * args.steps / dt,
            "images_per_s_sparse": None if args.dense_only else nimg * world * args.steps / dt_sparse,
            "losses": [float(v) for v in losses.cpu().numpy()]}
@@ -264,6 +275,10 @@ def main():
                                     "gradient (identical losses and gradients, "
                                     "tests/test_engine_gpu.py::test_sparse_mask_backward_equals_dense); product default, "
                                     "never the headline value",
+            "value_f16_mask_head": None if args.dense_only else round(r["images_per_s_f16_mask_head"], 3),
+            "note_f16_mask_head": "BASELINE configs[4], stage 1: the headline (dense) step with the four 3x3 mask-head convolutions "
+                                  "(forward, data and weight gradient) on the fp16 matrix cores, float32 master weights / "
+                                  "accumulation / gradients, loss scale 4096; reduced precision, never the headline value",
             "losses_last_step": [round(v, 5) for v in r["losses"]],
             "roofline": r["roofline"],
         }

@@ -209,13 +209,76 @@ __global__ void weights_to_h16_kernel(const float* __restrict__ w, T* wt_f, T* w
 }
 
 template <typename T>
-__global__ void cast_to_h16_kernel(const float* __restrict__ src, T* dst, long long n) {
+__global__ void cast_to_h16_kernel(const float* __restrict__ src, T* dst, long long n, float mul) {
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {
         const f32x4 v = *(const f32x4*)(src + i);
-        dst[i] = (T)v[0]; dst[i + 1] = (T)v[1]; dst[i + 2] = (T)v[2]; dst[i + 3] = (T)v[3];
+        dst[i] = (T)(v[0] * mul); dst[i + 1] = (T)(v[1] * mul); dst[i + 2] = (T)(v[2] * mul); dst[i + 3] = (T)(v[3] * mul);
     } else {
-        for (long long j = i; j < n; ++j) dst[j] = (T)src[j];
+        for (long long j = i; j < n; ++j) dst[j] = (T)(src[j] * mul);
+    }
+}
+
+// Backward of  out = act(scale * (conv + bias) + shift)  on 16-bit tensors (mrcnn_epilogue_bwd in 16 bits): reads the
+// upstream gradient, the activated output and the pre-BN value z, writes dz (16 bit) and accumulates the channel sums
+// dgamma / dbeta / dbias in float32, multiplied by `gmul` (1 / loss scale) -- dz itself stays scaled.
+template <typename T>
+__global__ __launch_bounds__(256) void epilogue_bwd_h16_kernel(const T* __restrict__ dout, const T* __restrict__ out,
+                                                               const T* __restrict__ z, const float* __restrict__ scale,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               T* dz_out, float* dgamma, float* dbeta, float* dbias, long long M,
+                                                               int C, int act, long long rows_per_block, float gmul) {
+    extern __shared__ float sacc[];   // [3][C]
+    for (int c = threadIdx.x; c < 3 * C; c += 256) sacc[c] = 0.f;
+    __syncthreads();
+    const int c4n = C >> 2;
+    const int L = c4n < 256 ? c4n : 256;
+    const int R = 256 / L;
+    const int rsub = threadIdx.x / L, lane = threadIdx.x % L;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    for (int cg = lane; cg < c4n; cg += L) {
+        const int c = cg * 4;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, mu = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+        if (scale) sc = *(const f32x4*)(scale + c);
+        if (dgamma) { mu = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c); }
+        f32x4 a_db = {0.f, 0.f, 0.f, 0.f}, a_dg = a_db, a_bias = a_db;
+        for (long long r = r0 + rsub; r < r1; r += R) {
+            const long long e = r * C + c;
+            const t4 gv = *(const t4*)(dout + e);
+            f32x4 g = {(float)gv[0], (float)gv[1], (float)gv[2], (float)gv[3]};
+            if (act == MRCNN_ACT_RELU) {
+                const t4 o = *(const t4*)(out + e);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = (float)o[k] > 0.f ? g[k] : 0.f;
+            }
+            t4 dzv;
+            f32x4 dz;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { dz[k] = g[k] * sc[k]; dzv[k] = (T)dz[k]; }
+            *(t4*)(dz_out + e) = dzv;
+            if (dgamma) {
+                const t4 zz = *(const t4*)(z + e);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a_dg[k] += g[k] * ((float)zz[k] - mu[k]) * rs[k];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { a_db[k] += g[k]; a_bias[k] += dz[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (dbeta || dgamma) atomicAdd(&sacc[c + k], a_db[k]);
+            if (dgamma) atomicAdd(&sacc[C + c + k], a_dg[k]);
+            if (dbias) atomicAdd(&sacc[2 * C + c + k], a_bias[k]);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        if (dbeta) atomicAdd(&dbeta[c], sacc[c] * gmul);
+        if (dgamma) atomicAdd(&dgamma[c], sacc[C + c] * gmul);
+        if (dbias) atomicAdd(&dbias[c], sacc[2 * C + c] * gmul);
     }
 }
 
@@ -531,15 +594,38 @@ extern "C" int mrcnn_weights_to_h16(const float* w, void* wt_fwd, void* wt_dgrad
     return mrcnn_launch_status();
 }
 
-extern "C" int mrcnn_cast_to_h16(const float* src, void* dst, int64_t n, int dtype, void* stream) {
+extern "C" int mrcnn_epilogue_bwd_h16(int dtype, const void* dout, const void* out, const void* z, const float* scale,
+                                      const float* mean, const float* rstd, void* dz_out, float* dgamma, float* dbeta,
+                                      float* dbias, int64_t M, int C, int act, float grad_multiplier, void* stream) {
+    if (!dout || !dz_out || M <= 0 || C < 16 || C > 4096 || (C & (C - 1)) || !h16_dtype_ok(dtype)) return MRCNN_ERR_ARG;
+    if ((act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) || (act == MRCNN_ACT_RELU && !out)) return MRCNN_ERR_ARG;
+    if (dgamma && (!z || !mean || !rstd)) return MRCNN_ERR_ARG;
+    long long rows_per_block = cdiv64(M, 2048);
+    const long long min_rows = cdiv64(4096, C);
+    if (rows_per_block < min_rows) rows_per_block = min_rows;
+    const unsigned grid = (unsigned)cdiv64(M, rows_per_block);
+    if (dtype == MRCNN_DTYPE_F16)
+        hipLaunchKernelGGL(epilogue_bwd_h16_kernel<_Float16>, dim3(grid), dim3(256), 3 * C * sizeof(float), (hipStream_t)stream,
+                           (const _Float16*)dout, (const _Float16*)out, (const _Float16*)z, scale, mean, rstd, (_Float16*)dz_out,
+                           dgamma, dbeta, dbias, (long long)M, C, act, rows_per_block, grad_multiplier);
+    else
+        hipLaunchKernelGGL(epilogue_bwd_h16_kernel<__bf16>, dim3(grid), dim3(256), 3 * C * sizeof(float), (hipStream_t)stream,
+                           (const __bf16*)dout, (const __bf16*)out, (const __bf16*)z, scale, mean, rstd, (__bf16*)dz_out, dgamma,
+                           dbeta, dbias, (long long)M, C, act, rows_per_block, grad_multiplier);
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_cast_to_h16(const float* src, void* dst, int64_t n, int dtype, float multiplier, void* stream) {
     if (!src || !dst || n < 0 || !h16_dtype_ok(dtype)) return MRCNN_ERR_ARG;
     if (n == 0) return 0;
     if (reinterpret_cast<uintptr_t>(src) & 15) return MRCNN_ERR_ARG;
     const unsigned blocks = (unsigned)cdiv64(cdiv64(n, 4), 256);
     if (dtype == MRCNN_DTYPE_F16)
-        hipLaunchKernelGGL(cast_to_h16_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst, (long long)n);
+        hipLaunchKernelGGL(cast_to_h16_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (_Float16*)dst,
+                           (long long)n, multiplier);
     else
-        hipLaunchKernelGGL(cast_to_h16_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst, (long long)n);
+        hipLaunchKernelGGL(cast_to_h16_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, (__bf16*)dst,
+                           (long long)n, multiplier);
     return mrcnn_launch_status();
 }
 

@@ -179,6 +179,13 @@ class MaskRCNNEngine(object):
                             2: (s2, s3), "head": (0, s2), "bn": (L.gamma_offset, L.total)}
         self.grad_ready = None          # callable(start, end) or None
         self.sparse_mask_bwd = True     # skip the exactly-zero rows of the mask-head backward
+        # BASELINE configs[4], stage 1: torch.float16 / torch.bfloat16 runs the four 3x3 convolutions of the mask head
+        # (forward, data and weight gradient) on the 16-bit matrix cores; master weights, accumulation and every
+        # gradient buffer stay float32.  None (default) = float32 everywhere.  loss_scale guards float16 gradients.
+        self.head_dtype = None
+        self.loss_scale = 4096.0
+        self._h16 = {}
+        self._h16_valid = False
         self.fused_mask_out_bwd = True  # single-pass backward of the mask-head output stage
         self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self.aux_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
@@ -204,6 +211,29 @@ class MaskRCNNEngine(object):
         dz.record_stream(ws)
         x.record_stream(ws)
 
+    def wgrad_h16_async(self, x, dz, wshape, dw, multiplier):
+        ws = self.wgrad_stream
+        if ws is None:
+            ops.conv2d_wgrad_h16(x, dz, wshape, 1, "same", dw=dw, multiplier=multiplier)
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(ws):
+            ws.wait_event(ev)
+            ops.conv2d_wgrad_h16(x, dz, wshape, 1, "same", dw=dw, multiplier=multiplier)
+        dz.record_stream(ws)
+        x.record_stream(ws)
+
+    def _ensure_h16(self):
+        """16-bit operand images (W^T and the rotated data-gradient image) of the mask-head convolutions."""
+        if self._h16_valid and self._h16.get("dtype") == self.head_dtype:
+            return
+        self._h16 = {"dtype": self.head_dtype}
+        for i in range(1, 5):
+            op = self.op("mrcnn_mask_conv%d" % i)
+            self._h16[op.name] = ops.weights_to_h16(op.w, self.head_dtype)
+        self._h16_valid = True
+
     def join_wgrad(self):
         if self.wgrad_stream is not None:
             torch.cuda.current_stream(self.dev).wait_stream(self.wgrad_stream)
@@ -217,6 +247,7 @@ class MaskRCNNEngine(object):
     def set_weights(self, weights, strict=True):
         L = self.layout
         self.wt_valid = False
+        self._h16_valid = False
         for name, (off, n, shape) in L.offsets.items():
             if name not in weights:
                 if strict:
@@ -356,9 +387,20 @@ class MaskRCNNEngine(object):
         pooled = ops.roialign(rois, fms, cfg.MASK_POOL_SIZE, image_area)
         x = pooled.view(B * R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1)
         ctxs = []
-        for i in range(1, 5):
-            x, c = self.op("mrcnn_mask_conv%d" % i).forward(x, ACT_RELU, train=train)
-            ctxs.append(c)
+        if self.head_dtype is None:
+            for i in range(1, 5):
+                x, c = self.op("mrcnn_mask_conv%d" % i).forward(x, ACT_RELU, train=train)
+                ctxs.append(c)
+        else:                                   # 16-bit matrix cores; float32 again from the deconvolution on
+            self._ensure_h16()
+            h = ops.cast_to_h16(x, self.head_dtype)
+            for i in range(1, 5):
+                op = self.op("mrcnn_mask_conv%d" % i)
+                z = ops.empty(tuple(h.shape[:3]) + (op.wshape[3],), self.head_dtype, self.dev) if (train and op.bn) else None
+                y = ops.conv2d_h16(h, self._h16[op.name][0], op.wshape, op.b, op.scale, op.shift, 1, "same", ACT_RELU, z_out=z)
+                ctxs.append((h, z, y, ACT_RELU) if train else None)
+                h = y
+            x = ops.cast_from_h16(h)
         dc = self.op("mrcnn_mask_deconv")
         up = ops.deconv2x2(x, dc.w.view(dc.wshape[2], dc.wshape[3]), dc.b, ACT_RELU)
         m, cm = self.op("mrcnn_mask").forward(up, ACT_SIGMOID, train=train)
@@ -561,11 +603,24 @@ class MaskRCNNEngine(object):
         if not self.wt_valid:
             ops.weight_flip_transpose(dc.w, dc.wt)
         d = ops.conv2d(dzg, dc.wt, stride=1, padding="valid")
-        for i, c in ((4, c4), (3, c3), (2, c2), (1, c1)):
-            op = self.op("mrcnn_mask_conv%d" % i)
-            dz, _ = op.epilogue_bwd(d, c)
-            op.wgrad(dz, c, accumulate=acc)
-            d = op.dgrad(dz, c)
+        if self.head_dtype is None:
+            for i, c in ((4, c4), (3, c3), (2, c2), (1, c1)):
+                op = self.op("mrcnn_mask_conv%d" % i)
+                dz, _ = op.epilogue_bwd(d, c)
+                op.wgrad(dz, c, accumulate=acc)
+                d = op.dgrad(dz, c)
+        else:
+            S = float(self.loss_scale) if self.head_dtype == torch.float16 else 1.0
+            d16 = ops.cast_to_h16(d, self.head_dtype, multiplier=S)
+            for i, c in ((4, c4), (3, c3), (2, c2), (1, c1)):
+                op = self.op("mrcnn_mask_conv%d" % i)
+                kh, kw, cin, cout = op.wshape
+                xin, z, y, _ = c
+                dz = ops.epilogue_bwd_h16(d16, y, z, op.scale, op.mean, op.rstd, op.dgamma, op.dbeta, op.db, ACT_RELU, 1.0 / S)
+                self.wgrad_h16_async(xin, dz, op.wshape, op.dw, 1.0 / S)
+                d16 = ops.conv2d_h16(dz, self._h16[op.name][1], (kh, kw, cout, cin), None, None, None, 1,
+                                     ((kh - 1) // 2, (kw - 1) // 2), ACT_NONE)
+            d = ops.cast_from_h16(d16, 1.0 / S)
         B, R = rois.shape[0], rois.shape[1]
         ops.roialign_bwd(rois, d.view(B, R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1), dP, cfg.MASK_POOL_SIZE, area)
 
@@ -692,4 +747,5 @@ class MaskRCNNEngine(object):
         ops.sgd_momentum(self.params, self.momentum, self.grads, self.sumsq, cfg.GRADIENT_CLIP_NORM, learning_rate,
                          momentum, self.gran_coef)
         self.wt_valid = False
+        self._h16_valid = False
         self.fold_bn()

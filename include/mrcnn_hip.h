@@ -200,7 +200,12 @@ int mrcnn_weights_to_h16(const float* w_hwio, void* wt_fwd, void* wt_dgrad, int 
 size_t mrcnn_conv2d_wgrad_h16_workspace(const mrcnn_conv_desc* d);
 int mrcnn_conv2d_wgrad_h16(const mrcnn_conv_desc* d, int dtype, const void* x, const void* dy, float* dw,
                            void* workspace, size_t workspace_bytes, int beta_acc, float multiplier, void* stream);
-int mrcnn_cast_to_h16(const float* src, void* dst, int64_t n, int dtype, void* stream);
+/* mrcnn_epilogue_bwd on 16-bit tensors (act NONE / RELU, C a power of two >= 16): dz_out 16 bit; the float32 channel
+ * sums dgamma / dbeta / dbias are multiplied by grad_multiplier (1 / loss scale) before they are added.          */
+int mrcnn_epilogue_bwd_h16(int dtype, const void* dout, const void* out, const void* z, const float* scale,
+                           const float* mean, const float* rstd, void* dz_out, float* dgamma, float* dbeta,
+                           float* dbias, int64_t M, int C, int act, float grad_multiplier, void* stream);
+int mrcnn_cast_to_h16(const float* src, void* dst, int64_t n, int dtype, float multiplier, void* stream);
 int mrcnn_cast_from_h16(const void* src, float* dst, int64_t n, int dtype, float multiplier, void* stream);
 
 /* build_rpn_targets (mrcnn/model.py:1536-1644), the per-image RPN target builder of the CPU input

@@ -118,3 +118,35 @@ def test_casts(dev):
         h = ops.cast_to_h16(x, dtype)
         assert torch.equal(h, x.to(dtype))
         assert torch.equal(ops.cast_from_h16(h, 0.5), h.float() * 0.5)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_mixed_precision_mask_head_training_step(dev, dtype):
+    """engine.head_dtype: the four mask-head convolutions on the 16-bit matrix cores (forward, data and weight
+    gradient), everything else float32.  Against the all-float32 engine on the same batch: losses to 1e-2, every
+    gradient tensor to 4e-2 of its float32 maximum (f16: 11-bit operands; bf16: 8-bit operands), and the
+    gradients of the layers that never see 16-bit data through the mask branch only via the pyramid sum."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_engine_gpu as T
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = T._small_cfg("custom", 128)
+    w = T._weights(cfg, 31)
+    inputs, keys = T._train_inputs(cfg, 2, 33)
+    res = {}
+    for mode in (None, dtype):
+        model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+        model.engine.head_dtype = mode
+        losses = model.train_on_batch(inputs, rand_keys=keys, apply=False)
+        torch.cuda.synchronize()
+        res[mode] = (losses.cpu().numpy(), model.engine.get_weights(grads=True))
+    tol = 1e-2 if dtype == torch.float16 else 4e-2
+    np.testing.assert_allclose(res[dtype][0], res[None][0], rtol=tol)
+    bad = []
+    for name, ref in res[None][1].items():
+        scale = max(float(np.abs(ref).max()), 1e-10)
+        err = float(np.abs(res[dtype][1][name] - ref).max()) / scale
+        if err > 4 * tol:
+            bad.append((name, err))
+    assert not bad, bad[:6]
+    g = res[dtype][1]["mrcnn_mask_conv2/kernel"]
+    assert np.abs(g).max() > 0 and np.isfinite(g).all()
