@@ -78,7 +78,13 @@ class MaskRCNN(object):
                                         "there is no CPU execution path")
             device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
             torch.cuda.set_device(device)
-        return MaskRCNNEngine(config, device, weights=weights, seed=seed)
+        eng = MaskRCNNEngine(config, device, weights=weights, seed=seed)
+        hd = getattr(config, "HEAD_DTYPE", None)
+        if hd is not None:
+            assert hd in ("float16", "bfloat16"), "HEAD_DTYPE must be None, 'float16' or 'bfloat16'"
+            eng.head_dtype = getattr(torch, hd)
+            eng.loss_scale = float(getattr(config, "HEAD_LOSS_SCALE", 4096.0))
+        return eng
 
     # ---- checkpoints ------------------------------------------------------------------------------
     def find_last(self):

@@ -72,6 +72,7 @@ def parse_args(argv=None):
                    choices=['binary_crossentropy', 'dice_coef_loss'])
     p.add_argument('--weight_classes', action='store_true', default=False)
     p.add_argument('--exclude_first_layer_weights', action='store_true', default=False)
+    p.add_argument('--head_dtype', type=str, default="", help="extension: float16 | bfloat16 mask-head convolutions")
     p.add_argument('--no_augmentation', dest='use_augmentation', action='store_false', default=True)
     p.add_argument('--scoreThr', type=float, default=0.7)
     p.add_argument('--iouThr', type=float, default=0.6)
@@ -122,6 +123,7 @@ def build_config(args, class_dict_model):
     cfg.IMG_XMIN, cfg.IMG_XMAX, cfg.IMG_YMIN, cfg.IMG_YMAX = args.xmin, args.xmax, args.ymin, args.ymax
     cfg.SPLIT_IMG_IN_TILES = args.split_img_in_tiles
     cfg.TILE_XSIZE, cfg.TILE_YSIZE, cfg.TILE_XSTEP, cfg.TILE_YSTEP = args.tile_xsize, args.tile_ysize, args.tile_xstep, args.tile_ystep
+    cfg.HEAD_DTYPE = args.head_dtype or None
     return cfg
 
 
