@@ -103,8 +103,10 @@ def measure(args, backbone, nimg, rank, local_rank, world, full):
     dev = torch.device("cuda", local_rank)
     cfg = run_py_config(num_classes=4, imgsize=args.imgsize, backbone=backbone, images_per_gpu=nimg,
                         gpu_count=world)
-    model = MaskRCNN("training", cfg, "/tmp/mrcnn_bench_logs", device=dev, seed=0)
-    model.compile(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):          # stdout carries the ONE JSON line only
+        model = MaskRCNN("training", cfg, "/tmp/mrcnn_bench_logs", device=dev, seed=0)
+        model.compile(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM)
     batch = synthetic_batch(cfg, nimg, seed=1234 + rank)
     dev_inputs = model._to_device(batch)
     eng = model.engine
