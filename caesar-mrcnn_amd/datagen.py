@@ -162,3 +162,69 @@ def data_generator(dataset, config, shuffle=True, augment=False, augmentation=No
             error_count += 1
             if error_count > 5:
                 raise
+
+
+class Prefetcher(object):
+    """Background producer threads in front of one or more batch generators (the reference hands its generator
+    to Keras ``fit_generator(workers=n, max_queue_size=100)``, model.py:2497-2510).  Worker k advances its own
+    generator and the batches are handed out in arrival order; with a single worker the order is the generator's.
+    Threads, not processes: the loaders are NumPy / file I/O (which release the GIL for the heavy parts) and a
+    process that has initialised the GPU must neither fork-and-exec nor share its HIP context with children."""
+
+    _END = object()
+
+    def __init__(self, generators, depth=8):
+        import queue
+        import threading
+        self._q = queue.Queue(maxsize=max(1, int(depth)))
+        self._stop = threading.Event()
+        self._threads = []
+        self._alive = len(generators)
+        self._lock = threading.Lock()
+        for g in generators:
+            t = threading.Thread(target=self._run, args=(g,), daemon=True)
+            t.start()
+            self._threads.append(t)
+
+    def _put(self, item):
+        import queue
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _run(self, gen):
+        try:
+            for item in gen:
+                if not self._put(item):
+                    return
+        except BaseException as e:                   # handed to the consumer, raised by __next__
+            self._put(e)
+            return
+        finally:
+            with self._lock:
+                self._alive -= 1
+                last = self._alive == 0
+            if last:
+                self._put(self._END)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self._q.get()
+        if item is self._END:
+            self._q.put(item)
+            raise StopIteration
+        if isinstance(item, BaseException):
+            self.close()
+            raise item
+        return item
+
+    def close(self):
+        self._stop.set()
+        for t in self._threads:
+            t.join(timeout=2.0)

@@ -236,13 +236,18 @@ class MaskRCNN(object):
         from .parallel import GradReducer, allreduce_mean_scalars, init_distributed
         rank, _, world = init_distributed()
         cfg = self.config
-        train_gen = data_generator(train_dataset, cfg, shuffle=True, augmentation=augmentation,
-                                   batch_size=cfg.IMAGES_PER_GPU, no_augmentation_sources=no_augmentation_sources,
-                                   rank=rank, world_size=world, seed=1234,
-                                   device_targets=bool(getattr(cfg, "DEVICE_RPN_TARGETS", False)))
-        val_gen = data_generator(val_dataset, cfg, shuffle=True, batch_size=cfg.IMAGES_PER_GPU, rank=rank,
-                                 world_size=world, seed=4321,
-                                 device_targets=bool(getattr(cfg, "DEVICE_RPN_TARGETS", False)))
+        # n_worker_threads loader threads (<= 0: one per host core, at most 8) prefetch batches while the GPU works
+        # (fit_generator(workers=..., max_queue_size=100), model.py:2497-2510); worker 0 walks the data like the
+        # unthreaded generator, further workers use their own shuffles
+        from .datagen import Prefetcher
+        nw = int(n_worker_threads) if n_worker_threads and n_worker_threads > 0 else min(8, os.cpu_count() or 1)
+        dev_t = bool(getattr(cfg, "DEVICE_RPN_TARGETS", False))
+        train_gen = Prefetcher([data_generator(train_dataset, cfg, shuffle=True, augmentation=augmentation,
+                                               batch_size=cfg.IMAGES_PER_GPU, no_augmentation_sources=no_augmentation_sources,
+                                               rank=rank, world_size=world, seed=1234 + 1000 * k, device_targets=dev_t)
+                                for k in range(nw)], depth=2 * nw + 2)
+        val_gen = Prefetcher([data_generator(val_dataset, cfg, shuffle=True, batch_size=cfg.IMAGES_PER_GPU, rank=rank,
+                                             world_size=world, seed=4321, device_targets=dev_t)], depth=2)
         if rank == 0 and not os.path.exists(self.log_dir):
             os.makedirs(self.log_dir)
         log("\nStarting at epoch {}. LR={}\n".format(self.epoch, learning_rate))
@@ -275,6 +280,8 @@ class MaskRCNN(object):
                     if callable(cb):
                         cb(epoch, dict(zip(names, tr.tolist())))
         self.epoch = max(self.epoch, epochs)
+        train_gen.close()
+        val_gen.close()
 
     # ---- inference ------------------------------------------------------------------------------------
     def mold_inputs(self, images):

@@ -309,3 +309,35 @@ def test_keras_h5_weights_roundtrip_and_by_name_semantics(tmp_path):
     bad.write_bytes(b"not an hdf5 file at all")
     with pytest.raises(ValueError):
         hdf5_min.H5File(str(bad))
+
+
+def test_prefetcher_order_errors_and_shutdown():
+    """Loader threads in front of the batch generators (fit_generator(workers=...), model.py:2497-2510)."""
+    import itertools
+    import time
+    from caesar_mrcnn_amd.datagen import Prefetcher
+
+    def gen(k, n=None, fail_at=None):
+        for i in itertools.count():
+            if n is not None and i >= n:
+                return
+            if fail_at is not None and i == fail_at:
+                raise ValueError("boom %d" % k)
+            time.sleep(0.001)
+            yield (k, i)
+
+    p = Prefetcher([gen(0)], depth=3)
+    assert [next(p) for _ in range(20)] == [(0, i) for i in range(20)]         # one worker: the generator's order
+    p.close()
+    p = Prefetcher([gen(k) for k in range(3)], depth=4)
+    got = [next(p) for _ in range(60)]
+    for k in range(3):
+        mine = [i for kk, i in got if kk == k]
+        assert mine == list(range(len(mine))) and len(mine) > 0                # every worker's own order is kept
+    p.close()
+    p = Prefetcher([gen(0, n=5), gen(1, n=3)], depth=2)
+    assert sorted(p) == [(0, 0), (0, 1), (0, 2), (0, 3), (0, 4), (1, 0), (1, 1), (1, 2)]   # finite generators end the stream
+    p = Prefetcher([gen(7, fail_at=2)], depth=2)
+    assert next(p) == (7, 0) and next(p) == (7, 1)
+    with pytest.raises(ValueError, match="boom 7"):
+        next(p)
