@@ -77,3 +77,32 @@ static inline FastDiv make_fastdiv(unsigned d) {
     return f;
 }
 __device__ __forceinline__ unsigned fast_div(unsigned n, const FastDiv& f) { return (__umulhi(n, f.mul) + n) >> f.shift; }
+
+// Per-output-pixel addressing table of the weight-gradient kernels: byte offset of input pixel
+// (n, oh*stride - pad_t, ow*stride - pad_l) from the (shifted) tensor base and the validity mask of the
+// KH*KW filter taps (<= 64).  Rows past M carry an out-of-range offset and an empty mask.  Built once per call,
+// it takes the two divisions per pixel out of the kernels' loops.
+#define PIXEL_TABLE_OOB 0x80000000u
+struct PixelEntry { unsigned off, mask_lo, mask_hi, pad; };
+
+static __global__ void pixel_table_kernel(PixelEntry* table, int N, int H, int W, int Cin, int KH, int KW, int stride, int pad_t,
+                                          int pad_l, int OH, int OW, int M, int rows, unsigned x_shift, int esize) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= rows) return;
+    PixelEntry e;
+    e.off = PIXEL_TABLE_OOB; e.mask_lo = 0u; e.mask_hi = 0u; e.pad = 0u;
+    if (m < M) {
+        const int ohw = OH * OW;
+        const int n = m / ohw, rem = m - n * ohw;
+        const int oh = rem / OW, ow = rem - oh * OW;
+        const int ih0 = oh * stride - pad_t, iw0 = ow * stride - pad_l;
+        e.off = (unsigned)((((long long)n * H + ih0) * W + iw0) * Cin * esize + x_shift);
+        unsigned long long mk = 0ull;
+        for (int t = 0; t < KH * KW; ++t) {
+            const int th = t / KW, tw = t - th * KW;
+            if ((unsigned)(ih0 + th) < (unsigned)H && (unsigned)(iw0 + tw) < (unsigned)W) mk |= 1ull << t;
+        }
+        e.mask_lo = (unsigned)mk; e.mask_hi = (unsigned)(mk >> 32);
+    }
+    table[m] = e;
+}

@@ -302,31 +302,7 @@ __global__ void cast_from_h16_kernel(const T* __restrict__ src, float* dst, long
 // (pixel_table_kernel): 16 bytes per pixel, prefetched one step ahead -- no divisions in the loop.
 typedef short s16x4 __attribute__((__vector_size__(4 * sizeof(short))));
 typedef __attribute__((address_space(3))) s16x4* h16_tr_ptr;
-#define H16_WG_OOB 0x80000000u
-
-struct PixelEntry { unsigned off, mask_lo, mask_hi, pad; };
-
-__global__ void pixel_table_kernel(PixelEntry* table, int N, int H, int W, int Cin, int KH, int KW, int stride, int pad_t,
-                                   int pad_l, int OH, int OW, int M, int rows, unsigned x_shift) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= rows) return;
-    PixelEntry e;
-    e.off = H16_WG_OOB; e.mask_lo = 0u; e.mask_hi = 0u; e.pad = 0u;
-    if (m < M) {
-        const int ohw = OH * OW;
-        const int n = m / ohw, rem = m - n * ohw;
-        const int oh = rem / OW, ow = rem - oh * OW;
-        const int ih0 = oh * stride - pad_t, iw0 = ow * stride - pad_l;
-        e.off = (unsigned)((((long long)n * H + ih0) * W + iw0) * Cin * 2 + x_shift);
-        unsigned long long mk = 0ull;
-        for (int t = 0; t < KH * KW; ++t) {
-            const int th = t / KW, tw = t - th * KW;
-            if ((unsigned)(ih0 + th) < (unsigned)H && (unsigned)(iw0 + tw) < (unsigned)W) mk |= 1ull << t;
-        }
-        e.mask_lo = (unsigned)mk; e.mask_hi = (unsigned)(mk >> 32);
-    }
-    table[m] = e;
-}
+#define H16_WG_OOB PIXEL_TABLE_OOB
 
 struct WgradH16Args {
     const void* x; const void* dy; float* out; const PixelEntry* table;
@@ -534,7 +510,7 @@ extern "C" int mrcnn_conv2d_wgrad_h16(const mrcnn_conv_desc* d, int dtype, const
     hipStream_t s = (hipStream_t)stream;
     const int rows = (int)M + 32;
     hipLaunchKernelGGL(pixel_table_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, table, d->N, d->H, d->W, d->Cin,
-                       d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->OH, d->OW, (int)M, rows, (unsigned)shift_b);
+                       d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->OH, d->OW, (int)M, rows, (unsigned)shift_b, 2);
     WgradH16Args a;
     a.x = x; a.dy = dy; a.out = slabs; a.table = table;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.OH = d->OH; a.OW = d->OW;

@@ -16,6 +16,7 @@ struct WgradArgs {
     int N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW;
     int M, Ktot, fast, splits, chunk, acc;
     FastDiv d_ohw, d_ow;
+    const PixelEntry* table;      // large layers: per-pixel offsets / tap masks (conv_wgrad_blds_kernel<.., true>)
 };
 
 template <int BI, int BN, int WM, int WN>
@@ -300,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_glds_kernel(const WgradArgs
 typedef __attribute__((address_space(3))) void* wgrad_lds_ptr;
 #define WGRAD_OOB_OFFSET 0x80000000u
 
-template <int BP>
+template <int BP, bool TABLE>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_blds_kernel(const WgradArgs p, const unsigned x_shift, const unsigned x_records) {
     constexpr int BI = 128, BN = 128, TM = 2, TN = 2;
     constexpr int XF = BP * BI, YF = BP * BN;
@@ -328,11 +329,31 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_blds_kernel(const WgradArgs
     const bool upper = lane >= 32;
     const unsigned y_voff = (unsigned)(((lane >> 5) * p.Cout + (lane & 31) * 4) * 4);
 
+    // TABLE (layers with many pixels): the row offsets and tap masks come from a table built once per call and are
+    // prefetched one step ahead -- nothing but a bit test is left per piece; otherwise the decomposition runs on the
+    // scalar unit (no extra launch for the many small layers).
+    const unsigned soff_tab = (unsigned)(((kh * p.W + kw) * p.Cin + ci0) * 4);
+    const unsigned tapbit = 1u << (tap & 31);
+    const bool tap_hi = tap >= 32;
+    const PixelEntry* tab = TABLE ? p.table + (lane >> 5) : nullptr;
+    PixelEntry ent[NP / 4];
+    auto fetch = [&](int mb) {
+        if constexpr (TABLE) {
+#pragma unroll
+            for (int jj = 0; jj < NP / 4; ++jj) ent[jj] = tab[mb + 2 * (wave + jj * 4)];
+        }
+    };
     auto stage = [&](float* xb, int mb) {
         float* yb = xb + XF;
 #pragma unroll
         for (int jj = 0; jj < NP / 4; ++jj) {
             const int j = wave + jj * 4;
+            if constexpr (TABLE) {
+                const unsigned word = tap_hi ? ent[jj].mask_hi : ent[jj].mask_lo;
+                const unsigned vo = ((word & tapbit) ? ent[jj].off : WGRAD_OOB_OFFSET) + lane_chan;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (wgrad_lds_ptr)(xb + j * 256), 16, vo, soff_tab, 0, 0);
+                continue;
+            }
             unsigned off[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {                       // wave-uniform: scalar unit
@@ -387,14 +408,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_blds_kernel(const WgradArgs
     };
 
     if (m_begin < m_end) {
+        fetch(m_begin);
         stage(lds, m_begin);
+        if (m_begin + BP < m_end) fetch(m_begin + BP);
         __syncthreads();
         for (int mb = m_begin; mb < m_end; mb += 2 * BP) {
-            if (mb + BP < m_end) stage(lds + (XF + YF), mb + BP);
+            if (mb + BP < m_end) { stage(lds + (XF + YF), mb + BP); if (mb + 2 * BP < m_end) fetch(mb + 2 * BP); }
             compute(std::integral_constant<int, 0>{});
             __syncthreads();
             if (mb + BP < m_end) {
-                if (mb + 2 * BP < m_end) stage(lds, mb + 2 * BP);
+                if (mb + 2 * BP < m_end) { stage(lds, mb + 2 * BP); if (mb + 3 * BP < m_end) fetch(mb + 3 * BP); }
                 compute(std::integral_constant<int, 1>{});
                 __syncthreads();
             }
@@ -450,11 +473,19 @@ static WgradPlan plan_wgrad(const mrcnn_conv_desc* d) {
     return pl;
 }
 
+// layers with at least this many output pixels address X through the pixel table (one extra tiny launch)
+#define WGRAD_TABLE_MIN_PIXELS 65536
+static size_t wgrad_table_bytes(const mrcnn_conv_desc* d) {
+    const long long M = (long long)d->N * d->OH * d->OW;
+    const bool lds_dma = d->Cin % 128 == 0 && d->Cout % 128 == 0 && d->KH * d->KW <= 64;
+    return (lds_dma && M >= WGRAD_TABLE_MIN_PIXELS) ? (size_t)(M + WGRAD_BP) * sizeof(PixelEntry) + 256 : 0;
+}
+
 extern "C" size_t mrcnn_conv2d_wgrad_workspace(const mrcnn_conv_desc* d) {
     if (!d || d->N <= 0 || d->Cin <= 0 || d->Cout <= 0) return 0;
     WgradPlan pl = plan_wgrad(d);
-    if (pl.splits <= 1) return 0;
-    return (size_t)pl.splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
+    const size_t slabs = pl.splits > 1 ? (size_t)pl.splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float) : 0;
+    return slabs + wgrad_table_bytes(d);
 }
 
 template <int BI, int BN, int WM, int WN>
@@ -473,7 +504,8 @@ extern "C" int mrcnn_conv2d_wgrad(const mrcnn_conv_desc* d, const float* x, cons
     if (M >= (1LL << 31)) return MRCNN_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(dy) & 15)) return MRCNN_ERR_ARG;
     WgradPlan pl = plan_wgrad(d);
-    if (pl.splits > 1 && (!workspace || workspace_bytes < mrcnn_conv2d_wgrad_workspace(d))) return MRCNN_ERR_WORKSPACE;
+    const size_t slab_bytes = pl.splits > 1 ? (size_t)pl.splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float) : 0;
+    if (pl.splits > 1 && (!workspace || workspace_bytes < slab_bytes)) return MRCNN_ERR_WORKSPACE;
     WgradArgs a;
     a.x = x; a.dy = dy; a.out = pl.splits > 1 ? workspace : dw;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
@@ -488,9 +520,23 @@ extern "C" int mrcnn_conv2d_wgrad(const mrcnn_conv_desc* d, const float* x, cons
         const long long shift = ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
         const long long ybytes = M * d->Cout * 4;
         // + 16 pixel rows: offsets of rows past the tensor must not wrap before the range check sees them
-        if (xbytes + shift + 16LL * d->H * d->W * d->Cin * 4 < 0x7FFFFFF0LL && ybytes < 0x7FFFFFF0LL && !getenv("MRCNN_CONV_FLAT_GLDS"))
-            hipLaunchKernelGGL((conv_wgrad_blds_kernel<WGRAD_BP>), dim3((unsigned)blocks), dim3(256), 0, s, a, (unsigned)shift,
-                               (unsigned)(xbytes + shift));
+        if (xbytes + shift + 16LL * d->H * d->W * d->Cin * 4 < 0x7FFFFFF0LL && ybytes < 0x7FFFFFF0LL && !getenv("MRCNN_CONV_FLAT_GLDS")) {
+            const size_t tb = wgrad_table_bytes(d);
+            a.table = nullptr;
+            if (tb && workspace && workspace_bytes >= slab_bytes + tb) {
+                char* q = (char*)workspace + slab_bytes;
+                a.table = (const PixelEntry*)((reinterpret_cast<uintptr_t>(q) + 255) & ~(uintptr_t)255);
+                const int rows = (int)M + WGRAD_BP;
+                hipLaunchKernelGGL(pixel_table_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, (PixelEntry*)a.table, d->N,
+                                   d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->OH, d->OW, (int)M, rows,
+                                   (unsigned)shift, 4);
+                hipLaunchKernelGGL((conv_wgrad_blds_kernel<WGRAD_BP, true>), dim3((unsigned)blocks), dim3(256), 0, s, a, (unsigned)shift,
+                                   (unsigned)(xbytes + shift));
+            } else {
+                hipLaunchKernelGGL((conv_wgrad_blds_kernel<WGRAD_BP, false>), dim3((unsigned)blocks), dim3(256), 0, s, a, (unsigned)shift,
+                                   (unsigned)(xbytes + shift));
+            }
+        }
         else
             hipLaunchKernelGGL((conv_wgrad_glds_kernel<128, 128, WGRAD_BP>), dim3((unsigned)blocks), dim3(256), 0, s, a);
     } else if (pl.bi == 128) {

@@ -137,6 +137,7 @@ WGRAD_CASES = [
     (2, 8, 8, 2048, 512, 1, 1, "valid"),
     (3, 13, 11, 128, 256, 3, 1, "same"),        # LDS-DMA wgrad: M = 429 (pixel tail inside a 16-row piece), odd H/W
     (90, 13, 11, 128, 256, 3, 1, "same"),       # LDS-DMA wgrad + LDS-DMA dgrad, ragged M
+    (459, 13, 11, 128, 128, 3, 1, "same"),      # M = 65637 >= 65536: pixel-table addressing, tail inside a step
 ]
 
 
