@@ -575,6 +575,10 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     return mrcnn_launch_status();
 }
 
+// 128-row tiles only when they give every CU several workgroups (256 CUs x 5 resident): fewer, and the chip idles
+#ifndef CONV_BIG_TILE_MIN_BLOCKS
+#define CONV_BIG_TILE_MIN_BLOCKS 640
+#endif
 struct ConvPlan { int bm, bn, ksplit, ksteps; };
 
 // Tile + split-K choice.  Large problems: 128-row tiles, no split.  Small feature maps (C3..C5, P3..P6
@@ -594,14 +598,14 @@ static ConvPlan plan_conv(const mrcnn_conv_desc* d) {
         pl.bm = ((M + 127) / 128 >= 256) ? 128 : 64;
     } else {
         pl.bn = 128;
-        pl.bm = (((M + 127) / 128) * ((Cout + 127) / 128) >= 256) ? 128 : 64;
+        pl.bm = (((M + 127) / 128) * ((Cout + 127) / 128) >= CONV_BIG_TILE_MIN_BLOCKS) ? 128 : 64;
         if (pl.bm == 64 && ((M + 63) / 64) * ((Cout + 127) / 128) < 128) pl.bn = 64;   // more, smaller tiles
     }
     blocks = ((M + pl.bm - 1) / pl.bm) * ((Cout + pl.bn - 1) / pl.bn);
     pl.ksplit = 1;
     pl.ksteps = nk;
-    if (blocks < 192 && nk >= 8) {
-        long long want = (512 + blocks - 1) / blocks;          // aim at ~2 workgroups per CU
+    if (blocks < 768 && nk >= 8) {
+        long long want = (1024 + blocks - 1) / blocks;         // aim at ~4 workgroups per CU
         long long maxs = nk / 4;                               // at least 4 K-steps per slice
         long long ks = want < maxs ? want : maxs;
         if (ks > 16) ks = 16;
