@@ -39,6 +39,14 @@ __device__ __forceinline__ bool iou_gt(const float* a, const float* bx, float th
 }
 
 
+// 64-bit value of lane `src` for a wave-uniform src: two v_readlane_b32 (a few cycles, result in SGPRs) instead of
+// two LDS-crossbar shuffles
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int src) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v & 0xFFFFFFFFull), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __device__ __forceinline__ unsigned long long shfl64(unsigned long long v, int src) {
     unsigned lo = (unsigned)__shfl((int)(unsigned)(v & 0xFFFFFFFFull), src, 64);
     unsigned hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src, 64);

@@ -177,21 +177,26 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const PropArgs p) {
     __shared__ int keep[SORT_CAP];
     unsigned long long rem0 = 0ull, rem1 = 0ull;     // removed bits: words lane and lane+64
     int total = 0;
+    // The greedy decision inside a chunk is wave-uniform: it runs on the scalar unit over the ALIVE candidates only
+    // (find-first-set, two v_readlane per kept box).  What is left on the critical path is memory latency: the
+    // diagonal word of the next chunk is prefetched, and the rows of the boxes a chunk keeps are fetched sixteen at a
+    // time so that their independent loads overlap.
+    unsigned long long diag = (lane < K) ? mask[(int64_t)lane * nw] : 0ull;
     for (int c = 0; c < nw && total < maxk; ++c) {
         const int i = c * 64 + lane;
-        unsigned long long diag = (i < K) ? mask[(int64_t)i * nw + c] : 0ull;
-        unsigned long long remc = shfl64(c < 64 ? rem0 : rem1, c & 63);
+        unsigned long long diag_next = 0ull;
+        if (c + 1 < nw && i + 64 < K) diag_next = mask[(int64_t)(i + 64) * nw + c + 1];
+        const unsigned long long remc = readlane64(c < 64 ? rem0 : rem1, c & 63);
         const int valid_n = (K - c * 64) < 64 ? (K - c * 64) : 64;
         unsigned long long alive = ~remc;
         if (valid_n < 64) alive &= (1ull << valid_n) - 1ull;
         unsigned long long kept = 0ull;
-        for (int t = 0; t < 64; ++t) {
-            unsigned long long d = shfl64(diag, t);
-            if (((alive >> t) & 1ull) && total < maxk) {
-                kept |= 1ull << t;
-                ++total;
-                alive &= ~d;
-            }
+        while (alive && total < maxk) {
+            const int t = __ffsll((long long)alive) - 1;
+            kept |= 1ull << t;
+            ++total;
+            alive &= ~readlane64(diag, t);
+            alive &= ~(1ull << t);
         }
         // record kept boxes of this chunk
         if ((kept >> lane) & 1ull) {
@@ -199,14 +204,12 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const PropArgs p) {
             keep[pos] = i;
         }
         // OR the rows of the kept boxes into the removed bitmap (only words > c matter)
-        // rows are fetched eight at a time so their (independent) loads overlap instead of paying one
-        // L2 round trip per kept box
         unsigned long long k2 = kept;
         const bool w0 = lane > c && lane < nw, w1 = lane + 64 > c && lane + 64 < nw;
         while (k2) {
-            unsigned long long v0[8], v1[8];
+            unsigned long long v0[16], v1[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 v0[u] = 0ull; v1[u] = 0ull;
                 if (k2) {
                     const int t = __ffsll((long long)k2) - 1;
@@ -217,8 +220,9 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const PropArgs p) {
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { rem0 |= v0[u]; rem1 |= v1[u]; }
+            for (int u = 0; u < 16; ++u) { rem0 |= v0[u]; rem1 |= v1[u]; }
         }
+        diag = diag_next;
     }
     __syncthreads();
     if (p.num_keep && lane == 0) p.num_keep[b] = total;
