@@ -100,7 +100,7 @@ def measure(args, backbone, nimg, rank, local_rank, world, full):
     from caesar_mrcnn_amd.model import MaskRCNN
     from caesar_mrcnn_amd.parallel import GradReducer
 
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", int(os.environ.get("MRCNN_FORCE_DEVICE", local_rank)))   # override: rehearsals on one GPU
     cfg = run_py_config(num_classes=4, imgsize=args.imgsize, backbone=backbone, images_per_gpu=nimg,
                         gpu_count=world)
     import contextlib
@@ -251,7 +251,7 @@ def main():
     rank, local_rank, world = init_distributed()
     if world != args.gpus and rank == 0:
         sys.stderr.write("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n" % (args.gpus, world))
-    torch.cuda.set_device(torch.device("cuda", local_rank))
+    torch.cuda.set_device(torch.device("cuda", int(os.environ.get("MRCNN_FORCE_DEVICE", local_rank))))
 
     r = measure(args, args.backbone, args.nimg, rank, local_rank, world, full=True)
     second = None
