@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Step time of the engine modes: dense / sparse x float32 / float16 mask head (tools only)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from caesar_mrcnn_amd.config import run_py_config
+from caesar_mrcnn_amd.model import MaskRCNN
+backbone = sys.argv[1] if len(sys.argv) > 1 else "resnet101"
+nimg = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+dev = torch.device("cuda", 0)
+cfg = run_py_config(num_classes=4, imgsize=256, backbone=backbone, images_per_gpu=nimg, gpu_count=1)
+model = MaskRCNN("training", cfg, "/tmp/mrcnn_bench_logs", device=dev, seed=0)
+model.compile(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM)
+inp = model._to_device(bench.synthetic_batch(cfg, nimg, seed=1234))
+eng = model.engine
+for sparse in (False, True):
+    for hd in (None, torch.float16, torch.bfloat16):
+        eng.sparse_mask_bwd, eng.head_dtype = sparse, hd
+        for _ in range(3):
+            eng.forward_backward(*inp); eng.apply_gradients(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM, 1)
+        torch.cuda.synchronize(); t0 = time.time()
+        for _ in range(10):
+            eng.forward_backward(*inp); eng.apply_gradients(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM, 1)
+        torch.cuda.synchronize(); dt = (time.time() - t0) / 10
+        print("sparse=%-5s head=%-14s %.2f ms/step  %.1f img/s" % (sparse, hd, dt * 1e3, nimg / dt))
