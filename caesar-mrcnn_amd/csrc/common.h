@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 kernels of the Mask R-CNN hot path.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include "mrcnn_hip.h"
 
@@ -113,4 +114,11 @@ static __global__ void pixel_table_kernel(PixelEntry* table, int N, int H, int W
         e.mask_lo = (unsigned)mk; e.mask_hi = (unsigned)(mk >> 32);
     }
     table[m] = e;
+}
+
+// MRCNN_CONV_FLAT_GLDS=1 (read once): keep the flat-addressed LDS-DMA kernels, which are otherwise only used for
+// tensors too large for a 32-bit buffer descriptor -- lets the tests and A/B timings reach them on small shapes.
+static inline bool mrcnn_force_flat_glds() {
+    static const bool v = getenv("MRCNN_CONV_FLAT_GLDS") != nullptr;
+    return v;
 }

@@ -669,7 +669,7 @@ extern "C" int mrcnn_conv2d_fwd_ws(const mrcnn_conv_desc* d, const float* x, con
         const long long xbytes = (long long)d->N * d->H * d->W * d->Cin * 4;
         const long long shift = ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
         const long long wbytes = (long long)a.Ktot * d->Cout * 4;
-        if (xbytes + shift < 0x7FFFFFF0LL && wbytes < 0x7FFFFFF0LL && !getenv("MRCNN_CONV_FLAT_GLDS"))
+        if (xbytes + shift < 0x7FFFFFF0LL && wbytes < 0x7FFFFFF0LL && !mrcnn_force_flat_glds())
             hipLaunchKernelGGL(conv_fwd_blds_kernel, dim3((unsigned)(mt * nt)), dim3(256), 0, s, a, (unsigned)shift,
                                (unsigned)(xbytes + shift));
         else

@@ -520,7 +520,7 @@ extern "C" int mrcnn_conv2d_wgrad(const mrcnn_conv_desc* d, const float* x, cons
         const long long shift = ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
         const long long ybytes = M * d->Cout * 4;
         // + 16 pixel rows: offsets of rows past the tensor must not wrap before the range check sees them
-        if (xbytes + shift + 16LL * d->H * d->W * d->Cin * 4 < 0x7FFFFFF0LL && ybytes < 0x7FFFFFF0LL && !getenv("MRCNN_CONV_FLAT_GLDS")) {
+        if (xbytes + shift + 16LL * d->H * d->W * d->Cin * 4 < 0x7FFFFFF0LL && ybytes < 0x7FFFFFF0LL && !mrcnn_force_flat_glds()) {
             const size_t tb = wgrad_table_bytes(d);
             a.table = nullptr;
             if (tb && workspace && workspace_bytes >= slab_bytes + tb) {

@@ -578,9 +578,9 @@ class MaskRCNNEngine(object):
             row = int(np.prod(d_mmask.shape[2:])) * 4
             g = ops.empty((B, R) + tuple(d_mmask.shape[2:]), torch.float32, self.dev)
             ops.copy2d(g.data_ptr(), R * row, d_mmask.data_ptr(), T * row, R * row, B)
-        self._mask_head_bwd_rows(g.view((B * R,) + tuple(g.shape[2:])), ctxs, rois, dP, area, False)
+        self._mask_head_bwd_rows(g.view((B * R,) + tuple(g.shape[2:])), ctxs, rois, dP, area)
 
-    def _mask_head_bwd_rows(self, g, ctxs, rois, dP, area, acc):
+    def _mask_head_bwd_rows(self, g, ctxs, rois, dP, area):
         cfg = self.cfg
         c1, c2, c3, c4, cdec, cm = ctxs
         mop, dc = self.op("mrcnn_mask"), self.op("mrcnn_mask_deconv")
@@ -593,13 +593,13 @@ class MaskRCNNEngine(object):
                                    mop.dw.view(mop.wshape[2], mop.wshape[3]), mop.db, dc.db)
         else:
             dz, _ = mop.epilogue_bwd(g, cm)
-            mop.wgrad(dz, cm, accumulate=acc)
+            mop.wgrad(dz, cm)
             d_up = mop.dgrad(dz, cm)                                    # [M,28,28,256]
             # deconv: relu mask + bias, regroup to GEMM columns, then the two GEMM adjoints
             dzu = ops.empty_like(d_up)
             ops.epilogue_bwd(d_up, up, None, None, None, None, None, dzu, None, None, dc.db, ACT_RELU)
             dzg = ops.pixel_unshuffle2(dzu)                             # [M,14,14,1024]
-        self.wgrad_async(x_in, dzg, dc.wshape, 1, "valid", dc.dw, acc)
+        self.wgrad_async(x_in, dzg, dc.wshape, 1, "valid", dc.dw, False)
         if not self.wt_valid:
             ops.weight_flip_transpose(dc.w, dc.wt)
         d = ops.conv2d(dzg, dc.wt, stride=1, padding="valid")
@@ -607,7 +607,7 @@ class MaskRCNNEngine(object):
             for i, c in ((4, c4), (3, c3), (2, c2), (1, c1)):
                 op = self.op("mrcnn_mask_conv%d" % i)
                 dz, _ = op.epilogue_bwd(d, c)
-                op.wgrad(dz, c, accumulate=acc)
+                op.wgrad(dz, c)
                 d = op.dgrad(dz, c)
         else:
             S = float(self.loss_scale) if self.head_dtype == torch.float16 else 1.0

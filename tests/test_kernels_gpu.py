@@ -1,6 +1,9 @@
 """Kernel-level parity: every C-ABI entry point against the CPU oracle on seeded inputs (sizes the
 oracle finishes in seconds).  Float tolerances are written next to each check; index outputs are
 compared exactly."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -504,3 +507,36 @@ def test_sgd_step(dev):
             continue
         np.testing.assert_allclose(Pd[o:o + n].cpu().numpy(), params[i], rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(Vd[o:o + n].cpu().numpy(), vel[i], rtol=1e-5, atol=1e-6)
+
+
+_FLAT_SCRIPT = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "oracle"))
+import mrcnn_oracle as orc
+import caesar_mrcnn_amd
+from caesar_mrcnn_amd import ops
+rng = np.random.default_rng(3)
+dev = torch.device("cuda:0")
+x = torch.tensor(rng.standard_normal((90, 13, 11, 128)).astype(np.float32), requires_grad=True)
+w = torch.tensor((rng.standard_normal((3, 3, 128, 256)) / 34.0).astype(np.float32), requires_grad=True)
+y = orc.conv2d_nhwc(x, w, None, 1, "same")
+dy = torch.tensor(rng.standard_normal(tuple(y.shape)).astype(np.float32))
+y.backward(dy)
+got = ops.conv2d(x.detach().to(dev), w.detach().to(dev), None, None, None, None, 1, "same")
+dw = ops.conv2d_wgrad(x.detach().to(dev), dy.to(dev), (3, 3, 128, 256), 1, "same")
+torch.cuda.synchronize()
+assert float((got.cpu() - y.detach()).abs().max()) <= 2e-4 * float(y.abs().max())
+assert float((dw.cpu() - w.grad).abs().max()) <= 5e-4 * float(w.grad.abs().max())
+print("flat-ok")
+'''
+
+
+def test_flat_addressed_lds_dma_kernels(dev):
+    """conv_fwd_glds_kernel / conv_wgrad_glds_kernel serve tensors too large for a 32-bit buffer descriptor; the
+    MRCNN_CONV_FLAT_GLDS switch (read once per process) routes an ordinary shape through them."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MRCNN_CONV_FLAT_GLDS="1")
+    r = subprocess.run([sys.executable, "-c", _FLAT_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "flat-ok" in r.stdout, r.stderr[-2000:]
