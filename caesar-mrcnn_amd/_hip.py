@@ -43,6 +43,10 @@ class RpnTargetDesc(C.Structure):
                 ("bbox_std_dev", C.c_double * 4)]
 
 
+class BwdEpilogue(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("out", "z", "scale", "mean", "rstd", "dgamma", "dbeta", "dbias")] + [("act", C.c_int32)]
+
+
 class DetectionDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("R", C.c_int32), ("C", C.c_int32), ("max_instances", C.c_int32),
                 ("min_confidence", C.c_float), ("nms_threshold", C.c_float), ("bbox_std_dev", C.c_float * 4)]
@@ -85,6 +89,7 @@ _SIGNATURES = {
     "mrcnn_proposal_fwd": (C.c_int, [C.POINTER(ProposalDesc)] + [_P] * 8 + [C.c_size_t, _P]),
     "mrcnn_detection_targets": (C.c_int, [C.POINTER(DetTargetDesc)] + [_P] * 12),
     "mrcnn_conv2d_fwd_h16": (C.c_int, [C.POINTER(ConvDesc), C.c_int] + [_P] * 8),
+    "mrcnn_conv2d_dgrad_ep": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, C.POINTER(BwdEpilogue), _P]),
     "mrcnn_conv2d_wgrad_h16_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "mrcnn_conv2d_wgrad_h16": (C.c_int, [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_float, _P]),
     "mrcnn_weights_to_h16": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

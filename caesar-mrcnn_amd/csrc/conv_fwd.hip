@@ -19,6 +19,10 @@ struct ConvArgs {
     long long ons, ohs, ows;
     int M, Ktot, nk, fastA, vecB, dense;
     float* slab; int ksplit, ksteps;   // split-K: partial sums [ksplit][M][Cout], K-steps per split
+    // fused backward epilogue (mrcnn_conv2d_dgrad_ep, LDS-DMA kernel only): the result y is the gradient w.r.t. the
+    // activated output of the layer below; that layer's epilogue backward is applied before the store
+    const float* fb_out; const float* fb_z; const float* fb_scale; const float* fb_mean; const float* fb_rstd;
+    float* fb_dgamma; float* fb_dbeta; float* fb_dbias; int fb_act;
 };
 
 // One 32x32 accumulator tile: lane holds column n, rows mbase + (r&3) + 8*(r>>2).
@@ -58,6 +62,28 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& p, const f32x
         if (p.act == MRCNN_ACT_RELU) y = fmaxf(y, 0.f);
         else if (p.act == MRCNN_ACT_SIGMOID) y = 1.f / (1.f + expf(-y));
         p.out[addr] = y;
+    }
+}
+
+// Fused-backward form of conv_epilogue_tile (dense NHWC only): y = acc (+ res) is d(loss)/d(out_below);
+//   g = y * act'(out_below),  dz = g * scale_below  -> stored;  sums: dbeta += g, dgamma += g*(z-mean)*rstd, dbias += dz
+// (mrcnn_epilogue_bwd applied in the producer).  s[0..2] accumulate this lane's column sums.
+__device__ __forceinline__ void conv_epilogue_tile_bwd(const ConvArgs& p, const f32x16& acc, int mbase, int n, float* s) {
+    const float sc = p.fb_scale ? p.fb_scale[n] : 1.f;
+    const float mu = p.fb_dgamma ? p.fb_mean[n] : 0.f, rs = p.fb_dgamma ? p.fb_rstd[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mbase + (r & 3) + 8 * (r >> 2);
+        if (m >= p.M) continue;
+        const long long addr = (long long)m * p.Cout + n;
+        float g = acc[r];
+        if (p.res_mode != MRCNN_RES_NONE) g += p.res[addr];
+        if (p.fb_act == MRCNN_ACT_RELU) g = p.fb_out[addr] > 0.f ? g : 0.f;
+        const float dz = g * sc;
+        p.out[addr] = dz;
+        s[0] += g;
+        if (p.fb_dgamma) s[1] += g * (p.fb_z[addr] - mu) * rs;
+        s[2] += dz;
     }
 }
 
@@ -519,6 +545,37 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_blds_kernel(const ConvArgs p,
         }
     }
     const int mw0 = m0 + wm * 64 + 4 * lh, nw0 = n0 + wn * 64 + li;
+    if (p.fb_act >= 0) {
+        // fused backward epilogue: column sums of this workgroup (2 row waves x 2 lane halves per column) meet in LDS,
+        // then one atomic per channel and sum
+        float s0[3] = {0.f, 0.f, 0.f}, s1[3] = {0.f, 0.f, 0.f};
+        conv_epilogue_tile_bwd(p, acc[0][0], mw0, nw0, s0);
+        conv_epilogue_tile_bwd(p, acc[1][0], mw0 + 32, nw0, s0);
+        conv_epilogue_tile_bwd(p, acc[0][1], mw0, nw0 + 32, s1);
+        conv_epilogue_tile_bwd(p, acc[1][1], mw0 + 32, nw0 + 32, s1);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s0[k] += __shfl_xor(s0[k], 32, 64); s1[k] += __shfl_xor(s1[k], 32, 64); }
+        __syncthreads();                                        // the K loop's LDS tiles are dead
+        float* red = lds;                                       // [wm][wn*64 + col][3]
+        if (lh == 0) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                red[(wm * 128 + wn * 64 + li) * 3 + k] = s0[k];
+                red[(wm * 128 + wn * 64 + 32 + li) * 3 + k] = s1[k];
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            const int n = n0 + tid;
+            const float db = red[tid * 3 + 0] + red[(128 + tid) * 3 + 0];
+            const float dg = red[tid * 3 + 1] + red[(128 + tid) * 3 + 1];
+            const float dbi = red[tid * 3 + 2] + red[(128 + tid) * 3 + 2];
+            if (p.fb_dbeta) atomicAdd(p.fb_dbeta + n, db);
+            if (p.fb_dgamma) atomicAdd(p.fb_dgamma + n, dg);
+            if (p.fb_dbias) atomicAdd(p.fb_dbias + n, dbi);
+        }
+        return;
+    }
     conv_epilogue_tile(p, acc[0][0], mw0, nw0);
     conv_epilogue_tile(p, acc[0][1], mw0, nw0 + 32);
     conv_epilogue_tile(p, acc[1][0], mw0 + 32, nw0);
@@ -624,10 +681,10 @@ extern "C" size_t mrcnn_conv2d_fwd_workspace(const mrcnn_conv_desc* d) {
     return (size_t)pl.ksplit * d->N * d->OH * d->OW * d->Cout * sizeof(float);
 }
 
-extern "C" int mrcnn_conv2d_fwd_ws(const mrcnn_conv_desc* d, const float* x, const float* w,
-                                   const float* bias, const float* scale, const float* shift,
-                                   const float* res, float* out, float* z_out, void* workspace,
-                                   size_t workspace_bytes, void* stream) {
+static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* w,
+                         const float* bias, const float* scale, const float* shift,
+                         const float* res, float* out, float* z_out, void* workspace,
+                         size_t workspace_bytes, const mrcnn_bwd_epilogue* ep, void* stream) {
     if (!d || !x || !w || !out) return MRCNN_ERR_ARG;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 ||
         d->stride <= 0 || d->OH <= 0 || d->OW <= 0 || d->cmod <= 0)
@@ -663,7 +720,21 @@ extern "C" int mrcnn_conv2d_fwd_ws(const mrcnn_conv_desc* d, const float* x, con
         pl.ksteps = a.nk;
     }
     a.ksplit = pl.ksplit; a.ksteps = pl.ksteps; a.slab = (float*)workspace;
-    if (pl.bm == 128 && pl.bn == 128 && pl.ksplit == 1 && a.fastA && a.vecB && d->Cout % 128 == 0) {
+    a.fb_act = -1;
+    a.fb_out = a.fb_z = a.fb_scale = a.fb_mean = a.fb_rstd = nullptr;
+    a.fb_dgamma = a.fb_dbeta = a.fb_dbias = nullptr;
+    const bool lds_dma = pl.bm == 128 && pl.bn == 128 && pl.ksplit == 1 && a.fastA && a.vecB && d->Cout % 128 == 0;
+    if (ep) {                                   // fused backward epilogue: LDS-DMA kernel, dense output, plain store
+        const long long xb = (long long)d->N * d->H * d->W * d->Cin * 4 + ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
+        if (!lds_dma || !a.dense || bias || scale || z_out || d->act != MRCNN_ACT_NONE || d->res_mode == MRCNN_RES_UP2 ||
+            xb >= 0x7FFFFFF0LL || mrcnn_force_flat_glds())
+            return MRCNN_ERR_UNSUPPORTED;
+        if ((ep->act != MRCNN_ACT_NONE && ep->act != MRCNN_ACT_RELU) || (ep->act == MRCNN_ACT_RELU && !ep->out)) return MRCNN_ERR_ARG;
+        if (ep->dgamma && (!ep->z || !ep->mean || !ep->rstd)) return MRCNN_ERR_ARG;
+        a.fb_act = ep->act; a.fb_out = ep->out; a.fb_z = ep->z; a.fb_scale = ep->scale; a.fb_mean = ep->mean; a.fb_rstd = ep->rstd;
+        a.fb_dgamma = ep->dgamma; a.fb_dbeta = ep->dbeta; a.fb_dbias = ep->dbias;
+    }
+    if (lds_dma) {
         const int mt = (a.M + 127) / 128, nt = a.Cout / 128;
         // buffer-addressed variant when the input (plus the padding shift) fits a 32-bit descriptor range
         const long long xbytes = (long long)d->N * d->H * d->W * d->Cin * 4;
@@ -679,6 +750,19 @@ extern "C" int mrcnn_conv2d_fwd_ws(const mrcnn_conv_desc* d, const float* x, con
     if (pl.bn == 32) return pl.bm == 128 ? launch_conv<128, 32, 4, 1>(a, s) : launch_conv<64, 32, 2, 1>(a, s);
     if (pl.bn == 64) return pl.bm == 128 ? launch_conv<128, 64, 2, 2>(a, s) : launch_conv<64, 64, 2, 2>(a, s);
     return pl.bm == 128 ? launch_conv<128, 128, 2, 2>(a, s) : launch_conv<64, 128, 2, 2>(a, s);
+}
+
+extern "C" int mrcnn_conv2d_fwd_ws(const mrcnn_conv_desc* d, const float* x, const float* w,
+                                   const float* bias, const float* scale, const float* shift,
+                                   const float* res, float* out, float* z_out, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
+    return conv_fwd_impl(d, x, w, bias, scale, shift, res, out, z_out, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int mrcnn_conv2d_dgrad_ep(const mrcnn_conv_desc* d, const float* dz, const float* w_t, const float* res,
+                                     float* dz_below, const mrcnn_bwd_epilogue* ep, void* stream) {
+    if (!ep) return MRCNN_ERR_ARG;
+    return conv_fwd_impl(d, dz, w_t, nullptr, nullptr, nullptr, res, dz_below, nullptr, nullptr, 0, ep, stream);
 }
 
 extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc* d, const float* x, const float* w,

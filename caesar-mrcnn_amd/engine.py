@@ -187,6 +187,7 @@ class MaskRCNNEngine(object):
         self._h16 = {}
         self._h16_valid = False
         self.fused_mask_out_bwd = True  # single-pass backward of the mask-head output stage
+        self.fused_dgrad_epilogue = True  # data-gradient convs of the mask head apply the lower layer's epilogue backward
         self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self.aux_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
 
@@ -602,14 +603,22 @@ class MaskRCNNEngine(object):
         self.wgrad_async(x_in, dzg, dc.wshape, 1, "valid", dc.dw, False)
         if not self.wt_valid:
             ops.weight_flip_transpose(dc.w, dc.wt)
-        d = ops.conv2d(dzg, dc.wt, stride=1, padding="valid")
         if self.head_dtype is None:
-            for i, c in ((4, c4), (3, c3), (2, c2), (1, c1)):
-                op = self.op("mrcnn_mask_conv%d" % i)
-                dz, _ = op.epilogue_bwd(d, c)
+            # every data-gradient convolution applies the epilogue backward of the layer below in its own epilogue
+            # (mrcnn_conv2d_dgrad_ep): the gradient w.r.t. the activated output is never written or re-read
+            chain = [(self.op("mrcnn_mask_conv%d" % i), c) for i, c in ((4, c4), (3, c3), (2, c2), (1, c1))]
+            dz = self._dgrad_ep(dzg, dc.wt, "valid", chain[0][0], chain[0][1])
+            for k, (op, c) in enumerate(chain):
                 op.wgrad(dz, c)
-                d = op.dgrad(dz, c)
+                if k + 1 < len(chain):
+                    kh, kw = op.wshape[0], op.wshape[1]
+                    if not self.wt_valid:
+                        ops.weight_flip_transpose(op.w, op.wt)
+                    dz = self._dgrad_ep(dz, op.wt, ((kh - 1) // 2, (kw - 1) // 2), chain[k + 1][0], chain[k + 1][1])
+                else:
+                    d = op.dgrad(dz, c)
         else:
+            d = ops.conv2d(dzg, dc.wt, stride=1, padding="valid")
             S = float(self.loss_scale) if self.head_dtype == torch.float16 else 1.0
             d16 = ops.cast_to_h16(d, self.head_dtype, multiplier=S)
             for i, c in ((4, c4), (3, c3), (2, c2), (1, c1)):
@@ -623,6 +632,18 @@ class MaskRCNNEngine(object):
             d = ops.cast_from_h16(d16, 1.0 / S)
         B, R = rois.shape[0], rois.shape[1]
         ops.roialign_bwd(rois, d.view(B, R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1), dP, cfg.MASK_POOL_SIZE, area)
+
+    def _dgrad_ep(self, dz, wt, padding, below, below_ctx):
+        """dz of layer `below` from the dz of the layer above: data-gradient convolution with `wt` fused with
+        `below`'s epilogue backward when the layer is large enough for that kernel, the two separate calls otherwise."""
+        _, z, out, act = below_ctx
+        if self.fused_dgrad_epilogue and below.bn is not None:
+            got = ops.conv2d_dgrad_ep(dz, wt, padding, out if act != ACT_NONE else None, z, below.scale, below.mean, below.rstd,
+                                      below.dgamma, below.dbeta, below.db, act)
+            if got is not None:
+                return got
+        d = ops.conv2d(dz, wt, stride=1, padding=padding)
+        return below.epilogue_bwd(d, below_ctx)[0]
 
     def _class_head_bwd(self, d_logits, d_mbbox, ctxs, rois, dP, area):
         cfg = self.cfg

@@ -68,6 +68,26 @@ def conv2d(x, w, bias=None, scale=None, shift=None, res=None, stride=1, padding=
     return out
 
 
+ERR_UNSUPPORTED = -4
+
+
+def conv2d_dgrad_ep(dz, w_t, padding, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, act, res=None, out=None):
+    """Data-gradient convolution (stride 1) fused with the epilogue backward of the layer below; returns dz_below, or
+    None when the layer is too small for the fused kernel (the caller then uses conv2d + epilogue_bwd)."""
+    _need_cuda(dz, w_t, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, res, out)
+    d = conv_desc(tuple(dz.shape), tuple(w_t.shape), 1, padding, ACT_NONE, RES_SAME if res is not None else RES_NONE)
+    ep = _hip.BwdEpilogue()
+    ep.out, ep.z, ep.scale, ep.mean, ep.rstd = ptr(below_out), ptr(below_z), ptr(scale), ptr(mean), ptr(rstd)
+    ep.dgamma, ep.dbeta, ep.dbias, ep.act = ptr(dgamma), ptr(dbeta), ptr(dbias), act
+    if out is None:
+        out = empty((d.N, d.OH, d.OW, d.Cout), torch.float32, dz.device)
+    rc = _hip.lib().mrcnn_conv2d_dgrad_ep(C.byref(d), ptr(dz), ptr(w_t), ptr(res), ptr(out), C.byref(ep), current_stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    check(rc, "mrcnn_conv2d_dgrad_ep")
+    return out
+
+
 def conv2d_into(x, w, bias, out_view_ptr, n_stride, h_stride, w_stride, stride=1, padding="same", act=ACT_NONE):
     """Conv whose output rows land inside a larger buffer (e.g. one pyramid level of the concatenated
     RPN outputs).  out_view_ptr is the device address of element (0,0,0,0)."""

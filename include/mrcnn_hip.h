@@ -23,6 +23,7 @@ extern "C" {
 #define MRCNN_ERR_ARG (-1)
 #define MRCNN_ERR_LAUNCH (-2)
 #define MRCNN_ERR_WORKSPACE (-3)
+#define MRCNN_ERR_UNSUPPORTED (-4)   /* valid request this entry point has no kernel for: use the unfused calls */
 
 #define MRCNN_ACT_NONE 0
 #define MRCNN_ACT_RELU 1
@@ -82,6 +83,21 @@ int mrcnn_weight_flip_transpose(const float* w, float* w_t, int KH, int KW, int 
  * KH*KW*ceil(Cin/32)*ceil(Cout/32).                                                                     */
 int mrcnn_weight_flip_transpose_batched(const float* params, float* params_t, const void* table, int n_layers,
                                         int total_tiles, void* stream);
+
+/* Data-gradient convolution fused with the epilogue backward of the layer below (TF autodiff through Conv2D, then
+ * through the lower layer's Activation / BatchNorm / bias): y = conv(dz, w_t) (+ res) is d(loss)/d(out_below); stored is
+ *   dz_below = y * act'(out_below) * scale_below,   and   dbeta += sum y*act',  dgamma += sum y*act'*(z-mean)*rstd,
+ *   dbias += sum dz_below   (atomics, like mrcnn_epilogue_bwd).
+ * Same result as mrcnn_conv2d_fwd followed by mrcnn_epilogue_bwd, without writing / re-reading y.  Only the large
+ * layers (the LDS-DMA kernel: >= 640 tiles of 128x128, Cin % 32 == 0, Cout % 128 == 0, dense output) are
+ * supported; otherwise MRCNN_ERR_UNSUPPORTED and nothing is launched.  res_mode SAME adds `res` to y first.      */
+typedef struct mrcnn_bwd_epilogue {
+    const float* out; const float* z; const float* scale; const float* mean; const float* rstd;
+    float* dgamma; float* dbeta; float* dbias;
+    int32_t act;                 /* MRCNN_ACT_NONE or MRCNN_ACT_RELU of the layer below */
+} mrcnn_bwd_epilogue;
+int mrcnn_conv2d_dgrad_ep(const mrcnn_conv_desc* d, const float* dz, const float* w_t, const float* res,
+                          float* dz_below, const mrcnn_bwd_epilogue* ep, void* stream);
 
 /* Frozen BatchNorm (KL.BatchNormalization with training=False, mrcnn/model.py:57-72; eps = Keras
  * default 1e-3):  scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, for n channels.          */

@@ -431,3 +431,23 @@ def test_device_rpn_targets_in_training_step(dev):
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-5)
     assert np.abs(res[0][1] - res[1][1]).max() <= 1e-5 * np.abs(res[0][1]).max()
     assert (rpn_match == 1).sum() > 0
+
+
+def test_fused_dgrad_epilogue_equals_unfused(dev):
+    """engine.fused_dgrad_epilogue (mask-head data-gradient convs apply the lower layer's epilogue backward) changes no
+    gradient beyond float32 atomics order; ResNet-50 256x256 so that the layers are large enough to be fused."""
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _full_cfg("resnet50", 256)
+    w = _weights(cfg, 43)
+    inputs, keys = _train_inputs(cfg, 2, 45)
+    res = []
+    for fused in (True, False):
+        model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+        model.engine.fused_dgrad_epilogue = fused
+        model.engine.sparse_mask_bwd = False                      # all 1024 ROI rows: 3136 tiles per conv
+        losses = model.train_on_batch(inputs, rand_keys=keys, apply=False)
+        torch.cuda.synchronize()
+        res.append((losses.cpu().numpy(), model.engine.grads.cpu().numpy().copy()))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    scale = np.abs(res[1][1]).max()
+    assert np.abs(res[0][1] - res[1][1]).max() <= 2e-5 * scale and scale > 0

@@ -540,3 +540,32 @@ def test_flat_addressed_lds_dma_kernels(dev):
     env = dict(os.environ, MRCNN_CONV_FLAT_GLDS="1")
     r = subprocess.run([sys.executable, "-c", _FLAT_SCRIPT % {"root": root}], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "flat-ok" in r.stdout, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("k,res", [(3, False), (1, True)])
+def test_conv_dgrad_fused_with_epilogue_backward(dev, k, res):
+    """mrcnn_conv2d_dgrad_ep == mrcnn_conv2d_fwd followed by mrcnn_epilogue_bwd (both checked against the oracle above):
+    identical dz, channel sums equal up to the order of the float32 atomics; small layers report 'unsupported'."""
+    ops = _ops()
+    rng = np.random.default_rng(77 + k)
+    N, H, W, Cin, Cout = 430, 14, 14, 128, 256                      # M = 84280 -> 659 x 2 tiles of 128 x 128
+    dz = torch.tensor(_rand(rng, N, H, W, Cin), device=dev)
+    wt = torch.tensor(_rand(rng, k, k, Cin, Cout, scale=1.0 / np.sqrt(k * k * Cin)), device=dev)
+    below_out = torch.relu(torch.tensor(_rand(rng, N, H, W, Cout), device=dev))
+    below_z = torch.tensor(_rand(rng, N, H, W, Cout), device=dev)
+    r = torch.tensor(_rand(rng, N, H, W, Cout), device=dev) if res else None
+    scale, mean, rstd = (torch.tensor(rng.uniform(0.5, 1.5, Cout).astype(np.float32), device=dev) for _ in range(3))
+    pad = ((k - 1) // 2, (k - 1) // 2) if k > 1 else "valid"
+    sums = [torch.zeros(Cout, device=dev) for _ in range(3)]
+    got = ops.conv2d_dgrad_ep(dz, wt, pad, below_out, below_z, scale, mean, rstd, sums[0], sums[1], sums[2], 1, res=r)
+    assert got is not None
+    y = ops.conv2d(dz, wt, res=r, stride=1, padding=pad, res_mode=1 if res else 0)
+    ref = torch.empty_like(y)
+    rs = [torch.zeros(Cout, device=dev) for _ in range(3)]
+    ops.epilogue_bwd(y, below_out, below_z, scale, mean, rstd, None, ref, rs[0], rs[1], rs[2], 1)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+    for a, b in zip(sums, rs):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max()))
+    small = ops.conv2d_dgrad_ep(dz[:4], wt, pad, below_out[:4], below_z[:4], scale, mean, rstd, sums[0], sums[1], sums[2], 1)
+    assert small is None
