@@ -618,6 +618,74 @@ __global__ void conv_splitk_epilogue_kernel(const ConvArgs p) {
     p.out[addr] = y;
 }
 
+// Split-K second pass fused with the epilogue backward of the layer below (mrcnn_conv2d_dgrad_ep on small feature
+// maps): y = sum of the slabs in slice order (+ res), then exactly what epilogue_bwd_vec_kernel does with y -- one
+// launch and one round trip of y less per layer.  C = 4 * 2^k >= 16; a thread owns one float4 channel group and walks
+// rows; channel sums stay in registers until one LDS + one global atomic per channel per workgroup.
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_bwd_kernel(const ConvArgs p, const long long rows_per_block) {
+    extern __shared__ float sacc[];   // [3][C]
+    const int C = p.Cout;
+    for (int c = threadIdx.x; c < 3 * C; c += 256) sacc[c] = 0.f;
+    __syncthreads();
+    const int c4n = C >> 2;
+    const int L = c4n < 256 ? c4n : 256;
+    const int R = 256 / L;
+    const int rsub = threadIdx.x / L, lane = threadIdx.x % L;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > p.M) r1 = p.M;
+    const long long slab_stride = (long long)p.M * C;
+    for (int cg = lane; cg < c4n; cg += L) {
+        const int c = cg * 4;
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, mu = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+        if (p.fb_scale) sc = *(const f32x4*)(p.fb_scale + c);
+        if (p.fb_dgamma) { mu = *(const f32x4*)(p.fb_mean + c); rs = *(const f32x4*)(p.fb_rstd + c); }
+        f32x4 a_db = {0.f, 0.f, 0.f, 0.f}, a_dg = a_db, a_bias = a_db;
+        for (long long r = r0 + rsub; r < r1; r += R) {
+            const long long e = r * C + c;
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            for (int k = 0; k < p.ksplit; ++k) {
+                const f32x4 v = *(const f32x4*)(p.slab + k * slab_stride + e);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] += v[q];
+            }
+            if (p.res_mode != MRCNN_RES_NONE) {
+                const f32x4 v = *(const f32x4*)(p.res + e);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] += v[q];
+            }
+            if (p.fb_act == MRCNN_ACT_RELU) {
+                const f32x4 o = *(const f32x4*)(p.fb_out + e);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = o[q] > 0.f ? g[q] : 0.f;
+            }
+            f32x4 dz;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dz[q] = g[q] * sc[q];
+            *(f32x4*)(p.out + e) = dz;
+            if (p.fb_dgamma) {
+                const f32x4 zz = *(const f32x4*)(p.fb_z + e);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a_dg[q] += g[q] * (zz[q] - mu[q]) * rs[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a_db[q] += g[q]; a_bias[q] += dz[q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (p.fb_dbeta || p.fb_dgamma) atomicAdd(&sacc[c + q], a_db[q]);
+            if (p.fb_dgamma) atomicAdd(&sacc[C + c + q], a_dg[q]);
+            if (p.fb_dbias) atomicAdd(&sacc[2 * C + c + q], a_bias[q]);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        if (p.fb_dbeta) atomicAdd(&p.fb_dbeta[c], sacc[c]);
+        if (p.fb_dgamma) atomicAdd(&p.fb_dgamma[c], sacc[C + c]);
+        if (p.fb_dbias) atomicAdd(&p.fb_dbias[c], sacc[2 * C + c]);
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
     const int mt = (a.M + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
@@ -625,7 +693,13 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);
     else
         hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);
-    if (a.ksplit > 1) {
+    if (a.ksplit > 1 && a.fb_act >= 0) {         // slabs -> epilogue backward of the layer below
+        long long rows_per_block = cdiv64(a.M, 2048);
+        const long long min_rows = cdiv64(4096, a.Cout);
+        if (rows_per_block < min_rows) rows_per_block = min_rows;
+        hipLaunchKernelGGL(conv_splitk_epilogue_bwd_kernel, dim3((unsigned)cdiv64(a.M, rows_per_block)), dim3(256),
+                           3 * a.Cout * sizeof(float), s, a, rows_per_block);
+    } else if (a.ksplit > 1) {
         const long long n = (long long)a.M * a.Cout;
         hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, a);
     }
@@ -726,8 +800,12 @@ static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* 
     const bool lds_dma = pl.bm == 128 && pl.bn == 128 && pl.ksplit == 1 && a.fastA && a.vecB && d->Cout % 128 == 0;
     if (ep) {                                   // fused backward epilogue: LDS-DMA kernel, dense output, plain store
         const long long xb = (long long)d->N * d->H * d->W * d->Cin * 4 + ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
-        if (!lds_dma || !a.dense || bias || scale || z_out || d->act != MRCNN_ACT_NONE || d->res_mode == MRCNN_RES_UP2 ||
-            xb >= 0x7FFFFFF0LL || mrcnn_force_flat_glds())
+        const bool pow2c = d->Cout >= 16 && (d->Cout & (d->Cout - 1)) == 0;
+        auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        const bool split_ok = pl.ksplit > 1 && pow2c && al(out) && al(res) && al(ep->out) && al(ep->z) && al(ep->scale) &&
+                              al(ep->mean) && al(ep->rstd);
+        const bool dma_ok = lds_dma && xb < 0x7FFFFFF0LL && !mrcnn_force_flat_glds();
+        if (!(dma_ok || split_ok) || !a.dense || bias || scale || z_out || d->act != MRCNN_ACT_NONE || d->res_mode == MRCNN_RES_UP2)
             return MRCNN_ERR_UNSUPPORTED;
         if ((ep->act != MRCNN_ACT_NONE && ep->act != MRCNN_ACT_RELU) || (ep->act == MRCNN_ACT_RELU && !ep->out)) return MRCNN_ERR_ARG;
         if (ep->dgamma && (!ep->z || !ep->mean || !ep->rstd)) return MRCNN_ERR_ARG;
@@ -760,9 +838,10 @@ extern "C" int mrcnn_conv2d_fwd_ws(const mrcnn_conv_desc* d, const float* x, con
 }
 
 extern "C" int mrcnn_conv2d_dgrad_ep(const mrcnn_conv_desc* d, const float* dz, const float* w_t, const float* res,
-                                     float* dz_below, const mrcnn_bwd_epilogue* ep, void* stream) {
+                                     float* dz_below, const mrcnn_bwd_epilogue* ep, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
     if (!ep) return MRCNN_ERR_ARG;
-    return conv_fwd_impl(d, dz, w_t, nullptr, nullptr, nullptr, res, dz_below, nullptr, nullptr, 0, ep, stream);
+    return conv_fwd_impl(d, dz, w_t, nullptr, nullptr, nullptr, res, dz_below, nullptr, workspace, workspace_bytes, ep, stream);
 }
 
 extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc* d, const float* x, const float* w,

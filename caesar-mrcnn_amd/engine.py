@@ -741,11 +741,14 @@ class MaskRCNNEngine(object):
         ca, cb, cc, c1c = ctxs
         dz, dy = blk.c2c.epilogue_bwd(d_out, cc, want_dy=True)
         blk.c2c.wgrad(dz, cc)
-        d = blk.c2c.dgrad(dz, cc)
-        dz, _ = blk.c2b.epilogue_bwd(d, cb)
+        # 2c -> 2b -> 2a: each data-gradient convolution (or its split-K reduction) applies the epilogue backward of
+        # the layer below (mrcnn_conv2d_dgrad_ep)
+        if not self.wt_valid:
+            ops.weight_flip_transpose(blk.c2c.w, blk.c2c.wt)
+            ops.weight_flip_transpose(blk.c2b.w, blk.c2b.wt)
+        dz = self._dgrad_ep(dz, blk.c2c.wt, "valid", blk.c2b, cb)
         blk.c2b.wgrad(dz, cb)
-        d = blk.c2b.dgrad(dz, cb)
-        dza, _ = blk.c2a.epilogue_bwd(d, ca)
+        dza = self._dgrad_ep(dz, blk.c2b.wt, (1, 1), blk.c2a, ca)
         blk.c2a.wgrad(dza, ca)
         if blk.c1 is None:
             # identity shortcut: dx = dy + dgrad_2a (in place on dy)

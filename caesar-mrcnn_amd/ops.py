@@ -81,7 +81,10 @@ def conv2d_dgrad_ep(dz, w_t, padding, below_out, below_z, scale, mean, rstd, dga
     ep.dgamma, ep.dbeta, ep.dbias, ep.act = ptr(dgamma), ptr(dbeta), ptr(dbias), act
     if out is None:
         out = empty((d.N, d.OH, d.OW, d.Cout), torch.float32, dz.device)
-    rc = _hip.lib().mrcnn_conv2d_dgrad_ep(C.byref(d), ptr(dz), ptr(w_t), ptr(res), ptr(out), C.byref(ep), current_stream())
+    nbytes = _hip.lib().mrcnn_conv2d_fwd_workspace(C.byref(d))
+    ws = workspace(nbytes, dz.device, "conv_splitk") if nbytes else None
+    rc = _hip.lib().mrcnn_conv2d_dgrad_ep(C.byref(d), ptr(dz), ptr(w_t), ptr(res), ptr(out), C.byref(ep), ptr(ws),
+                                          ws.numel() if ws is not None else 0, current_stream())
     if rc == ERR_UNSUPPORTED:
         return None
     check(rc, "mrcnn_conv2d_dgrad_ep")

@@ -88,16 +88,19 @@ int mrcnn_weight_flip_transpose_batched(const float* params, float* params_t, co
  * through the lower layer's Activation / BatchNorm / bias): y = conv(dz, w_t) (+ res) is d(loss)/d(out_below); stored is
  *   dz_below = y * act'(out_below) * scale_below,   and   dbeta += sum y*act',  dgamma += sum y*act'*(z-mean)*rstd,
  *   dbias += sum dz_below   (atomics, like mrcnn_epilogue_bwd).
- * Same result as mrcnn_conv2d_fwd followed by mrcnn_epilogue_bwd, without writing / re-reading y.  Only the large
- * layers (the LDS-DMA kernel: >= 640 tiles of 128x128, Cin % 32 == 0, Cout % 128 == 0, dense output) are
- * supported; otherwise MRCNN_ERR_UNSUPPORTED and nothing is launched.  res_mode SAME adds `res` to y first.      */
+ * Same result as mrcnn_conv2d_fwd followed by mrcnn_epilogue_bwd, without writing / re-reading y.  Supported: the
+ * large layers (LDS-DMA kernel: >= 640 tiles of 128x128, Cin % 32 == 0, Cout % 128 == 0) and the split-K layers (small
+ * feature maps; Cout a power of two, workspace as for mrcnn_conv2d_fwd_ws: the slab reduction then carries the
+ * backward epilogue), dense output; otherwise MRCNN_ERR_UNSUPPORTED and nothing is launched.  res_mode SAME adds
+ * `res` to y first.                                                                                            */
 typedef struct mrcnn_bwd_epilogue {
     const float* out; const float* z; const float* scale; const float* mean; const float* rstd;
     float* dgamma; float* dbeta; float* dbias;
     int32_t act;                 /* MRCNN_ACT_NONE or MRCNN_ACT_RELU of the layer below */
 } mrcnn_bwd_epilogue;
 int mrcnn_conv2d_dgrad_ep(const mrcnn_conv_desc* d, const float* dz, const float* w_t, const float* res,
-                          float* dz_below, const mrcnn_bwd_epilogue* ep, void* stream);
+                          float* dz_below, const mrcnn_bwd_epilogue* ep, void* workspace, size_t workspace_bytes,
+                          void* stream);
 
 /* Frozen BatchNorm (KL.BatchNormalization with training=False, mrcnn/model.py:57-72; eps = Keras
  * default 1e-3):  scale = gamma*rsqrt(var+eps), shift = beta - mean*scale, for n channels.          */

@@ -448,6 +448,6 @@ def test_fused_dgrad_epilogue_equals_unfused(dev):
         losses = model.train_on_batch(inputs, rand_keys=keys, apply=False)
         torch.cuda.synchronize()
         res.append((losses.cpu().numpy(), model.engine.grads.cpu().numpy().copy()))
-    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-6)       # the loss reductions use float atomics
     scale = np.abs(res[1][1]).max()
     assert np.abs(res[0][1] - res[1][1]).max() <= 2e-5 * scale and scale > 0

@@ -542,6 +542,30 @@ def test_flat_addressed_lds_dma_kernels(dev):
     assert r.returncode == 0 and "flat-ok" in r.stdout, r.stderr[-2000:]
 
 
+def test_conv_dgrad_fused_with_epilogue_backward_splitk(dev):
+    """The same entry point on a small feature map: the split-K slab reduction carries the backward epilogue."""
+    ops = _ops()
+    rng = np.random.default_rng(91)
+    for (N, H, W, Cin, Cout, k) in ((4, 16, 16, 1024, 256, 1), (4, 16, 16, 256, 256, 3), (2, 8, 8, 512, 2048, 1)):
+        dz = torch.tensor(_rand(rng, N, H, W, Cin), device=dev)
+        wt = torch.tensor(_rand(rng, k, k, Cin, Cout, scale=1.0 / np.sqrt(k * k * Cin)), device=dev)
+        below_out = torch.relu(torch.tensor(_rand(rng, N, H, W, Cout), device=dev))
+        below_z = torch.tensor(_rand(rng, N, H, W, Cout), device=dev)
+        scale, mean, rstd = (torch.tensor(rng.uniform(0.5, 1.5, Cout).astype(np.float32), device=dev) for _ in range(3))
+        pad = ((k - 1) // 2, (k - 1) // 2) if k > 1 else "valid"
+        sums = [torch.zeros(Cout, device=dev) for _ in range(3)]
+        got = ops.conv2d_dgrad_ep(dz, wt, pad, below_out, below_z, scale, mean, rstd, sums[0], sums[1], sums[2], 1)
+        assert got is not None, "expected the split-K path for %s" % ((N, H, W, Cin, Cout, k),)
+        y = ops.conv2d(dz, wt, stride=1, padding=pad)
+        ref = torch.empty_like(y)
+        rs = [torch.zeros(Cout, device=dev) for _ in range(3)]
+        ops.epilogue_bwd(y, below_out, below_z, scale, mean, rstd, None, ref, rs[0], rs[1], rs[2], 1)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
+        for a, b in zip(sums, rs):
+            torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max()))
+
+
 @pytest.mark.parametrize("k,res", [(3, False), (1, True)])
 def test_conv_dgrad_fused_with_epilogue_backward(dev, k, res):
     """mrcnn_conv2d_dgrad_ep == mrcnn_conv2d_fwd followed by mrcnn_epilogue_bwd (both checked against the oracle above):
@@ -567,5 +591,6 @@ def test_conv_dgrad_fused_with_epilogue_backward(dev, k, res):
     assert torch.equal(got, ref)
     for a, b in zip(sums, rs):
         torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max()))
-    small = ops.conv2d_dgrad_ep(dz[:4], wt, pad, below_out[:4], below_z[:4], scale, mean, rstd, sums[0], sums[1], sums[2], 1)
-    assert small is None
+    if k == 1:          # 4 images, K = 128: neither LDS-DMA tiles nor a split-K plan -> the caller must use the two calls
+        small = ops.conv2d_dgrad_ep(dz[:4], wt, pad, below_out[:4], below_z[:4], scale, mean, rstd, sums[0], sums[1], sums[2], 1)
+        assert small is None
