@@ -27,9 +27,94 @@ struct PropArgs {
     float* rois; int32_t* top_idx; int32_t* keep_idx; int32_t* num_keep;
     float* boxes_ws;               // [B, K, 4]
     unsigned long long* mask_ws;   // [B, K, nwords]
+    unsigned* pre_ws;              // [B, PRE_WORDS]: hist1[4096], hist2[4096], counter, candidate count
+    unsigned long long* cand_ws;   // [B, SORT_CAP] candidate keys of the multi-workgroup pre-selection
+    int pre_groups;                // workgroups per image of the pre-selection (0 = off)
     int B, A, K, proposal_count, nwords;
     float thr, s0, s1, s2, s3;
 };
+
+// ---- multi-workgroup pre-selection ----------------------------------------------------------------------
+// One workgroup walking all A scores four times is what the selection costs at large images (A = 261 888 at
+// 1024^2: 0.9 ms).  Three small launches over many workgroups narrow the field first: a 12-bit histogram of the
+// key's top bits (LDS per workgroup, then global atomics), a second 12-bit histogram inside the threshold bin, and a
+// collection of every anchor whose top 24 key bits reach the 24-bit threshold -- all of the top K plus the few
+// anchors that share the threshold's 24-bit prefix.  If those fit the sorter (<= SORT_CAP) the single-workgroup kernel
+// only sorts them (exact, ties by anchor index as before); otherwise it runs its own full selection.
+#define PRE_THREADS 256
+#define PRE_BINS 4096
+#define PRE_WORDS (2 * PRE_BINS + 2)
+
+// bin d with count(bins > d) < need <= count(bins >= d); returns d, *left = need - count(bins > d)
+__device__ int pre_find_bin(const unsigned* __restrict__ hist, unsigned need, unsigned* left, unsigned* s_part, int* s_res) {
+    const int tid = threadIdx.x;
+    unsigned sum = 0;
+    for (int i = 0; i < PRE_BINS / PRE_THREADS; ++i) sum += hist[tid * (PRE_BINS / PRE_THREADS) + i];
+    __syncthreads();
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        unsigned cum = 0;
+        int t = PRE_THREADS - 1;
+        for (; t > 0; --t) {
+            if (cum + s_part[t] >= need) break;
+            cum += s_part[t];
+        }
+        int d = t * (PRE_BINS / PRE_THREADS) + (PRE_BINS / PRE_THREADS) - 1;
+        for (; d > t * (PRE_BINS / PRE_THREADS); --d) {
+            if (cum + hist[d] >= need) break;
+            cum += hist[d];
+        }
+        s_res[0] = d;
+        s_res[1] = (int)(need - cum);
+    }
+    __syncthreads();
+    *left = (unsigned)s_res[1];
+    return s_res[0];
+}
+
+// pass 0: hist1 over key >> 20;  pass 1: hist2 over (key >> 8) & 4095 inside the threshold bin of hist1
+__global__ __launch_bounds__(PRE_THREADS) void topk_hist_kernel(const PropArgs p, const int pass) {
+    __shared__ unsigned hist[PRE_BINS];
+    __shared__ unsigned s_part[PRE_THREADS];
+    __shared__ int s_res[2];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    unsigned* pre = p.pre_ws + (int64_t)b * PRE_WORDS;
+    const float* sc = p.probs + (int64_t)b * p.A * 2 + 1;
+    unsigned b1 = 0, left = 0;
+    if (pass == 1) b1 = (unsigned)pre_find_bin(pre, (unsigned)p.K, &left, s_part, s_res);
+    for (int i = tid; i < PRE_BINS; i += PRE_THREADS) hist[i] = 0;
+    __syncthreads();
+    for (int a = blockIdx.x * PRE_THREADS + tid; a < p.A; a += gridDim.x * PRE_THREADS) {
+        const unsigned u = f2key(sc[(int64_t)a * 2]);
+        if (pass == 0) atomicAdd(&hist[u >> 20], 1u);
+        else if ((u >> 20) == b1) atomicAdd(&hist[(u >> 8) & (PRE_BINS - 1)], 1u);
+    }
+    __syncthreads();
+    unsigned* out = pre + pass * PRE_BINS;
+    for (int i = tid; i < PRE_BINS; i += PRE_THREADS)
+        if (hist[i]) atomicAdd(&out[i], hist[i]);
+}
+
+__global__ __launch_bounds__(PRE_THREADS) void topk_collect_kernel(const PropArgs p) {
+    __shared__ unsigned s_part[PRE_THREADS];
+    __shared__ int s_res[2];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    unsigned* pre = p.pre_ws + (int64_t)b * PRE_WORDS;
+    const float* sc = p.probs + (int64_t)b * p.A * 2 + 1;
+    unsigned need1 = 0, need2 = 0;
+    const unsigned b1 = (unsigned)pre_find_bin(pre, (unsigned)p.K, &need1, s_part, s_res);
+    const unsigned b2 = (unsigned)pre_find_bin(pre + PRE_BINS, need1, &need2, s_part, s_res);
+    const unsigned t24 = (b1 << 12) | b2;
+    const unsigned count = (unsigned)p.K - need2 + pre[PRE_BINS + b2];     // anchors with key >> 8 >= t24
+    if (blockIdx.x == 0 && tid == 0) pre[2 * PRE_BINS + 1] = count;
+    if (count > SORT_CAP) return;                                          // the sorter selects by itself
+    unsigned long long* cand = p.cand_ws + (int64_t)b * SORT_CAP;
+    for (int a = blockIdx.x * PRE_THREADS + tid; a < p.A; a += gridDim.x * PRE_THREADS) {
+        const unsigned u = f2key(sc[(int64_t)a * 2]);
+        if ((u >> 8) >= t24) cand[atomicAdd(&pre[2 * PRE_BINS], 1u)] = ((unsigned long long)(~u) << 32) | (unsigned)a;
+    }
+}
 
 __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const PropArgs p) {
     __shared__ unsigned long long keys[SORT_CAP];
@@ -39,11 +124,14 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
     const float* sc = p.probs + (int64_t)b * p.A * 2 + 1;     // foreground probability, stride 2
     const int A = p.A, K = p.K;
 
+    const unsigned ncand = p.pre_groups ? p.pre_ws[(int64_t)b * PRE_WORDS + 2 * PRE_BINS + 1] : ~0u;
+    const bool preselected = ncand <= SORT_CAP;     // workgroup-uniform: the pre-selection's candidates only need sorting
+
     // ---- radix select: largest K keys ------------------------------------------------------------
     if (tid == 0) { s_prefix = 0; s_need = (unsigned)K; }
     __syncthreads();
     unsigned cnt_eq = 0;
-    for (int pass = 0; pass < 4; ++pass) {
+    for (int pass = 0; pass < 4 && !preselected; ++pass) {
         const int shift = 24 - 8 * pass;
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
@@ -77,7 +165,11 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
     if (tid == 0) { s_count = 0; s_base = 0; }
     __syncthreads();
     const bool ordered = cnt_eq > need_eq;      // more ties than slots: lowest anchor index first
-    for (int a0 = 0; a0 < A; a0 += K1_THREADS) {
+    if (preselected) {                          // >= K candidates, every one of the top K among them: sort them all
+        const unsigned long long* cand = p.cand_ws + (int64_t)b * SORT_CAP;
+        for (int i = tid; i < (int)ncand; i += K1_THREADS) keys[i] = cand[i];
+    }
+    for (int a0 = 0; a0 < A && !preselected; a0 += K1_THREADS) {
         const int a = a0 + tid;
         unsigned u = 0;
         bool gt = false, eq = false;
@@ -115,7 +207,8 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
 
     // ---- bitonic sort (ascending 64-bit keys == score descending, index ascending) ----------------
     int n = 1;
-    while (n < K) n <<= 1;
+    const int nsort = preselected && (int)ncand > K ? (int)ncand : K;
+    while (n < nsort) n <<= 1;
     for (int size = 2; size <= n; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             for (int t = tid; t < (n >> 1); t += K1_THREADS) {
@@ -244,7 +337,8 @@ static inline int prop_k(const mrcnn_proposal_desc* d) { return d->pre_nms_limit
 extern "C" size_t mrcnn_proposal_workspace(const mrcnn_proposal_desc* d) {
     if (!d || d->B <= 0 || d->A <= 0) return 0;
     size_t K = (size_t)prop_k(d), nw = (K + 63) / 64;
-    return (size_t)d->B * (K * 4 * sizeof(float) + K * nw * sizeof(unsigned long long)) + 256;
+    return (size_t)d->B * (K * 4 * sizeof(float) + K * nw * sizeof(unsigned long long) + SORT_CAP * sizeof(unsigned long long) +
+                           PRE_WORDS * sizeof(unsigned)) + 512;
 }
 
 extern "C" int mrcnn_proposal_fwd(const mrcnn_proposal_desc* d, const float* rpn_probs, const float* rpn_bbox,
@@ -263,7 +357,17 @@ extern "C" int mrcnn_proposal_fwd(const mrcnn_proposal_desc* d, const float* rpn
     uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
     a.boxes_ws = reinterpret_cast<float*>(base);
     a.mask_ws = reinterpret_cast<unsigned long long*>(base + (size_t)d->B * K * 4 * sizeof(float));
+    a.cand_ws = a.mask_ws + (size_t)d->B * K * a.nwords;
+    a.pre_ws = reinterpret_cast<unsigned*>(a.cand_ws + (size_t)d->B * SORT_CAP);
     hipStream_t s = (hipStream_t)stream;
+    // pre-selection over many workgroups when one workgroup would have to walk > 32 anchors per thread four times
+    a.pre_groups = d->A >= 32 * K1_THREADS ? (int)((d->A + 4095) / 4096 < 64 ? (d->A + 4095) / 4096 : 64) : 0;
+    if (a.pre_groups) {
+        if (hipMemsetAsync(a.pre_ws, 0, (size_t)d->B * PRE_WORDS * sizeof(unsigned), s) != hipSuccess) return MRCNN_ERR_LAUNCH;
+        hipLaunchKernelGGL(topk_hist_kernel, dim3(a.pre_groups, d->B), dim3(PRE_THREADS), 0, s, a, 0);
+        hipLaunchKernelGGL(topk_hist_kernel, dim3(a.pre_groups, d->B), dim3(PRE_THREADS), 0, s, a, 1);
+        hipLaunchKernelGGL(topk_collect_kernel, dim3(a.pre_groups, d->B), dim3(PRE_THREADS), 0, s, a);
+    }
     hipLaunchKernelGGL(select_sort_decode_kernel, dim3(d->B), dim3(K1_THREADS), 0, s, a);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(a.nwords, a.nwords, d->B), dim3(64), 0, s, a);
     hipLaunchKernelGGL(nms_scan_kernel, dim3(d->B), dim3(64), 0, s, a);

@@ -594,3 +594,26 @@ def test_conv_dgrad_fused_with_epilogue_backward(dev, k, res):
     if k == 1:          # 4 images, K = 128: neither LDS-DMA tiles nor a split-K plan -> the caller must use the two calls
         small = ops.conv2d_dgrad_ep(dz[:4], wt, pad, below_out[:4], below_z[:4], scale, mean, rstd, sums[0], sums[1], sums[2], 1)
         assert small is None
+
+
+def test_proposal_topk_preselection_fallback_on_massive_ties(dev):
+    """A >= 32768 anchors go through the multi-workgroup pre-selection; when (almost) all scores are equal the
+    candidates cannot be narrowed below the sorter's capacity and the single-workgroup selection takes over --
+    top_k's tie rule (lowest anchor index first) must hold either way."""
+    ops = _ops()
+    rng = np.random.default_rng(123)
+    A, limit, count = 40000, 6000, 50
+    cfg = _cfg()
+    ctr = rng.uniform(0, 1, (A, 2)); sz = np.exp(rng.uniform(np.log(0.02), np.log(0.5), (A, 2)))
+    anchors = np.concatenate([ctr - sz / 2, ctr + sz / 2], 1).astype(np.float32)
+    fg = np.full((2, A), 0.5, np.float32)
+    fg[0, 100:300] = 0.9                                   # image 0: 200 distinct leaders, then 39 800 ties
+    fg[1, :] = np.where(rng.uniform(0, 1, A) < 0.1, 0.75, 0.25)      # image 1: ~4000 at 0.75, the rest tie at 0.25
+    probs = np.stack([1 - fg, fg], -1).astype(np.float32)
+    deltas = _rand(rng, 2, A, 4, scale=0.1)
+    _, top_idx, _, _, _ = ops.proposals(torch.tensor(probs, device=dev), torch.tensor(deltas, device=dev),
+                                        torch.tensor(anchors, device=dev), limit, count, 0.7, cfg.RPN_BBOX_STD_DEV, debug=True)
+    torch.cuda.synchronize()
+    for b in range(2):
+        ref = orc.tf_top_k_indices(fg[b], limit)
+        assert np.array_equal(top_idx[b].cpu().numpy(), ref.astype(np.int32))
