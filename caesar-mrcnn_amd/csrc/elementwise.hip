@@ -434,10 +434,34 @@ extern "C" int mrcnn_mask_out_bwd(const float* d_mask_out, const float* mask_out
     return mrcnn_launch_status();
 }
 
-// Strided row copy on the DMA path (no kernel): `rows` rows of `row_bytes` bytes.
+// Strided row copy / zero fill as KERNELS whenever sizes and pointers are 4-byte multiples (every use in this
+// package): these calls may sit inside a HIP-graph capture (infer_graphed), and a captured memset node proved
+// unreliable inside a large graph (stale counters on replay), so nothing on the captured path uses memcpy / memset nodes.
+__global__ void copy2d_kernel(unsigned* dst, size_t dst_pitch_w, const unsigned* __restrict__ src, size_t src_pitch_w,
+                              size_t row_w, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / row_w, c = i - r * row_w;
+        dst[r * dst_pitch_w + c] = src[r * src_pitch_w + c];
+    }
+}
+
+__global__ void fill_zero_kernel(f32x4* dst, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        dst[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
 extern "C" int mrcnn_copy2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t row_bytes,
                             size_t rows, void* stream) {
     if (!dst || !src || row_bytes == 0 || rows == 0 || dst_pitch < row_bytes || src_pitch < row_bytes) return MRCNN_ERR_ARG;
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src) | dst_pitch | src_pitch | row_bytes;
+    if ((bits & 3) == 0) {
+        const size_t total = rows * (row_bytes / 4);
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 65536) blocks = 65536;
+        hipLaunchKernelGGL(copy2d_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (unsigned*)dst, dst_pitch / 4,
+                           (const unsigned*)src, src_pitch / 4, row_bytes / 4, total);
+        return mrcnn_launch_status();
+    }
     hipError_t e = hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, row_bytes, rows, hipMemcpyDeviceToDevice,
                                     (hipStream_t)stream);
     return e == hipSuccess ? MRCNN_OK : MRCNN_ERR_LAUNCH;
@@ -445,6 +469,13 @@ extern "C" int mrcnn_copy2d(void* dst, size_t dst_pitch, const void* src, size_t
 
 extern "C" int mrcnn_fill_zero(void* dst, size_t bytes, void* stream) {
     if (!dst || bytes == 0) return MRCNN_ERR_ARG;
+    if (((reinterpret_cast<uintptr_t>(dst) | bytes) & 15) == 0) {
+        const size_t n4 = bytes / 16;
+        size_t blocks = (n4 + 255) / 256;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(fill_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (f32x4*)dst, n4);
+        return mrcnn_launch_status();
+    }
     return hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream) == hipSuccess ? MRCNN_OK : MRCNN_ERR_LAUNCH;
 }
 

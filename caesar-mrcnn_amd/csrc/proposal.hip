@@ -27,29 +27,35 @@ struct PropArgs {
     float* rois; int32_t* top_idx; int32_t* keep_idx; int32_t* num_keep;
     float* boxes_ws;               // [B, K, 4]
     unsigned long long* mask_ws;   // [B, K, nwords]
-    unsigned* pre_ws;              // [B, PRE_WORDS]: hist1[4096], hist2[4096], counter, candidate count
+    unsigned* pre_ws;              // [B, PRE_WORDS]: three histograms, per-workgroup tie counts, counter, candidate count
     unsigned long long* cand_ws;   // [B, SORT_CAP] candidate keys of the multi-workgroup pre-selection
     int pre_groups;                // workgroups per image of the pre-selection (0 = off)
     int B, A, K, proposal_count, nwords;
     float thr, s0, s1, s2, s3;
 };
 
-// ---- multi-workgroup pre-selection ----------------------------------------------------------------------
-// One workgroup walking all A scores four times is what the selection costs at large images (A = 261 888 at
-// 1024^2: 0.9 ms).  Three small launches over many workgroups narrow the field first: a 12-bit histogram of the
-// key's top bits (LDS per workgroup, then global atomics), a second 12-bit histogram inside the threshold bin, and a
-// collection of every anchor whose top 24 key bits reach the 24-bit threshold -- all of the top K plus the few
-// anchors that share the threshold's 24-bit prefix.  If those fit the sorter (<= SORT_CAP) the single-workgroup kernel
-// only sorts them (exact, ties by anchor index as before); otherwise it runs its own full selection.
+// ---- multi-workgroup selection ----------------------------------------------------------------------------
+// One workgroup walking all A scores four times is what the selection costs on large images (A = 261 888 at 1024^2:
+// 0.9 ms).  For A >= 32 768 the exact selection runs over many workgroups in five small launches:
+//   topk_hist_kernel x3   histograms of key bits [31:20], [19:8], [7:0] (LDS per workgroup, then global atomics), each
+//                         restricted to the threshold prefix found in the previous ones -> the K-th largest key T and
+//                         how many anchors equal to T belong to the top K
+//   topk_ties_kernel      anchors == T per workgroup; workgroups own CONTIGUOUS anchor ranges, so tie order = index order
+//   topk_collect_kernel   keys > T (any order) and the first need_eq ties in anchor-index order (tf.nn.top_k's tie
+//                         rule), exactly K keys -> the single-workgroup kernel only sorts and decodes them.
 #define PRE_THREADS 256
 #define PRE_BINS 4096
-#define PRE_WORDS (2 * PRE_BINS + 2)
+#define PRE_MAXG 64
+#define PRE_TIE (2 * PRE_BINS + 256)               // word offsets inside pre_ws
+#define PRE_COUNTER (PRE_TIE + PRE_MAXG)
+#define PRE_NCAND (PRE_COUNTER + 1)
+#define PRE_WORDS (PRE_NCAND + 1)
 
-// bin d with count(bins > d) < need <= count(bins >= d); returns d, *left = need - count(bins > d)
-__device__ int pre_find_bin(const unsigned* __restrict__ hist, unsigned need, unsigned* left, unsigned* s_part, int* s_res) {
-    const int tid = threadIdx.x;
+// bin d of hist[0..nbins) with count(bins > d) < need <= count(bins >= d); *left = need - count(bins > d)
+__device__ int pre_find_bin(const unsigned* __restrict__ hist, int nbins, unsigned need, unsigned* left, unsigned* s_part, int* s_res) {
+    const int tid = threadIdx.x, per = nbins / PRE_THREADS;       // nbins = 4096 or 256
     unsigned sum = 0;
-    for (int i = 0; i < PRE_BINS / PRE_THREADS; ++i) sum += hist[tid * (PRE_BINS / PRE_THREADS) + i];
+    for (int i = 0; i < per; ++i) sum += hist[tid * per + i];
     __syncthreads();
     s_part[tid] = sum;
     __syncthreads();
@@ -60,8 +66,8 @@ __device__ int pre_find_bin(const unsigned* __restrict__ hist, unsigned need, un
             if (cum + s_part[t] >= need) break;
             cum += s_part[t];
         }
-        int d = t * (PRE_BINS / PRE_THREADS) + (PRE_BINS / PRE_THREADS) - 1;
-        for (; d > t * (PRE_BINS / PRE_THREADS); --d) {
+        int d = t * per + per - 1;
+        for (; d > t * per; --d) {
             if (cum + hist[d] >= need) break;
             cum += hist[d];
         }
@@ -73,7 +79,23 @@ __device__ int pre_find_bin(const unsigned* __restrict__ hist, unsigned need, un
     return s_res[0];
 }
 
-// pass 0: hist1 over key >> 20;  pass 1: hist2 over (key >> 8) & 4095 inside the threshold bin of hist1
+__global__ void topk_zero_kernel(unsigned* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
+
+struct PreThreshold { unsigned prefix, shift, need; };   // keys with (key >> shift) == prefix are still undecided
+
+// thresholds of the first `passes` histograms (workgroup-wide call)
+__device__ PreThreshold pre_threshold(const unsigned* pre, int K, int passes, unsigned* s_part, int* s_res) {
+    PreThreshold t;
+    t.prefix = 0; t.shift = 32; t.need = (unsigned)K;
+    if (passes >= 1) { const unsigned b1 = (unsigned)pre_find_bin(pre, PRE_BINS, t.need, &t.need, s_part, s_res); t.prefix = b1; t.shift = 20; }
+    if (passes >= 2) { const unsigned b2 = (unsigned)pre_find_bin(pre + PRE_BINS, PRE_BINS, t.need, &t.need, s_part, s_res); t.prefix = (t.prefix << 12) | b2; t.shift = 8; }
+    if (passes >= 3) { const unsigned b3 = (unsigned)pre_find_bin(pre + 2 * PRE_BINS, 256, t.need, &t.need, s_part, s_res); t.prefix = (t.prefix << 8) | b3; t.shift = 0; }
+    return t;
+}
+
 __global__ __launch_bounds__(PRE_THREADS) void topk_hist_kernel(const PropArgs p, const int pass) {
     __shared__ unsigned hist[PRE_BINS];
     __shared__ unsigned s_part[PRE_THREADS];
@@ -81,38 +103,70 @@ __global__ __launch_bounds__(PRE_THREADS) void topk_hist_kernel(const PropArgs p
     const int b = blockIdx.y, tid = threadIdx.x;
     unsigned* pre = p.pre_ws + (int64_t)b * PRE_WORDS;
     const float* sc = p.probs + (int64_t)b * p.A * 2 + 1;
-    unsigned b1 = 0, left = 0;
-    if (pass == 1) b1 = (unsigned)pre_find_bin(pre, (unsigned)p.K, &left, s_part, s_res);
-    for (int i = tid; i < PRE_BINS; i += PRE_THREADS) hist[i] = 0;
+    const PreThreshold t = pre_threshold(pre, p.K, pass, s_part, s_res);
+    const int nbins = pass == 2 ? 256 : PRE_BINS;
+    const int bshift = pass == 0 ? 20 : (pass == 1 ? 8 : 0);
+    for (int i = tid; i < nbins; i += PRE_THREADS) hist[i] = 0;
     __syncthreads();
     for (int a = blockIdx.x * PRE_THREADS + tid; a < p.A; a += gridDim.x * PRE_THREADS) {
         const unsigned u = f2key(sc[(int64_t)a * 2]);
-        if (pass == 0) atomicAdd(&hist[u >> 20], 1u);
-        else if ((u >> 20) == b1) atomicAdd(&hist[(u >> 8) & (PRE_BINS - 1)], 1u);
+        if (pass == 0 || (u >> t.shift) == t.prefix) atomicAdd(&hist[(u >> bshift) & (nbins - 1)], 1u);
     }
     __syncthreads();
     unsigned* out = pre + pass * PRE_BINS;
-    for (int i = tid; i < PRE_BINS; i += PRE_THREADS)
+    for (int i = tid; i < nbins; i += PRE_THREADS)
         if (hist[i]) atomicAdd(&out[i], hist[i]);
 }
 
-__global__ __launch_bounds__(PRE_THREADS) void topk_collect_kernel(const PropArgs p) {
+// workgroup g owns anchors [g*chunk, (g+1)*chunk)
+__global__ __launch_bounds__(PRE_THREADS) void topk_ties_kernel(const PropArgs p, const int chunk) {
     __shared__ unsigned s_part[PRE_THREADS];
     __shared__ int s_res[2];
-    const int b = blockIdx.y, tid = threadIdx.x;
+    __shared__ unsigned s_cnt;
+    const int b = blockIdx.y, tid = threadIdx.x, g = blockIdx.x;
     unsigned* pre = p.pre_ws + (int64_t)b * PRE_WORDS;
     const float* sc = p.probs + (int64_t)b * p.A * 2 + 1;
-    unsigned need1 = 0, need2 = 0;
-    const unsigned b1 = (unsigned)pre_find_bin(pre, (unsigned)p.K, &need1, s_part, s_res);
-    const unsigned b2 = (unsigned)pre_find_bin(pre + PRE_BINS, need1, &need2, s_part, s_res);
-    const unsigned t24 = (b1 << 12) | b2;
-    const unsigned count = (unsigned)p.K - need2 + pre[PRE_BINS + b2];     // anchors with key >> 8 >= t24
-    if (blockIdx.x == 0 && tid == 0) pre[2 * PRE_BINS + 1] = count;
-    if (count > SORT_CAP) return;                                          // the sorter selects by itself
+    const PreThreshold t = pre_threshold(pre, p.K, 3, s_part, s_res);
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    const int a1 = min(p.A, (g + 1) * chunk);
+    unsigned mine = 0;
+    for (int a = g * chunk + tid; a < a1; a += PRE_THREADS) mine += f2key(sc[(int64_t)a * 2]) == t.prefix;
+    atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (tid == 0) pre[PRE_TIE + g] = s_cnt;
+}
+
+__global__ __launch_bounds__(PRE_THREADS) void topk_collect_kernel(const PropArgs p, const int chunk) {
+    __shared__ unsigned s_part[PRE_THREADS];
+    __shared__ int s_res[2];
+    __shared__ unsigned s_wsum[PRE_THREADS / 64];
+    const int b = blockIdx.y, tid = threadIdx.x, g = blockIdx.x;
+    unsigned* pre = p.pre_ws + (int64_t)b * PRE_WORDS;
+    const float* sc = p.probs + (int64_t)b * p.A * 2 + 1;
+    const PreThreshold t = pre_threshold(pre, p.K, 3, s_part, s_res);
+    const unsigned T = t.prefix, need_eq = t.need;
+    unsigned base = 0;                                   // ties in the workgroups before this one
+    for (int q = 0; q < g; ++q) base += pre[PRE_TIE + q];
+    if (g == 0 && tid == 0) pre[PRE_NCAND] = (unsigned)p.K;
     unsigned long long* cand = p.cand_ws + (int64_t)b * SORT_CAP;
-    for (int a = blockIdx.x * PRE_THREADS + tid; a < p.A; a += gridDim.x * PRE_THREADS) {
-        const unsigned u = f2key(sc[(int64_t)a * 2]);
-        if ((u >> 8) >= t24) cand[atomicAdd(&pre[2 * PRE_BINS], 1u)] = ((unsigned long long)(~u) << 32) | (unsigned)a;
+    const int a1 = min(p.A, (g + 1) * chunk);
+    for (int a0 = g * chunk; a0 < a1; a0 += PRE_THREADS) {
+        const int a = a0 + tid;
+        unsigned u = 0;
+        bool gt = false, eq = false;
+        if (a < a1) { u = f2key(sc[(int64_t)a * 2]); gt = u > T; eq = u == T; }
+        // rank of this tie among all ties in anchor order
+        const unsigned long long bal = __ballot(eq);
+        const unsigned wrank = __popcll(bal & ((1ull << (tid & 63)) - 1ull));
+        if ((tid & 63) == 0) s_wsum[tid >> 6] = (unsigned)__popcll(bal);
+        __syncthreads();
+        unsigned before = base, tot = 0;
+        for (int w = 0; w < PRE_THREADS / 64; ++w) { if (w < (tid >> 6)) before += s_wsum[w]; tot += s_wsum[w]; }
+        if (gt || (eq && before + wrank < need_eq))
+            cand[atomicAdd(&pre[PRE_COUNTER], 1u)] = ((unsigned long long)(~u) << 32) | (unsigned)a;
+        base += tot;
+        __syncthreads();
     }
 }
 
@@ -124,7 +178,7 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
     const float* sc = p.probs + (int64_t)b * p.A * 2 + 1;     // foreground probability, stride 2
     const int A = p.A, K = p.K;
 
-    const unsigned ncand = p.pre_groups ? p.pre_ws[(int64_t)b * PRE_WORDS + 2 * PRE_BINS + 1] : ~0u;
+    const unsigned ncand = p.pre_groups ? p.pre_ws[(int64_t)b * PRE_WORDS + PRE_NCAND] : ~0u;
     const bool preselected = ncand <= SORT_CAP;     // workgroup-uniform: the pre-selection's candidates only need sorting
 
     // ---- radix select: largest K keys ------------------------------------------------------------
@@ -361,12 +415,15 @@ extern "C" int mrcnn_proposal_fwd(const mrcnn_proposal_desc* d, const float* rpn
     a.pre_ws = reinterpret_cast<unsigned*>(a.cand_ws + (size_t)d->B * SORT_CAP);
     hipStream_t s = (hipStream_t)stream;
     // pre-selection over many workgroups when one workgroup would have to walk > 32 anchors per thread four times
-    a.pre_groups = d->A >= 32 * K1_THREADS ? (int)((d->A + 4095) / 4096 < 64 ? (d->A + 4095) / 4096 : 64) : 0;
+    a.pre_groups = d->A >= 32 * K1_THREADS ? (int)((d->A + 4095) / 4096 < PRE_MAXG ? (d->A + 4095) / 4096 : PRE_MAXG) : 0;
     if (a.pre_groups) {
-        if (hipMemsetAsync(a.pre_ws, 0, (size_t)d->B * PRE_WORDS * sizeof(unsigned), s) != hipSuccess) return MRCNN_ERR_LAUNCH;
-        hipLaunchKernelGGL(topk_hist_kernel, dim3(a.pre_groups, d->B), dim3(PRE_THREADS), 0, s, a, 0);
-        hipLaunchKernelGGL(topk_hist_kernel, dim3(a.pre_groups, d->B), dim3(PRE_THREADS), 0, s, a, 1);
-        hipLaunchKernelGGL(topk_collect_kernel, dim3(a.pre_groups, d->B), dim3(PRE_THREADS), 0, s, a);
+        const int chunk = (d->A + a.pre_groups - 1) / a.pre_groups;
+        const dim3 grid(a.pre_groups, d->B);
+        const int nz = d->B * PRE_WORDS;            // a kernel, not a memset node: the call may be inside a graph capture
+        hipLaunchKernelGGL(topk_zero_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, s, a.pre_ws, nz);
+        for (int pass = 0; pass < 3; ++pass) hipLaunchKernelGGL(topk_hist_kernel, grid, dim3(PRE_THREADS), 0, s, a, pass);
+        hipLaunchKernelGGL(topk_ties_kernel, grid, dim3(PRE_THREADS), 0, s, a, chunk);
+        hipLaunchKernelGGL(topk_collect_kernel, grid, dim3(PRE_THREADS), 0, s, a, chunk);
     }
     hipLaunchKernelGGL(select_sort_decode_kernel, dim3(d->B), dim3(K1_THREADS), 0, s, a);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(a.nwords, a.nwords, d->B), dim3(64), 0, s, a);

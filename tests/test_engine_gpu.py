@@ -451,3 +451,24 @@ def test_fused_dgrad_epilogue_equals_unfused(dev):
     np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-6)       # the loss reductions use float atomics
     scale = np.abs(res[1][1]).max()
     assert np.abs(res[0][1] - res[1][1]).max() <= 2e-5 * scale and scale > 0
+
+
+def test_graph_replay_with_multiworkgroup_topk_512(dev):
+    """512x512 (A = 65 472 anchors >= 32 768): the proposal layer selects its top-k over many workgroups; several
+    HIP-graph replays must return exactly what the eager launches return (the selection zeroes its counters itself --
+    with a kernel, a captured hipMemsetAsync node was not reliable inside the large graph)."""
+    from caesar_mrcnn_amd.config import run_py_config
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = run_py_config(backbone="resnet50", imgsize=512, mode="inference")
+    model = MaskRCNN("inference", cfg, "/tmp/mrcnn_logs", device=dev, seed=5)
+    rng = np.random.default_rng(9)
+    x = torch.tensor(rng.uniform(0, 255, (1, 512, 512, 3)).astype(np.float32), device=dev)
+    w = torch.tensor([[0., 0., 1., 1.]], device=dev)
+    keys = ("rpn_rois", "detections", "mrcnn_mask")
+    eager = {k: model.engine.infer(x, w)[k].cpu().numpy().copy() for k in keys}
+    for rep in range(4):
+        out = model.engine.infer_graphed(x, w)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert np.array_equal(out[k].cpu().numpy(), eager[k]), (k, rep)
+    assert np.abs(eager["rpn_rois"]).sum() > 0

@@ -12,8 +12,10 @@ m = MaskRCNN("inference", cfg, "/tmp/x", device=torch.device("cuda:0"))
 x = torch.rand(1, size, size, 3, device="cuda") * 255
 w = torch.tensor([[0., 0., 1., 1.]], device="cuda")
 for fn, name in ((m.engine.infer, "eager"), (m.engine.infer_graphed, "graph")):
-    for _ in range(3):
+    for i in range(3):
         fn(x, w)
+        torch.cuda.synchronize()
+        print("warm", name, i, flush=True)
     torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(10):
