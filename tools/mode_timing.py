@@ -14,8 +14,12 @@ model = MaskRCNN("training", cfg, "/tmp/mrcnn_bench_logs", device=dev, seed=0)
 model.compile(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM)
 inp = model._to_device(bench.synthetic_batch(cfg, nimg, seed=1234))
 eng = model.engine
+only = sys.argv[3] if len(sys.argv) > 3 else ""            # e.g. "sparse-f32": profile a single mode
 for sparse in (False, True):
     for hd in (None, torch.float16, torch.bfloat16):
+        tag = ("sparse" if sparse else "dense") + "-" + {None: "f32", torch.float16: "f16", torch.bfloat16: "bf16"}[hd]
+        if only and tag != only:
+            continue
         eng.sparse_mask_bwd, eng.head_dtype = sparse, hd
         for _ in range(3):
             eng.forward_backward(*inp); eng.apply_gradients(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM, 1)
