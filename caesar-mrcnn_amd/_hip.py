@@ -92,6 +92,8 @@ _SIGNATURES = {
     "mrcnn_conv2d_dgrad_ep": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, C.POINTER(BwdEpilogue), _P, C.c_size_t, _P]),
     "mrcnn_conv2d_wgrad_h16_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "mrcnn_conv2d_wgrad_h16": (C.c_int, [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_float, _P]),
+    "mrcnn_mask_out_fwd_h16": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "mrcnn_mask_out_bwd_h16": (C.c_int, [C.c_int] + [_P] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "mrcnn_weights_to_h16": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_cast_to_h16": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "mrcnn_epilogue_bwd_h16": (C.c_int, [C.c_int] + [_P] * 10 + [C.c_int64, C.c_int, C.c_int, C.c_float, _P]),

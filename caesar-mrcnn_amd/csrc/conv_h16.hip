@@ -34,6 +34,7 @@ struct ConvH16Args {
     const void* x; const void* wt; const float* bias; const float* scale; const float* shift; void* out; void* z;
     int N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW, act, M, Ktot;
     unsigned x_shift, x_records, w_records;
+    int out_mode, cmod; long long ons, ohs, ows;     // MRCNN_OUT_DECONV2: pixel-shuffle store of the 2x2 transposed conv
 };
 
 #define H16_OOB_OFFSET 0xFFFFFFF0u
@@ -159,11 +160,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h16_kernel(const ConvH16Args 
     // ---- epilogue: bias, frozen-BN affine, activation in float32; one rounding to 16 bits --------------
     T* out = (T*)p.out;
     T* zo = (T*)p.z;
+    const bool deconv = p.out_mode == MRCNN_OUT_DECONV2;        // column n = (a*2+b)*cmod + c -> pixel (2oh+a, 2ow+b), channel c
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + wn * 64 + b * 32 + li;
-        const float bias = p.bias ? p.bias[n] : 0.f;
-        const float sc = p.scale ? p.scale[n] : 1.f, sh = p.scale ? p.shift[n] : 0.f;
+        const int ab = deconv ? n / p.cmod : 0;
+        const int c = deconv ? n - ab * p.cmod : n;
+        const float bias = p.bias ? p.bias[c] : 0.f;
+        const float sc = p.scale ? p.scale[c] : 1.f, sh = p.scale ? p.shift[c] : 0.f;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const int mb = m0 + wm * 128 + a * 32 + 4 * lh;
@@ -172,7 +176,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h16_kernel(const ConvH16Args 
                 const int m = mb + (r & 3) + 8 * (r >> 2);
                 if (m >= p.M) continue;
                 const float zv = acc[a][b][r] + bias;
-                const long long addr = (long long)m * p.Cout + n;
+                long long addr = (long long)m * p.Cout + n;
+                if (deconv) {
+                    const int ni = m / ohw, rem = m - ni * ohw;
+                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                    addr = (long long)ni * p.ons + (long long)(2 * oh + (ab >> 1)) * p.ohs + (long long)(2 * ow + (ab & 1)) * p.ows + c;
+                }
                 if (zo) zo[addr] = (T)zv;
                 float y = sc * zv + sh;
                 if (p.act == MRCNN_ACT_RELU) y = fmaxf(y, 0.f);
@@ -180,6 +189,142 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h16_kernel(const ConvH16Args 
                 out[addr] = (T)y;
             }
         }
+    }
+}
+
+// mrcnn_mask (1x1 conv to C <= 16 class maps) + sigmoid on the 16-bit deconvolution output: one wave per pixel group,
+// a lane owns 4 of the Cd channels (8-byte load), dot products reduced across the wave, float32 result [npix, C].
+template <typename T>
+__global__ __launch_bounds__(256) void mask_out_fwd_h16_kernel(const T* __restrict__ up, const float* __restrict__ wm,
+                                                               const float* __restrict__ bm, float* mask, long long npix, int Cd, int C) {
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float w[4][16];
+    const int nseg = Cd / 256;                                   // 256 channels per wave pass
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e][c] = (c < C && nseg == 1) ? wm[(long long)(lane * 4 + e) * C + c] : 0.f;
+    const long long p0 = ((long long)blockIdx.x * 4 + wave) * 16;
+    for (int q = 0; q < 16; ++q) {
+        const long long pix = p0 + q;
+        if (pix >= npix) break;
+        float acc[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+        for (int sgm = 0; sgm < nseg; ++sgm) {
+            const t4 u = *(const t4*)(up + pix * Cd + sgm * 256 + lane * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float uf = (float)u[e];
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+                    if (c < C) acc[c] += uf * (nseg == 1 ? w[e][c] : wm[(long long)(sgm * 256 + lane * 4 + e) * C + c]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            if (c < C) acc[c] = wave_sum(acc[c]);
+        if (lane < C) {
+            float v = 0.f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) if (c == lane) v = acc[c];
+            v += bm ? bm[lane] : 0.f;
+            mask[pix * C + lane] = 1.f / (1.f + expf(-v));
+        }
+    }
+}
+
+// C <= 4 (the repo's 3 classes + background), Cd = 256: a 16-lane group owns one pixel (16 channels = 32 bytes per lane),
+// four pixels per wave at a time; the 4 dot products are reduced inside the group (4 xor steps).
+template <typename T>
+__global__ __launch_bounds__(256) void mask_out_fwd_h16_c4_kernel(const T* __restrict__ up, const float* __restrict__ wm,
+                                                                  const float* __restrict__ bm, float* mask, long long npix, int C) {
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    const int lane = threadIdx.x & 63, sub = lane & 15, grp = lane >> 4;
+    float w[16][4];
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[e][c] = c < C ? wm[(long long)(sub * 16 + e) * C + c] : 0.f;
+    const float bias = (sub < C && bm) ? bm[sub] : 0.f;
+    const long long wave0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;       // 64 pixels per wave
+    for (int it = 0; it < 16; ++it) {
+        const long long pix = wave0 + it * 4 + grp;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pix < npix) {
+            const t8 u0 = *(const t8*)(up + pix * 256 + sub * 16);
+            const t8 u1 = *(const t8*)(up + pix * 256 + sub * 16 + 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float a = (float)u0[e], b = (float)u1[e];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[c] += a * w[e][c] + b * w[8 + e][c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) acc[c] += __shfl_xor(acc[c], o, 64);
+        if (pix < npix && sub < C) {
+            const float v = (sub == 0 ? acc[0] : sub == 1 ? acc[1] : sub == 2 ? acc[2] : acc[3]) + bias;
+            mask[pix * C + sub] = 1.f / (1.f + expf(-v));
+        }
+    }
+}
+
+// mask_out_bwd_kernel on a 16-bit `up`: dzg is written in 16 bits, multiplied by the loss scale; sums stay float32.
+template <typename T, int CP>
+__global__ void mask_out_bwd_h16_kernel(const float* __restrict__ dmask, const float* __restrict__ mask, const T* __restrict__ up,
+                                        const float* __restrict__ wm, T* dzg, float* dWm, float* dbm, float* dbd, long long npix,
+                                        int H, int W, int Cd, int C, float lscale) {
+    constexpr int PPB = 128;
+    __shared__ __attribute__((aligned(16))) float sdz[PPB * CP];
+    const int ci = threadIdx.x;
+    const long long p0 = (long long)blockIdx.x * PPB;
+    const int np = (int)((npix - p0) < PPB ? (npix - p0) : PPB);
+    for (int i = ci; i < PPB * CP; i += blockDim.x) {
+        const int pl = i / CP, c = i - pl * CP;
+        float v = 0.f;
+        if (pl < np && c < C) {
+            const float g = dmask[(p0 + pl) * C + c], q = mask[(p0 + pl) * C + c];
+            v = g * q * (1.f - q);
+        }
+        sdz[i] = v;
+    }
+    float wrow[CP], aw[CP];
+#pragma unroll
+    for (int c = 0; c < CP; ++c) { wrow[c] = c < C ? wm[(long long)ci * C + c] : 0.f; aw[c] = 0.f; }
+    float abd = 0.f;
+    __syncthreads();
+    const int hw = H * W, W2 = W >> 1, H2 = H >> 1;
+    const T* upp = up + p0 * Cd + ci;
+#pragma unroll 4
+    for (int pl = 0; pl < np; ++pl) {
+        const float u = (float)upp[(long long)pl * Cd];
+        float d = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < CP; c4 += 4) {
+            const f32x4 z = *(const f32x4*)&sdz[pl * CP + c4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { d += z[e] * wrow[c4 + e]; aw[c4 + e] += u * z[e]; }
+        }
+        const float dzu = u > 0.f ? d : 0.f;
+        abd += dzu;
+        const long long pix = p0 + pl;
+        const long long n = pix / hw;
+        const int rem = (int)(pix - n * hw);
+        const int y = rem / W, x = rem - y * W;
+        dzg[(((n * H2 + (y >> 1)) * W2 + (x >> 1)) * 4 + ((y & 1) * 2 + (x & 1))) * Cd + ci] = (T)(dzu * lscale);
+    }
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
+        if (c < C) atomicAdd(&dWm[(long long)ci * C + c], aw[c]);
+    atomicAdd(&dbd[ci], abd);
+    if (ci < C) {
+        float s_ = 0.f;
+        for (int pl = 0; pl < np; ++pl) s_ += sdz[pl * CP + ci];
+        atomicAdd(&dbm[ci], s_);
     }
 }
 
@@ -534,8 +679,12 @@ extern "C" int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const v
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 ||
         d->OH <= 0 || d->OW <= 0 || d->KH * d->KW > 64)
         return MRCNN_ERR_ARG;
-    if (d->Cin % 32 || d->Cout % 128 || d->res_mode != MRCNN_RES_NONE || d->out_mode != MRCNN_OUT_NHWC || d->cmod != d->Cout)
-        return MRCNN_ERR_ARG;                                    // the shapes of the ROI heads; nothing else yet
+    if (d->Cin % 32 || d->Cout % 128 || d->res_mode != MRCNN_RES_NONE) return MRCNN_ERR_ARG;   // the shapes of the ROI heads
+    if (d->out_mode == MRCNN_OUT_DECONV2) {
+        if (d->Cout != 4 * d->cmod || d->cmod % 128 || z_out) return MRCNN_ERR_ARG;
+    } else if (d->out_mode != MRCNN_OUT_NHWC || d->cmod != d->Cout) {
+        return MRCNN_ERR_ARG;
+    }
     if (scale && !shift) return MRCNN_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(w_t) & 15)) return MRCNN_ERR_ARG;
     const long long M = (long long)d->N * d->OH * d->OW;
@@ -549,11 +698,62 @@ extern "C" int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const v
     a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.OH = d->OH; a.OW = d->OW; a.act = d->act;
     a.M = (int)M; a.Ktot = d->KH * d->KW * d->Cin;
     a.x_shift = (unsigned)shift_b; a.x_records = (unsigned)(xbytes + shift_b); a.w_records = (unsigned)wbytes;
+    a.out_mode = d->out_mode; a.cmod = d->cmod; a.ons = d->out_n_stride; a.ohs = d->out_h_stride; a.ows = d->out_w_stride;
     const unsigned blocks = (unsigned)(((M + 255) / 256) * (d->Cout / 128));
     if (dtype == MRCNN_DTYPE_F16)
         hipLaunchKernelGGL(conv_fwd_h16_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(conv_fwd_h16_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_mask_out_fwd_h16(int dtype, const void* up, const float* w_mask, const float* b_mask, float* mask_out,
+                                      int64_t npix, int Cd, int C, void* stream) {
+    if (!up || !w_mask || !mask_out || npix <= 0 || Cd < 256 || Cd % 256 || C < 1 || C > 16 || !h16_dtype_ok(dtype)) return MRCNN_ERR_ARG;
+    if (Cd == 256 && C <= 4) {
+        const unsigned blocks4 = (unsigned)cdiv64(npix, 256);
+        if (dtype == MRCNN_DTYPE_F16)
+            hipLaunchKernelGGL(mask_out_fwd_h16_c4_kernel<_Float16>, dim3(blocks4), dim3(256), 0, (hipStream_t)stream,
+                               (const _Float16*)up, w_mask, b_mask, mask_out, (long long)npix, C);
+        else
+            hipLaunchKernelGGL(mask_out_fwd_h16_c4_kernel<__bf16>, dim3(blocks4), dim3(256), 0, (hipStream_t)stream, (const __bf16*)up,
+                               w_mask, b_mask, mask_out, (long long)npix, C);
+        return mrcnn_launch_status();
+    }
+    const unsigned blocks = (unsigned)cdiv64(npix, 64);
+    if (dtype == MRCNN_DTYPE_F16)
+        hipLaunchKernelGGL(mask_out_fwd_h16_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)up,
+                           w_mask, b_mask, mask_out, (long long)npix, Cd, C);
+    else
+        hipLaunchKernelGGL(mask_out_fwd_h16_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)up, w_mask,
+                           b_mask, mask_out, (long long)npix, Cd, C);
+    return mrcnn_launch_status();
+}
+
+template <typename T>
+static void launch_mask_out_bwd_h16(const float* dm, const float* m, const void* up, const float* wm, void* dzg, float* dw, float* dbm,
+                                    float* dbd, long long npix, int H, int W, int Cd, int C, float ls, hipStream_t s) {
+    const dim3 grid((unsigned)cdiv64(npix, 128)), block(Cd);
+    if (C <= 4)
+        hipLaunchKernelGGL((mask_out_bwd_h16_kernel<T, 4>), grid, block, 0, s, dm, m, (const T*)up, wm, (T*)dzg, dw, dbm, dbd, npix, H, W, Cd, C, ls);
+    else if (C <= 8)
+        hipLaunchKernelGGL((mask_out_bwd_h16_kernel<T, 8>), grid, block, 0, s, dm, m, (const T*)up, wm, (T*)dzg, dw, dbm, dbd, npix, H, W, Cd, C, ls);
+    else
+        hipLaunchKernelGGL((mask_out_bwd_h16_kernel<T, 16>), grid, block, 0, s, dm, m, (const T*)up, wm, (T*)dzg, dw, dbm, dbd, npix, H, W, Cd, C, ls);
+}
+
+extern "C" int mrcnn_mask_out_bwd_h16(int dtype, const float* d_mask_out, const float* mask_out, const void* up, const float* w_mask,
+                                      void* dzg, float* dw_mask, float* db_mask, float* db_deconv, int64_t M, int H, int W, int Cd,
+                                      int C, float loss_scale, void* stream) {
+    if (!d_mask_out || !mask_out || !up || !w_mask || !dzg || !dw_mask || !db_mask || !db_deconv || !h16_dtype_ok(dtype)) return MRCNN_ERR_ARG;
+    if (M <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || Cd < 64 || Cd > 1024 || (Cd & 63) || C < 1 || C > 16) return MRCNN_ERR_ARG;
+    const long long npix = (long long)M * H * W;
+    if (dtype == MRCNN_DTYPE_F16)
+        launch_mask_out_bwd_h16<_Float16>(d_mask_out, mask_out, up, w_mask, dzg, dw_mask, db_mask, db_deconv, npix, H, W, Cd, C, loss_scale,
+                                          (hipStream_t)stream);
+    else
+        launch_mask_out_bwd_h16<__bf16>(d_mask_out, mask_out, up, w_mask, dzg, dw_mask, db_mask, db_deconv, npix, H, W, Cd, C, loss_scale,
+                                        (hipStream_t)stream);
     return mrcnn_launch_status();
 }
 

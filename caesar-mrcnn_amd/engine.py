@@ -233,6 +233,8 @@ class MaskRCNNEngine(object):
         for i in range(1, 5):
             op = self.op("mrcnn_mask_conv%d" % i)
             self._h16[op.name] = ops.weights_to_h16(op.w, self.head_dtype)
+        dc = self.op("mrcnn_mask_deconv")              # GEMM matrix [Cin, 4*Cd]: forward W^T and the data-gradient image
+        self._h16[dc.name] = ops.weights_to_h16(dc.w, self.head_dtype)
         self._h16_valid = True
 
     def join_wgrad(self):
@@ -401,6 +403,15 @@ class MaskRCNNEngine(object):
                 y = ops.conv2d_h16(h, self._h16[op.name][0], op.wshape, op.b, op.scale, op.shift, 1, "same", ACT_RELU, z_out=z)
                 ctxs.append((h, z, y, ACT_RELU) if train else None)
                 h = y
+            dc, mop = self.op("mrcnn_mask_deconv"), self.op("mrcnn_mask")
+            Cd = dc.wshape[3] // 4
+            C_ = mop.wshape[3]
+            if Cd % 256 == 0 and C_ <= 16:             # deconvolution + mask 1x1 conv + sigmoid on the 16-bit tensors too
+                up = ops.deconv2x2_h16(h, self._h16[dc.name][0], dc.b, Cd, ACT_RELU)
+                m = ops.mask_out_fwd_h16(up, mop.w.view(mop.wshape[2], C_), mop.b)
+                ctxs.append((h, None, up, ACT_RELU) if train else None)
+                ctxs.append((up, None, m, ACT_SIGMOID) if train else None)
+                return m.view(B, R, m.shape[1], m.shape[2], m.shape[3]), ctxs
             x = ops.cast_from_h16(h)
         dc = self.op("mrcnn_mask_deconv")
         up = ops.deconv2x2(x, dc.w.view(dc.wshape[2], dc.wshape[3]), dc.b, ACT_RELU)
@@ -587,7 +598,16 @@ class MaskRCNNEngine(object):
         mop, dc = self.op("mrcnn_mask"), self.op("mrcnn_mask_deconv")
         x_in, _, up, _ = cdec
         C_ = cm[2].shape[-1]
-        if self.fused_mask_out_bwd and C_ <= 16 and up.shape[-1] % 64 == 0 and up.shape[-1] <= 1024:
+        S = float(self.loss_scale) if self.head_dtype == torch.float16 else 1.0
+        d16 = None
+        if up.dtype != torch.float32:
+            # output stage and deconvolution on the 16-bit tensors: dzg comes out scaled, in 16 bits
+            dzg = ops.mask_out_bwd_h16(g, cm[2], up, mop.w.view(mop.wshape[2], mop.wshape[3]),
+                                       mop.dw.view(mop.wshape[2], mop.wshape[3]), mop.db, dc.db, S)
+            self.wgrad_h16_async(x_in, dzg, dc.wshape, dc.dw, 1.0 / S)
+            d16 = ops.conv2d_h16(dzg, self._h16[dc.name][1], (1, 1, dc.wshape[3], dc.wshape[2]), None, None, None, 1, "valid",
+                                 ACT_NONE)
+        elif self.fused_mask_out_bwd and C_ <= 16 and up.shape[-1] % 64 == 0 and up.shape[-1] <= 1024:
             # one pass over `up`: sigmoid', 1x1 conv wgrad/dgrad/bias, ReLU mask, deconv bias, GEMM regrouping
             # (dw accumulates: the flat gradient buffer was zeroed at the start of the step)
             dzg = ops.mask_out_bwd(g, cm[2], up, mop.w.view(mop.wshape[2], mop.wshape[3]),
@@ -600,9 +620,10 @@ class MaskRCNNEngine(object):
             dzu = ops.empty_like(d_up)
             ops.epilogue_bwd(d_up, up, None, None, None, None, None, dzu, None, None, dc.db, ACT_RELU)
             dzg = ops.pixel_unshuffle2(dzu)                             # [M,14,14,1024]
-        self.wgrad_async(x_in, dzg, dc.wshape, 1, "valid", dc.dw, False)
-        if not self.wt_valid:
-            ops.weight_flip_transpose(dc.w, dc.wt)
+        if d16 is None:
+            self.wgrad_async(x_in, dzg, dc.wshape, 1, "valid", dc.dw, False)
+            if not self.wt_valid:
+                ops.weight_flip_transpose(dc.w, dc.wt)
         if self.head_dtype is None:
             # every data-gradient convolution applies the epilogue backward of the layer below in its own epilogue
             # (mrcnn_conv2d_dgrad_ep): the gradient w.r.t. the activated output is never written or re-read
@@ -618,9 +639,9 @@ class MaskRCNNEngine(object):
                 else:
                     d = op.dgrad(dz, c)
         else:
-            d = ops.conv2d(dzg, dc.wt, stride=1, padding="valid")
-            S = float(self.loss_scale) if self.head_dtype == torch.float16 else 1.0
-            d16 = ops.cast_to_h16(d, self.head_dtype, multiplier=S)
+            if d16 is None:
+                d = ops.conv2d(dzg, dc.wt, stride=1, padding="valid")
+                d16 = ops.cast_to_h16(d, self.head_dtype, multiplier=S)
             for i, c in ((4, c4), (3, c3), (2, c2), (1, c1)):
                 op = self.op("mrcnn_mask_conv%d" % i)
                 kh, kw, cin, cout = op.wshape

@@ -532,6 +532,43 @@ def conv2d_h16(x, w_t, kshape, bias=None, scale=None, shift=None, stride=1, padd
     return out
 
 
+def deconv2x2_h16(x, w_t, bias, Cd, act=ACT_RELU):
+    """Conv2DTranspose(2x2, stride 2) on 16-bit x [N,H,W,Cin]: w_t = W^T [4*Cd, Cin] of the GEMM matrix."""
+    _need_cuda(x, w_t, bias)
+    N, H, W, Cin = x.shape
+    d = _hip.ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad_t, d.pad_l = N, H, W, Cin, 4 * Cd, 1, 1, 1, 0, 0
+    d.OH, d.OW, d.act, d.res_mode, d.out_mode, d.cmod = H, W, act, RES_NONE, OUT_DECONV2, Cd
+    d.out_w_stride, d.out_h_stride, d.out_n_stride = Cd, 2 * W * Cd, 4 * H * W * Cd
+    out = empty((N, 2 * H, 2 * W, Cd), x.dtype, x.device)
+    check(_hip.lib().mrcnn_conv2d_fwd_h16(C.byref(d), _H16[x.dtype], ptr(x), ptr(w_t), ptr(bias), None, None, ptr(out), None,
+                                          current_stream()), "mrcnn_conv2d_fwd_h16(deconv)")
+    return out
+
+
+def mask_out_fwd_h16(up, w_mask, b_mask):
+    """sigmoid(1x1 conv) of the 16-bit deconvolution output -> float32 [M,H,W,C]."""
+    _need_cuda(up, w_mask, b_mask)
+    M, H, W, Cd = up.shape
+    C_ = w_mask.shape[-1]
+    out = empty((M, H, W, C_), torch.float32, up.device)
+    check(_hip.lib().mrcnn_mask_out_fwd_h16(_H16[up.dtype], ptr(up), ptr(w_mask), ptr(b_mask), ptr(out), M * H * W, Cd, C_,
+                                            current_stream()), "mrcnn_mask_out_fwd_h16")
+    return out
+
+
+def mask_out_bwd_h16(d_mask_out, mask_out, up, w_mask, dw_mask, db_mask, db_deconv, loss_scale):
+    """One-pass backward of the mask-head output stage on a 16-bit `up`; returns dzg [M,H/2,W/2,4*Cd] (16 bit, scaled)."""
+    _need_cuda(d_mask_out, mask_out, up, w_mask, dw_mask, db_mask, db_deconv)
+    M, H, W, Cd = up.shape
+    C_ = mask_out.shape[-1]
+    dzg = empty((M, H // 2, W // 2, 4 * Cd), up.dtype, up.device)
+    check(_hip.lib().mrcnn_mask_out_bwd_h16(_H16[up.dtype], ptr(d_mask_out), ptr(mask_out), ptr(up), ptr(w_mask), ptr(dzg),
+                                            ptr(dw_mask), ptr(db_mask), ptr(db_deconv), M, H, W, Cd, C_, float(loss_scale),
+                                            current_stream()), "mrcnn_mask_out_bwd_h16")
+    return dzg
+
+
 def conv2d_wgrad_h16(x, dy, w_shape, stride=1, padding="same", dw=None, accumulate=False, multiplier=1.0):
     """dw (float32 HWIO) from 16-bit x / dy; multiplier undoes a loss scale."""
     _need_cuda(x, dy, dw)

@@ -224,6 +224,15 @@ int mrcnn_conv2d_wgrad_h16(const mrcnn_conv_desc* d, int dtype, const void* x, c
 int mrcnn_epilogue_bwd_h16(int dtype, const void* dout, const void* out, const void* z, const float* scale,
                            const float* mean, const float* rstd, void* dz_out, float* dgamma, float* dbeta,
                            float* dbias, int64_t M, int C, int act, float grad_multiplier, void* stream);
+/* Output stage of the mask head on a 16-bit deconvolution output `up` [M,H,W,Cd] (mrcnn_conv2d_fwd_h16 with out_mode
+ * MRCNN_OUT_DECONV2 writes it): mask_out [M,H,W,C] float32 = sigmoid(up . w_mask + b_mask); and the one-pass backward
+ * of mrcnn_mask_out_bwd with dzg written in 16 bits times loss_scale (the sums dw_mask / db_mask / db_deconv stay
+ * float32 and unscaled).  Cd % 256 == 0 (forward), C <= 16.                                                        */
+int mrcnn_mask_out_fwd_h16(int dtype, const void* up, const float* w_mask, const float* b_mask, float* mask_out,
+                           int64_t npix, int Cd, int C, void* stream);
+int mrcnn_mask_out_bwd_h16(int dtype, const float* d_mask_out, const float* mask_out, const void* up, const float* w_mask,
+                           void* dzg, float* dw_mask, float* db_mask, float* db_deconv, int64_t M, int H, int W, int Cd,
+                           int C, float loss_scale, void* stream);
 int mrcnn_cast_to_h16(const float* src, void* dst, int64_t n, int dtype, float multiplier, void* stream);
 int mrcnn_cast_from_h16(const void* src, float* dst, int64_t n, int dtype, float multiplier, void* stream);
 

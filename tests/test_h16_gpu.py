@@ -150,3 +150,43 @@ def test_mixed_precision_mask_head_training_step(dev, dtype):
     assert not bad, bad[:6]
     g = res[dtype][1]["mrcnn_mask_conv2/kernel"]
     assert np.abs(g).max() > 0 and np.isfinite(g).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_deconv_and_mask_output_stage_h16(dev, dtype):
+    """16-bit deconvolution (pixel-shuffle store) + mask 1x1 conv + sigmoid, and the one-pass backward of that stage,
+    against the float32 ops of the package (themselves checked against the oracle) on the same 16-bit-rounded tensors."""
+    ops = _ops()
+    from caesar_mrcnn_amd.params import deconv_keras_to_gemm
+    rng = np.random.default_rng(17)
+    M, Cd, C = 37, 256, 4
+    x = torch.tensor(rng.standard_normal((M, 14, 14, 256)).astype(np.float32)).to(dtype)
+    k = (rng.standard_normal((2, 2, Cd, 256)) * 0.05).astype(np.float32)                  # Keras (2,2,out,in)
+    wg = torch.tensor(deconv_keras_to_gemm(k).reshape(256, 4 * Cd)).to(dtype)            # GEMM matrix [Cin, 4*Cd], rounded
+    b = torch.tensor(rng.standard_normal(Cd).astype(np.float32) * 0.1)
+    up_ref = ops.deconv2x2(x.float().to(dev), wg.float().to(dev), b.to(dev), 1)           # float32 kernel, same operands
+    wt, _ = ops.weights_to_h16(wg.float().to(dev).view(1, 1, 256, 4 * Cd), dtype, want_dgrad=False)
+    up = ops.deconv2x2_h16(x.to(dev), wt, b.to(dev), Cd, 1)
+    torch.cuda.synchronize()
+    assert up.dtype == dtype and tuple(up.shape) == (M, 28, 28, Cd)
+    err = float((up.float() - up_ref).abs().max()) / float(up_ref.abs().max())
+    assert err <= TOL[dtype], err
+    wm = torch.tensor(rng.standard_normal((Cd, C)).astype(np.float32) * 0.1, device=dev)
+    bm = torch.tensor(rng.standard_normal(C).astype(np.float32) * 0.1, device=dev)
+    m_ref = ops.conv2d(up.float(), wm.view(1, 1, Cd, C), bm, stride=1, padding="valid", act=2)
+    m = ops.mask_out_fwd_h16(up, wm, bm)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(m, m_ref, rtol=1e-5, atol=1e-5)
+    # backward of the output stage
+    g = torch.tensor(rng.standard_normal((M, 28, 28, C)).astype(np.float32) * 1e-3, device=dev)
+    ref_dw, ref_dbm, ref_dbd = torch.zeros_like(wm), torch.zeros(C, device=dev), torch.zeros(Cd, device=dev)
+    dzg_ref = ops.mask_out_bwd(g, m, up.float(), wm, ref_dw, ref_dbm, ref_dbd)
+    dw, dbm, dbd = torch.zeros_like(wm), torch.zeros(C, device=dev), torch.zeros(Cd, device=dev)
+    S = 1024.0
+    dzg = ops.mask_out_bwd_h16(g, m, up, wm, dw, dbm, dbd, S)
+    torch.cuda.synchronize()
+    assert dzg.dtype == dtype
+    err = float((dzg.float() / S - dzg_ref).abs().max()) / float(dzg_ref.abs().max())
+    assert err <= TOL[dtype], err
+    for a, r in ((dw, ref_dw), (dbm, ref_dbm), (dbd, ref_dbd)):
+        torch.testing.assert_close(a, r, rtol=1e-4, atol=1e-4 * float(r.abs().max()))
