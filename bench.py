@@ -149,7 +149,7 @@ def measure(args, backbone, nimg, rank, local_rank, world, full):
     else:
         step()
         dt_sparse, _ = timed(args.steps)
-    # configs[4], stage 1 (NOT the headline: reduced precision): the four mask-head convolutions on the fp16 MFMA,
+    # configs[4], stages 1-2 (NOT the headline: reduced precision): the mask head on the fp16 MFMA,
     # every row computed as in the headline leg
     dt_h16 = float("nan")
     if not args.dense_only:
@@ -290,9 +290,10 @@ def main():
                                     "tests/test_engine_gpu.py::test_sparse_mask_backward_equals_dense); product default, "
                                     "never the headline value",
             "value_f16_mask_head": None if args.dense_only else round(r["images_per_s_f16_mask_head"], 3),
-            "note_f16_mask_head": "BASELINE configs[4], stage 1: the headline (dense) step with the four 3x3 mask-head convolutions "
-                                  "(forward, data and weight gradient) on the fp16 matrix cores, float32 master weights / "
-                                  "accumulation / gradients, loss scale 4096; reduced precision, never the headline value",
+            "note_f16_mask_head": "BASELINE configs[4], stages 1-2: the headline (dense) step with the mask head (four 3x3 convolutions, "
+                                  "transposed convolution, output stage; forward, data and weight gradient) on the fp16 matrix "
+                                  "cores, float32 master weights / accumulation / gradients, loss scale 4096; reduced precision, "
+                                  "never the headline value",
             "losses_last_step": [round(v, 5) for v in r["losses"]],
             "roofline": r["roofline"],
         }
