@@ -244,8 +244,8 @@ def measure(args, backbone, nimg, rank, local_rank, world, full):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--backbone", default="resnet101", help="BASELINE.json metric: ResNet-101 256x256")
     ap.add_argument("--imgsize", type=int, default=256)
     ap.add_argument("--nimg", type=int, default=4, help="images per GPU (IMAGES_PER_GPU; configs[2]: 4)")
