@@ -472,3 +472,48 @@ def test_graph_replay_with_multiworkgroup_topk_512(dev):
         for k in keys:
             assert np.array_equal(out[k].cpu().numpy(), eager[k]), (k, rep)
     assert np.abs(eager["rpn_rois"]).sum() > 0
+
+
+def test_overfit_one_batch_then_detect_it(dev):
+    """End to end: 120 full steps (forward, backward, clipnorm, SGD-momentum) on one synthetic batch drive the total
+    loss down by > 10x, and the inference graph with the trained weights then finds the training objects (a detection
+    with box IoU > 0.5 for at least a third of the ground-truth boxes; the float atomics make the trajectory -- and which
+    of the objects are found -- vary from run to run, typically 4-5 of 6, so the bar is set well below that)."""
+    import bench
+    from caesar_mrcnn_amd.config import run_py_config
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = run_py_config(num_classes=4, imgsize=256, backbone="resnet50", images_per_gpu=2, gpu_count=1)
+    model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, seed=0)
+    batch = bench.synthetic_batch(cfg, 2, seed=7)
+    keys = np.random.RandomState(0).uniform(0, 1, (2, cfg.POST_NMS_ROIS_TRAINING))
+    inp = model._to_device(batch, rand_keys=keys)
+    eng = model.engine
+    first = last = None
+    for s in range(120):
+        losses = eng.forward_backward(*inp)
+        eng.apply_gradients(0.002, cfg.LEARNING_MOMENTUM, 1)
+        if s == 0:
+            first = float(losses.sum())
+    last = float(losses.sum())
+    assert np.isfinite(last) and last < 0.1 * first, (first, last)
+    icfg = run_py_config(num_classes=4, imgsize=256, backbone="resnet50", mode="inference")
+    eng.cfg = icfg
+    images, _, _, _, gt_cls, gt_boxes, _ = batch
+    x = torch.tensor(images, device=dev)
+    win = torch.tensor([[0., 0., 1., 1.]] * 2, device=dev)
+    det = eng.infer(x, win)["detections"].cpu().numpy()          # [B, 100, (y1, x1, y2, x2, class, score)], normalised
+    found = total = 0
+    for b in range(2):
+        d = det[b][det[b, :, 4] > 0]
+        boxes = d[:, :4] * 255.0 + np.array([0, 0, 1, 1])
+        for g in range(int((gt_cls[b] > 0).sum())):
+            y1, x1, y2, x2 = gt_boxes[b, g]
+            total += 1
+            for k in range(d.shape[0]):
+                iy = max(0.0, min(y2, boxes[k, 2]) - max(y1, boxes[k, 0])); ix = max(0.0, min(x2, boxes[k, 3]) - max(x1, boxes[k, 1]))
+                inter = iy * ix
+                union = (y2 - y1) * (x2 - x1) + (boxes[k, 2] - boxes[k, 0]) * (boxes[k, 3] - boxes[k, 1]) - inter
+                if inter / union > 0.5:
+                    found += 1
+                    break
+    assert total > 0 and 3 * found >= total, (found, total)
