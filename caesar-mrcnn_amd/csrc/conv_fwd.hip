@@ -18,6 +18,7 @@ struct ConvArgs {
     int act, res_mode, out_mode, cmod;
     long long ons, ohs, ows;
     int M, Ktot, nk, fastA, vecB, dense;
+    FastDiv d_ohw, d_ow;               // exact division of output-pixel indices (non-dense stores: deconv, concat, UP2)
     float* slab; int ksplit, ksteps;   // split-K: partial sums [ksplit][M][Cout], K-steps per split
     // fused backward epilogue (mrcnn_conv2d_dgrad_ep, LDS-DMA kernel only): the result y is the gradient w.r.t. the
     // activated output of the layer below; that layer's epilogue backward is applied before the store
@@ -28,7 +29,8 @@ struct ConvArgs {
 // One 32x32 accumulator tile: lane holds column n, rows mbase + (r&3) + 8*(r>>2).
 __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& p, const f32x16& acc, int mbase, int n) {
     if (n >= p.Cout) return;
-    const int c = n % p.cmod;
+    const int ab_tile = n / p.cmod;              // (a*2+b) of the transposed-conv column; 0 otherwise (cmod == Cout)
+    const int c = n - ab_tile * p.cmod;
     const float bias = p.bias ? p.bias[c] : 0.f;
     const float sc = p.scale ? p.scale[c] : 1.f;
     const float sh = p.scale ? p.shift[c] : 0.f;
@@ -43,10 +45,10 @@ __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& p, const f32x
             addr = (long long)m * p.Cout + n;
             raddr = addr;
         } else {
-            int ni = m / ohw, rem = m - ni * ohw;
-            int oh = rem / p.OW, ow = rem - oh * p.OW;
+            const int ni = (int)fast_div((unsigned)m, p.d_ohw), rem = m - ni * ohw;
+            const int oh = (int)fast_div((unsigned)rem, p.d_ow), ow = rem - oh * p.OW;
             if (p.out_mode == MRCNN_OUT_DECONV2) {
-                int ab = n / p.cmod;
+                const int ab = ab_tile;
                 addr = (long long)ni * p.ons + (long long)(2 * oh + (ab >> 1)) * p.ohs +
                        (long long)(2 * ow + (ab & 1)) * p.ows + c;
             } else {
@@ -781,6 +783,7 @@ static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* 
     a.act = d->act; a.res_mode = d->res_mode; a.out_mode = d->out_mode; a.cmod = d->cmod;
     a.ons = d->out_n_stride; a.ohs = d->out_h_stride; a.ows = d->out_w_stride;
     a.M = (int)M; a.Ktot = d->KH * d->KW * d->Cin; a.nk = (a.Ktot + 31) / 32;
+    a.d_ohw = make_fastdiv((unsigned)(d->OH * d->OW)); a.d_ow = make_fastdiv((unsigned)d->OW);
     a.fastA = (d->Cin % 32 == 0) && (d->KH * d->KW <= 64) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     a.vecB = (d->Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
     a.dense = d->out_mode == MRCNN_OUT_NHWC && d->out_w_stride == d->Cout &&
