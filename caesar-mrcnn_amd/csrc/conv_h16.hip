@@ -13,6 +13,7 @@
 //   cast kernels          float32 <-> 16-bit, elementwise.
 #include "common.h"
 #include <type_traits>
+#include <utility>
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -39,13 +40,22 @@ struct ConvH16Args {
 
 #define H16_OOB_OFFSET 0xFFFFFFF0u
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void conv_fwd_h16_kernel(const ConvH16Args p) {
+template <class F, int... I>
+__device__ __forceinline__ void h16_static_for(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
+// NBUF = 2: double buffering, every wave waits for all its loads at each barrier (relies on 3 workgroups per CU to hide
+// the DMA latency).  NBUF = 4: a ring of four tile pairs with the loads issued THREE K-steps ahead and counted waits
+// (s_waitcnt vmcnt(12 / 6 / 0): the two younger stages stay in flight across the barrier) -- one workgroup per CU
+// (96 KiB LDS), latency hidden by prefetch distance instead of occupancy.
+template <typename T, int NBUF>
+__global__ __launch_bounds__(256, NBUF <= 3 ? 2 : 1) void conv_fwd_h16_kernel(const ConvH16Args p) {
     typedef typename H16Traits<T>::v8 v8;
     constexpr int BM = 256, BN = 128, TM = 4, TN = 2;
     constexpr int ROWB = 64;                                    // bytes per LDS row (32 x 16-bit)
     constexpr int AB = BM * ROWB, BB = BN * ROWB;               // 16 KiB + 8 KiB per buffer
-    __shared__ __attribute__((aligned(16))) char lds[2 * (AB + BB)];
+    __shared__ __attribute__((aligned(16))) char lds[NBUF * (AB + BB)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -144,46 +154,78 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h16_kernel(const ConvH16Args 
     };
 
     const int nk = p.Ktot / 32;
-    stage(lds);
-    __syncthreads();
-    for (int ks = 0; ks < nk; ks += 2) {
-        if (ks + 1 < nk) stage(lds + (AB + BB));
-        compute(std::integral_constant<int, 0>{});
+    if constexpr (NBUF == 2) {
+        stage(lds);
         __syncthreads();
-        if (ks + 1 < nk) {
-            if (ks + 2 < nk) stage(lds);
-            compute(std::integral_constant<int, 1>{});
+        for (int ks = 0; ks < nk; ks += 2) {
+            if (ks + 1 < nk) stage(lds + (AB + BB));
+            compute(std::integral_constant<int, 0>{});
             __syncthreads();
+            if (ks + 1 < nk) {
+                if (ks + 2 < nk) stage(lds);
+                compute(std::integral_constant<int, 1>{});
+                __syncthreads();
+            }
+        }
+    } else {
+        constexpr int D = NBUF - 1;                             // prefetch distance in K-steps; 6 DMA instructions per stage and wave
+        for (int s0 = 0; s0 < D && s0 < nk; ++s0) stage(lds + s0 * (AB + BB));
+        for (int ks0 = 0; ks0 < nk; ks0 += NBUF) {
+            h16_static_for([&](auto sc) {
+                constexpr int S = decltype(sc)::value;
+                const int ks = ks0 + S;
+                if (ks < nk) {
+                    const int younger = nk - 1 - ks;            // stages issued after ks that may still be in flight (<= D - 1)
+                    if (D >= 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();               // stage ks has landed for every wave; everyone is done with stage ks - 1
+                    if (ks + D < nk) stage(lds + ((S + D) % NBUF) * (AB + BB));
+                    compute(std::integral_constant<int, S>{});
+                }
+            }, std::make_integer_sequence<int, NBUF>{});
         }
     }
 
     // ---- epilogue: bias, frozen-BN affine, activation in float32; one rounding to 16 bits --------------
+    // rows outermost: one output address per row (the transposed conv needs two divisions for it), then the wave's two
+    // column tiles -- keeps the number of live registers small (256 x 128 accumulators are already 128 of them)
     T* out = (T*)p.out;
     T* zo = (T*)p.z;
     const bool deconv = p.out_mode == MRCNN_OUT_DECONV2;        // column n = (a*2+b)*cmod + c -> pixel (2oh+a, 2ow+b), channel c
+    int cn[TN], cab[TN];
+    float cbias[TN], csc[TN], csh[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int n = n0 + wn * 64 + b * 32 + li;
-        const int ab = deconv ? n / p.cmod : 0;
-        const int c = deconv ? n - ab * p.cmod : n;
-        const float bias = p.bias ? p.bias[c] : 0.f;
-        const float sc = p.scale ? p.scale[c] : 1.f, sh = p.scale ? p.shift[c] : 0.f;
+        cab[b] = deconv ? n / p.cmod : 0;
+        cn[b] = deconv ? n - cab[b] * p.cmod : n;
+        cbias[b] = p.bias ? p.bias[cn[b]] : 0.f;
+        csc[b] = p.scale ? p.scale[cn[b]] : 1.f;
+        csh[b] = p.scale ? p.shift[cn[b]] : 0.f;
+    }
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            const int mb = m0 + wm * 128 + a * 32 + 4 * lh;
+    for (int a = 0; a < TM; ++a) {
+        const int mb = m0 + wm * 128 + a * 32 + 4 * lh;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                if (m >= p.M) continue;
-                const float zv = acc[a][b][r] + bias;
-                long long addr = (long long)m * p.Cout + n;
-                if (deconv) {
-                    const int ni = m / ohw, rem = m - ni * ohw;
-                    const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                    addr = (long long)ni * p.ons + (long long)(2 * oh + (ab >> 1)) * p.ohs + (long long)(2 * ow + (ab & 1)) * p.ows + c;
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            if (m >= p.M) continue;
+            long long rowaddr = (long long)m * p.Cout;
+            int oh = 0, ow = 0;
+            if (deconv) {
+                const int ni = m / ohw, rem = m - ni * ohw;
+                oh = rem / p.OW; ow = rem - oh * p.OW;
+                rowaddr = (long long)ni * p.ons;
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const long long addr = deconv ? rowaddr + (long long)(2 * oh + (cab[b] >> 1)) * p.ohs +
+                                                    (long long)(2 * ow + (cab[b] & 1)) * p.ows + cn[b]
+                                              : rowaddr + cn[b];
+                const float zv = acc[a][b][r] + cbias[b];
                 if (zo) zo[addr] = (T)zv;
-                float y = sc * zv + sh;
+                float y = csc[b] * zv + csh[b];
                 if (p.act == MRCNN_ACT_RELU) y = fmaxf(y, 0.f);
                 else if (p.act == MRCNN_ACT_SIGMOID) y = 1.f / (1.f + expf(-y));
                 out[addr] = (T)y;
@@ -700,10 +742,16 @@ extern "C" int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const v
     a.x_shift = (unsigned)shift_b; a.x_records = (unsigned)(xbytes + shift_b); a.w_records = (unsigned)wbytes;
     a.out_mode = d->out_mode; a.cmod = d->cmod; a.ons = d->out_n_stride; a.ohs = d->out_h_stride; a.ows = d->out_w_stride;
     const unsigned blocks = (unsigned)(((M + 255) / 256) * (d->Cout / 128));
-    if (dtype == MRCNN_DTYPE_F16)
-        hipLaunchKernelGGL(conv_fwd_h16_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    static const bool ring = getenv("MRCNN_H16_RING") != nullptr;  // A/B switch: 3-slot ring (faster in isolation, slower in the step)
+    if (ring) {
+        if (dtype == MRCNN_DTYPE_F16)
+            hipLaunchKernelGGL((conv_fwd_h16_kernel<_Float16, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL((conv_fwd_h16_kernel<__bf16, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    } else if (dtype == MRCNN_DTYPE_F16)
+        hipLaunchKernelGGL((conv_fwd_h16_kernel<_Float16, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(conv_fwd_h16_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv_fwd_h16_kernel<__bf16, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return mrcnn_launch_status();
 }
 
