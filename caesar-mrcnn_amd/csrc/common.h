@@ -118,6 +118,32 @@ static __global__ void pixel_table_kernel(PixelEntry* table, int N, int H, int W
 
 // MRCNN_CONV_FLAT_GLDS=1 (read once): keep the flat-addressed LDS-DMA kernels, which are otherwise only used for
 // tensors too large for a 32-bit buffer descriptor -- lets the tests and A/B timings reach them on small shapes.
+// Sum of `ks` split slabs at element offset e, in slab order (bitwise the same as the plain loop), with the loads
+// issued eight at a time: written as `for k: s += slab[k]` the compiler waits for every load before the next
+// (one memory round trip per slab -- measured 6-10 us per reduction launch on the latency-bound backbone layers).
+template <typename V>
+__device__ __forceinline__ V mrcnn_slab_sum(V acc, const float* __restrict__ slab, long long stride, long long e, int ks) {
+    for (int k0 = 0; k0 < ks; k0 += 8) {               // uniform trip count
+        V v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int k = k0 + j;
+            if (k > ks - 1) k = ks - 1;                // clamped: a valid (cached) address, value not used
+            v[j] = *(const V*)(slab + (long long)k * stride + e);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k0 + j < ks) acc += v[j];
+    }
+    return acc;
+}
+
+// elements per workgroup of the backward-epilogue kernels (MRCNN_EPI_MIN_ELEMS overrides; read once)
+static inline long long mrcnn_epilogue_min_elems() {
+    static const long long v = getenv("MRCNN_EPI_MIN_ELEMS") ? atoll(getenv("MRCNN_EPI_MIN_ELEMS")) : 4096;
+    return v < 256 ? 256 : v;
+}
+
 static inline bool mrcnn_force_flat_glds() {
     static const bool v = getenv("MRCNN_CONV_FLAT_GLDS") != nullptr;
     return v;

@@ -589,8 +589,7 @@ __global__ void conv_splitk_epilogue_kernel(const ConvArgs p) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)p.M * p.Cout) return;
     const int m = (int)(i / p.Cout), n = (int)(i - (long long)m * p.Cout);
-    float a = 0.f;
-    for (int k = 0; k < p.ksplit; ++k) a += p.slab[(long long)k * p.M * p.Cout + i];
+    const float a = mrcnn_slab_sum<float>(0.f, p.slab, (long long)p.M * p.Cout, i, p.ksplit);
     const int c = n % p.cmod;
     float zv = a + (p.bias ? p.bias[c] : 0.f);
     const float sc = p.scale ? p.scale[c] : 1.f, sh = p.scale ? p.shift[c] : 0.f;
@@ -624,6 +623,7 @@ __global__ void conv_splitk_epilogue_kernel(const ConvArgs p) {
 // maps): y = sum of the slabs in slice order (+ res), then exactly what epilogue_bwd_vec_kernel does with y -- one
 // launch and one round trip of y less per layer.  C = 4 * 2^k >= 16; a thread owns one float4 channel group and walks
 // rows; channel sums stay in registers until one LDS + one global atomic per channel per workgroup.
+#define SPLITK_EPI_U 2
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_bwd_kernel(const ConvArgs p, const long long rows_per_block) {
     extern __shared__ float sacc[];   // [3][C]
     const int C = p.Cout;
@@ -643,35 +643,47 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_bwd_kernel(const Con
         if (p.fb_scale) sc = *(const f32x4*)(p.fb_scale + c);
         if (p.fb_dgamma) { mu = *(const f32x4*)(p.fb_mean + c); rs = *(const f32x4*)(p.fb_rstd + c); }
         f32x4 a_db = {0.f, 0.f, 0.f, 0.f}, a_dg = a_db, a_bias = a_db;
-        for (long long r = r0 + rsub; r < r1; r += R) {
-            const long long e = r * C + c;
-            f32x4 g = {0.f, 0.f, 0.f, 0.f};
-            for (int k = 0; k < p.ksplit; ++k) {
-                const f32x4 v = *(const f32x4*)(p.slab + k * slab_stride + e);
+        // rows in batches of SPLITK_EPI_U: all loads of a batch before its first store (p.out may alias nothing here,
+        // but the compiler cannot know) -- one memory round trip per batch instead of one per row
+        for (long long rb = r0 + rsub; rb < r1; rb += (long long)R * SPLITK_EPI_U) {
+            f32x4 gg[SPLITK_EPI_U], oo[SPLITK_EPI_U], zz[SPLITK_EPI_U];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] += v[q];
-            }
-            if (p.res_mode != MRCNN_RES_NONE) {
-                const f32x4 v = *(const f32x4*)(p.res + e);
+            for (int u = 0; u < SPLITK_EPI_U; ++u) {
+                long long r = rb + (long long)u * R;
+                if (r >= r1) r = r1 - 1;                       // clamped: in range, result discarded below
+                const long long e = r * C + c;
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 g = mrcnn_slab_sum<f32x4>(zero4, p.slab, slab_stride, e, p.ksplit);
+                if (p.res_mode != MRCNN_RES_NONE) {
+                    const f32x4 v = *(const f32x4*)(p.res + e);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] += v[q];
-            }
-            if (p.fb_act == MRCNN_ACT_RELU) {
-                const f32x4 o = *(const f32x4*)(p.fb_out + e);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) g[q] = o[q] > 0.f ? g[q] : 0.f;
-            }
-            f32x4 dz;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dz[q] = g[q] * sc[q];
-            *(f32x4*)(p.out + e) = dz;
-            if (p.fb_dgamma) {
-                const f32x4 zz = *(const f32x4*)(p.fb_z + e);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a_dg[q] += g[q] * (zz[q] - mu[q]) * rs[q];
+                    for (int q = 0; q < 4; ++q) g[q] += v[q];
+                }
+                gg[u] = g;
+                if (p.fb_act == MRCNN_ACT_RELU) oo[u] = *(const f32x4*)(p.fb_out + e);
+                if (p.fb_dgamma) zz[u] = *(const f32x4*)(p.fb_z + e);
             }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { a_db[q] += g[q]; a_bias[q] += dz[q]; }
+            for (int u = 0; u < SPLITK_EPI_U; ++u) {
+                const long long r = rb + (long long)u * R;
+                if (r >= r1) break;
+                const long long e = r * C + c;
+                f32x4 g = gg[u];
+                if (p.fb_act == MRCNN_ACT_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) g[q] = oo[u][q] > 0.f ? g[q] : 0.f;
+                }
+                f32x4 dz;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dz[q] = g[q] * sc[q];
+                *(f32x4*)(p.out + e) = dz;
+                if (p.fb_dgamma) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a_dg[q] += g[q] * (zz[u][q] - mu[q]) * rs[q];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { a_db[q] += g[q]; a_bias[q] += dz[q]; }
+            }
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -697,7 +709,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);
     if (a.ksplit > 1 && a.fb_act >= 0) {         // slabs -> epilogue backward of the layer below
         long long rows_per_block = cdiv64(a.M, 2048);
-        const long long min_rows = cdiv64(4096, a.Cout);
+        const long long min_rows = cdiv64(mrcnn_epilogue_min_elems(), a.Cout);
         if (rows_per_block < min_rows) rows_per_block = min_rows;
         hipLaunchKernelGGL(conv_splitk_epilogue_bwd_kernel, dim3((unsigned)cdiv64(a.M, rows_per_block)), dim3(256),
                            3 * a.Cout * sizeof(float), s, a, rows_per_block);

@@ -645,10 +645,24 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(const WgradH16Ar
 __global__ void wgrad_h16_reduce_kernel(const float* __restrict__ slabs, float* dw, long long n, int splits, int acc, float mul) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
-    s *= mul;
+    const float s = mrcnn_slab_sum<float>(0.f, slabs, n, i, splits) * mul;
     dw[i] = acc ? dw[i] + s : s;
+}
+
+// n % 4 == 0, 16-byte aligned buffers: four elements per thread
+__global__ void wgrad_h16_reduce_vec_kernel(const float* __restrict__ slabs, float* dw, long long n4, int splits, int acc, float mul) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 s = mrcnn_slab_sum<f32x4>(zero4, slabs, 4 * n4, 4 * i, splits);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] *= mul;
+    if (acc) {
+        const f32x4 o = *(const f32x4*)(dw + 4 * i);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = o[q] + s[q];
+    }
+    *(f32x4*)(dw + 4 * i) = s;
 }
 
 struct WgradH16Plan { int splits, chunk; size_t table_bytes, slab_bytes; };
@@ -709,8 +723,12 @@ extern "C" int mrcnn_conv2d_wgrad_h16(const mrcnn_conv_desc* d, int dtype, const
     else
         hipLaunchKernelGGL(conv_wgrad_h16_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, a);
     const long long n = (long long)a.Ktot * a.Cout;
-    hipLaunchKernelGGL(wgrad_h16_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, slabs, dw, n, pl.splits, beta_acc,
-                       multiplier);
+    if (n % 4 == 0 && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0)
+        hipLaunchKernelGGL(wgrad_h16_reduce_vec_kernel, dim3((unsigned)cdiv64(n / 4, 256)), dim3(256), 0, s, slabs, dw, n / 4,
+                           pl.splits, beta_acc, multiplier);
+    else
+        hipLaunchKernelGGL(wgrad_h16_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, slabs, dw, n, pl.splits,
+                           beta_acc, multiplier);
     return mrcnn_launch_status();
 }
 

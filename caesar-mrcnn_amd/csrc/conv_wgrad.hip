@@ -444,9 +444,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_blds_kernel(const WgradArgs
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* dw, long long n, int splits, int acc) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    float s = acc ? dw[i] : 0.f;
-    for (int k = 0; k < splits; ++k) s += slabs[(long long)k * n + i];
-    dw[i] = s;
+    dw[i] = mrcnn_slab_sum<float>(acc ? dw[i] : 0.f, slabs, n, i, splits);
+}
+
+// n % 4 == 0, 16-byte aligned buffers: four elements per thread
+__global__ void wgrad_reduce_vec_kernel(const float* __restrict__ slabs, float* dw, long long n4, int splits, int acc) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (acc) s = *(const f32x4*)(dw + 4 * i);
+    *(f32x4*)(dw + 4 * i) = mrcnn_slab_sum<f32x4>(s, slabs, 4 * n4, 4 * i, splits);
 }
 
 struct WgradPlan { int bi, bn, splits, chunk, fast; };
@@ -550,8 +557,12 @@ extern "C" int mrcnn_conv2d_wgrad(const mrcnn_conv_desc* d, const float* x, cons
     }
     if (pl.splits > 1) {
         const long long n = (long long)a.Ktot * a.Cout;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, workspace, dw, n,
-                           pl.splits, beta_acc);
+        if (n % 4 == 0 && ((reinterpret_cast<uintptr_t>(workspace) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0)
+            hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3((unsigned)cdiv64(n / 4, 256)), dim3(256), 0, s,
+                               (const float*)workspace, dw, n / 4, pl.splits, beta_acc);
+        else
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, workspace, dw, n,
+                               pl.splits, beta_acc);
     }
     return mrcnn_launch_status();
 }

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(
 // Vector form for C = 4 * 2^k (every BatchNorm layer of the graph): a thread owns one float4 channel
 // group and walks rows with stride 256/(C/4); sums stay in registers until one LDS + one global atomic
 // per channel per workgroup.
+#define EPI_U 4
 __global__ __launch_bounds__(256) void epilogue_bwd_vec_kernel(
     const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ z,
     const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ rstd,
@@ -92,30 +93,44 @@ __global__ __launch_bounds__(256) void epilogue_bwd_vec_kernel(
         if (scale) sc = *(const f32x4*)(scale + c);
         if (dgamma) { mu = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c); }
         f32x4 a_db = {0.f, 0.f, 0.f, 0.f}, a_dg = a_db, a_bias = a_db;
-        for (int64_t r = r0 + rsub; r < r1; r += R) {
-            const int64_t e = r * C + c;
-            f32x4 g = *(const f32x4*)(dout + e);
-            if (act == MRCNN_ACT_RELU) {
-                f32x4 o = *(const f32x4*)(out + e);
+        // rows in batches of EPI_U: every load of a batch is issued before its first store (the outputs may alias the
+        // inputs, so the compiler cannot hoist them itself) -- one memory round trip per batch instead of one per row
+        for (int64_t rb = r0 + rsub; rb < r1; rb += (int64_t)R * EPI_U) {
+            f32x4 gg[EPI_U], oo[EPI_U], zz[EPI_U];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) g[k] = o[k] > 0.f ? g[k] : 0.f;
-            } else if (act == MRCNN_ACT_SIGMOID) {
-                f32x4 o = *(const f32x4*)(out + e);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) g[k] = g[k] * o[k] * (1.f - o[k]);
-            }
-            if (dy_out) *(f32x4*)(dy_out + e) = g;
-            f32x4 dz;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) dz[k] = g[k] * sc[k];
-            if (dz_out) *(f32x4*)(dz_out + e) = dz;
-            if (dgamma) {
-                f32x4 zz = *(const f32x4*)(z + e);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a_dg[k] += g[k] * (zz[k] - mu[k]) * rs[k];
+            for (int u = 0; u < EPI_U; ++u) {
+                int64_t r = rb + (int64_t)u * R;
+                if (r >= r1) r = r1 - 1;                       // clamped: in range, result discarded below
+                const int64_t e = r * C + c;
+                gg[u] = *(const f32x4*)(dout + e);
+                if (act != MRCNN_ACT_NONE) oo[u] = *(const f32x4*)(out + e);
+                if (dgamma) zz[u] = *(const f32x4*)(z + e);
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { a_db[k] += g[k]; a_bias[k] += dz[k]; }
+            for (int u = 0; u < EPI_U; ++u) {
+                const int64_t r = rb + (int64_t)u * R;
+                if (r >= r1) break;
+                const int64_t e = r * C + c;
+                f32x4 g = gg[u];
+                if (act == MRCNN_ACT_RELU) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[k] = oo[u][k] > 0.f ? g[k] : 0.f;
+                } else if (act == MRCNN_ACT_SIGMOID) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) g[k] = g[k] * oo[u][k] * (1.f - oo[u][k]);
+                }
+                if (dy_out) *(f32x4*)(dy_out + e) = g;
+                f32x4 dz;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dz[k] = g[k] * sc[k];
+                if (dz_out) *(f32x4*)(dz_out + e) = dz;
+                if (dgamma) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a_dg[k] += g[k] * (zz[u][k] - mu[k]) * rs[k];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { a_db[k] += g[k]; a_bias[k] += dz[k]; }
+            }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -141,7 +156,7 @@ extern "C" int mrcnn_epilogue_bwd(const float* dout, const float* out, const flo
     if (dgamma && (!z || !mean || !rstd)) return MRCNN_ERR_ARG;
     int64_t rows_per_block = cdiv64(M, 2048);
     // keep at least ~4K elements per workgroup so the per-channel atomics stay negligible
-    int64_t min_rows = cdiv64(4096, C);
+    int64_t min_rows = cdiv64(mrcnn_epilogue_min_elems(), C);
     if (rows_per_block < min_rows) rows_per_block = min_rows;
     unsigned grid = (unsigned)cdiv64(M, rows_per_block);
     const bool pow2 = C >= 16 && (C & (C - 1)) == 0;
