@@ -138,10 +138,27 @@ __device__ __forceinline__ V mrcnn_slab_sum(V acc, const float* __restrict__ sla
     return acc;
 }
 
-// elements per workgroup of the backward-epilogue kernels (MRCNN_EPI_MIN_ELEMS overrides; read once)
-static inline long long mrcnn_epilogue_min_elems() {
-    static const long long v = getenv("MRCNN_EPI_MIN_ELEMS") ? atoll(getenv("MRCNN_EPI_MIN_ELEMS")) : 4096;
-    return v < 256 ? 256 : v;
+// Launch shape of the vector backward-epilogue kernels (C = 4 * 2^k): workgroups of 2^lg float4 channel groups x
+// rows_per_block rows.  MRCNN_EPI_MIN_ELEMS / MRCNN_EPI_LANES override the tile (read once; A/B timings).
+struct EpiGrid { unsigned row_blocks, chan_blocks; long long rows_per_block; int lg; };
+static inline EpiGrid mrcnn_epilogue_grid(long long M, int C) {
+    static const long long min_elems = getenv("MRCNN_EPI_MIN_ELEMS") ? atoll(getenv("MRCNN_EPI_MIN_ELEMS")) : 4096;
+    static const int max_lanes = getenv("MRCNN_EPI_LANES") ? atoi(getenv("MRCNN_EPI_LANES")) : 16;
+    EpiGrid g;
+    const int c4n = C >> 2;
+    int lanes = c4n < 256 ? c4n : 256;
+    if (lanes > max_lanes && max_lanes >= 4) lanes = max_lanes;
+    g.lg = 0;
+    while ((2 << g.lg) <= lanes) ++g.lg;                   // floor(log2(lanes)); lanes is a power of two here
+    const long long R = 256 >> g.lg;
+    long long rows = (M + 2047) / 2048;
+    const long long min_rows = (min_elems + (4ll << g.lg) - 1) / (4ll << g.lg);
+    if (rows < min_rows) rows = min_rows;
+    if (rows < R) rows = R;
+    g.rows_per_block = rows;
+    g.row_blocks = (unsigned)((M + rows - 1) / rows);
+    g.chan_blocks = (unsigned)(c4n >> g.lg);
+    return g;
 }
 
 static inline bool mrcnn_force_flat_glds() {

@@ -19,6 +19,7 @@ struct ConvArgs {
     long long ons, ohs, ows;
     int M, Ktot, nk, fastA, vecB, dense;
     FastDiv d_ohw, d_ow;               // exact division of output-pixel indices (non-dense stores: deconv, concat, UP2)
+    FastDiv d_c4;                      // Cout / 4 (vector split-K epilogue)
     float* slab; int ksplit, ksteps;   // split-K: partial sums [ksplit][M][Cout], K-steps per split
     // fused backward epilogue (mrcnn_conv2d_dgrad_ep, LDS-DMA kernel only): the result y is the gradient w.r.t. the
     // activated output of the layer below; that layer's epilogue backward is applied before the store
@@ -619,84 +620,138 @@ __global__ void conv_splitk_epilogue_kernel(const ConvArgs p) {
     p.out[addr] = y;
 }
 
+// Four channels per thread (Cout, cmod and the output strides multiples of 4, 16-byte aligned buffers, M*Cout < 2^31):
+// no 64-bit division, float4 traffic.  Same arithmetic per element as conv_splitk_epilogue_kernel.
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_vec_kernel(const ConvArgs p) {
+    const unsigned i4 = blockIdx.x * 256u + threadIdx.x;
+    const unsigned c4 = (unsigned)p.Cout >> 2;
+    if (i4 >= (unsigned)p.M * c4) return;
+    const int m = (int)fast_div(i4, p.d_c4), n = (int)(i4 - (unsigned)m * c4) * 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 a = mrcnn_slab_sum<f32x4>(zero4, p.slab, (long long)p.M * p.Cout, (long long)i4 * 4, p.ksplit);
+    int ab = 0, c = n;
+    if (p.cmod != p.Cout) { ab = n / p.cmod; c = n - ab * p.cmod; }
+    f32x4 bias = zero4, sc = {1.f, 1.f, 1.f, 1.f}, sh = zero4;
+    if (p.bias) bias = *(const f32x4*)(p.bias + c);
+    if (p.scale) { sc = *(const f32x4*)(p.scale + c); sh = *(const f32x4*)(p.shift + c); }
+    long long addr, raddr;
+    if (p.dense && p.res_mode != MRCNN_RES_UP2) {
+        addr = (long long)i4 * 4;
+        raddr = addr;
+    } else {
+        const int ohw = p.OH * p.OW;
+        const int ni = (int)fast_div((unsigned)m, p.d_ohw), rem = m - ni * ohw;
+        const int oh = (int)fast_div((unsigned)rem, p.d_ow), ow = rem - oh * p.OW;
+        if (p.out_mode == MRCNN_OUT_DECONV2)
+            addr = (long long)ni * p.ons + (long long)(2 * oh + (ab >> 1)) * p.ohs + (long long)(2 * ow + (ab & 1)) * p.ows + c;
+        else
+            addr = (long long)ni * p.ons + (long long)oh * p.ohs + (long long)ow * p.ows + n;
+        raddr = addr;
+        if (p.res_mode == MRCNN_RES_UP2)
+            raddr = (((long long)ni * (p.OH >> 1) + (oh >> 1)) * (p.OW >> 1) + (ow >> 1)) * p.Cout + n;
+    }
+    f32x4 zv, y;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) zv[q] = a[q] + bias[q];
+    if (p.z) *(f32x4*)(p.z + addr) = zv;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) y[q] = sc[q] * zv[q] + sh[q];
+    if (p.res_mode != MRCNN_RES_NONE) {
+        const f32x4 r = *(const f32x4*)(p.res + raddr);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[q] += r[q];
+    }
+    if (p.act == MRCNN_ACT_RELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[q] = fmaxf(y[q], 0.f);
+    } else if (p.act == MRCNN_ACT_SIGMOID) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) y[q] = 1.f / (1.f + expf(-y[q]));
+    }
+    *(f32x4*)(p.out + addr) = y;
+}
+
+static bool splitk_epilogue_vec_ok(const ConvArgs& a) {
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if ((a.Cout & 3) || (a.cmod & 3) || (long long)a.M * a.Cout >= (1ll << 31)) return false;
+    if (!a.dense && ((a.ons | a.ohs | a.ows) & 3)) return false;
+    return al(a.slab) && al(a.out) && al(a.z) && al(a.res) && al(a.bias) && al(a.scale) && al(a.shift);
+}
+
 // Split-K second pass fused with the epilogue backward of the layer below (mrcnn_conv2d_dgrad_ep on small feature
 // maps): y = sum of the slabs in slice order (+ res), then exactly what epilogue_bwd_vec_kernel does with y -- one
 // launch and one round trip of y less per layer.  C = 4 * 2^k >= 16; a thread owns one float4 channel group and walks
 // rows; channel sums stay in registers until one LDS + one global atomic per channel per workgroup.
 #define SPLITK_EPI_U 2
-__global__ __launch_bounds__(256) void conv_splitk_epilogue_bwd_kernel(const ConvArgs p, const long long rows_per_block) {
-    extern __shared__ float sacc[];   // [3][C]
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_bwd_kernel(const ConvArgs p, const long long rows_per_block, const int lg) {
+    __shared__ float sacc[3 * 4 * 256];   // [3][4L]
     const int C = p.Cout;
-    for (int c = threadIdx.x; c < 3 * C; c += 256) sacc[c] = 0.f;
+    const int L = 1 << lg, R = 256 >> lg;
+    for (int c = threadIdx.x; c < 12 * L; c += 256) sacc[c] = 0.f;
     __syncthreads();
-    const int c4n = C >> 2;
-    const int L = c4n < 256 ? c4n : 256;
-    const int R = 256 / L;
-    const int rsub = threadIdx.x / L, lane = threadIdx.x % L;
+    const int rsub = threadIdx.x >> lg, lane = threadIdx.x & (L - 1);
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > p.M) r1 = p.M;
     const long long slab_stride = (long long)p.M * C;
-    for (int cg = lane; cg < c4n; cg += L) {
-        const int c = cg * 4;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, mu = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
-        if (p.fb_scale) sc = *(const f32x4*)(p.fb_scale + c);
-        if (p.fb_dgamma) { mu = *(const f32x4*)(p.fb_mean + c); rs = *(const f32x4*)(p.fb_rstd + c); }
-        f32x4 a_db = {0.f, 0.f, 0.f, 0.f}, a_dg = a_db, a_bias = a_db;
-        // rows in batches of SPLITK_EPI_U: all loads of a batch before its first store (p.out may alias nothing here,
-        // but the compiler cannot know) -- one memory round trip per batch instead of one per row
-        for (long long rb = r0 + rsub; rb < r1; rb += (long long)R * SPLITK_EPI_U) {
-            f32x4 gg[SPLITK_EPI_U], oo[SPLITK_EPI_U], zz[SPLITK_EPI_U];
+    const int c = (blockIdx.y * L + lane) * 4;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, mu = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+    if (p.fb_scale) sc = *(const f32x4*)(p.fb_scale + c);
+    if (p.fb_dgamma) { mu = *(const f32x4*)(p.fb_mean + c); rs = *(const f32x4*)(p.fb_rstd + c); }
+    f32x4 a_db = {0.f, 0.f, 0.f, 0.f}, a_dg = a_db, a_bias = a_db;
+    // rows in batches of SPLITK_EPI_U: all loads of a batch before its first store
+    for (long long rb = r0 + rsub; rb < r1; rb += (long long)R * SPLITK_EPI_U) {
+        f32x4 gg[SPLITK_EPI_U], oo[SPLITK_EPI_U], zz[SPLITK_EPI_U];
 #pragma unroll
-            for (int u = 0; u < SPLITK_EPI_U; ++u) {
-                long long r = rb + (long long)u * R;
-                if (r >= r1) r = r1 - 1;                       // clamped: in range, result discarded below
-                const long long e = r * C + c;
-                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-                f32x4 g = mrcnn_slab_sum<f32x4>(zero4, p.slab, slab_stride, e, p.ksplit);
-                if (p.res_mode != MRCNN_RES_NONE) {
-                    const f32x4 v = *(const f32x4*)(p.res + e);
+        for (int u = 0; u < SPLITK_EPI_U; ++u) {
+            long long r = rb + (long long)u * R;
+            if (r >= r1) r = r1 - 1;                       // clamped: in range, result discarded below
+            const long long e = r * C + c;
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 g = mrcnn_slab_sum<f32x4>(zero4, p.slab, slab_stride, e, p.ksplit);
+            if (p.res_mode != MRCNN_RES_NONE) {
+                const f32x4 v = *(const f32x4*)(p.res + e);
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) g[q] += v[q];
-                }
-                gg[u] = g;
-                if (p.fb_act == MRCNN_ACT_RELU) oo[u] = *(const f32x4*)(p.fb_out + e);
-                if (p.fb_dgamma) zz[u] = *(const f32x4*)(p.fb_z + e);
+                for (int q = 0; q < 4; ++q) g[q] += v[q];
             }
-#pragma unroll
-            for (int u = 0; u < SPLITK_EPI_U; ++u) {
-                const long long r = rb + (long long)u * R;
-                if (r >= r1) break;
-                const long long e = r * C + c;
-                f32x4 g = gg[u];
-                if (p.fb_act == MRCNN_ACT_RELU) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) g[q] = oo[u][q] > 0.f ? g[q] : 0.f;
-                }
-                f32x4 dz;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) dz[q] = g[q] * sc[q];
-                *(f32x4*)(p.out + e) = dz;
-                if (p.fb_dgamma) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) a_dg[q] += g[q] * (zz[u][q] - mu[q]) * rs[q];
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { a_db[q] += g[q]; a_bias[q] += dz[q]; }
-            }
+            gg[u] = g;
+            if (p.fb_act == MRCNN_ACT_RELU) oo[u] = *(const f32x4*)(p.fb_out + e);
+            if (p.fb_dgamma) zz[u] = *(const f32x4*)(p.fb_z + e);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (p.fb_dbeta || p.fb_dgamma) atomicAdd(&sacc[c + q], a_db[q]);
-            if (p.fb_dgamma) atomicAdd(&sacc[C + c + q], a_dg[q]);
-            if (p.fb_dbias) atomicAdd(&sacc[2 * C + c + q], a_bias[q]);
+        for (int u = 0; u < SPLITK_EPI_U; ++u) {
+            const long long r = rb + (long long)u * R;
+            if (r >= r1) break;
+            const long long e = r * C + c;
+            f32x4 g = gg[u];
+            if (p.fb_act == MRCNN_ACT_RELU) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) g[q] = oo[u][q] > 0.f ? g[q] : 0.f;
+            }
+            f32x4 dz;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dz[q] = g[q] * sc[q];
+            *(f32x4*)(p.out + e) = dz;
+            if (p.fb_dgamma) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a_dg[q] += g[q] * (zz[u][q] - mu[q]) * rs[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { a_db[q] += g[q]; a_bias[q] += dz[q]; }
         }
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (p.fb_dbeta || p.fb_dgamma) atomicAdd(&sacc[lane * 4 + q], a_db[q]);
+        if (p.fb_dgamma) atomicAdd(&sacc[4 * L + lane * 4 + q], a_dg[q]);
+        if (p.fb_dbias) atomicAdd(&sacc[8 * L + lane * 4 + q], a_bias[q]);
+    }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        if (p.fb_dbeta) atomicAdd(&p.fb_dbeta[c], sacc[c]);
-        if (p.fb_dgamma) atomicAdd(&p.fb_dgamma[c], sacc[C + c]);
-        if (p.fb_dbias) atomicAdd(&p.fb_dbias[c], sacc[2 * C + c]);
+    const int cb = blockIdx.y * 4 * L;
+    for (int j = threadIdx.x; j < 4 * L; j += 256) {
+        if (p.fb_dbeta) atomicAdd(&p.fb_dbeta[cb + j], sacc[j]);
+        if (p.fb_dgamma) atomicAdd(&p.fb_dgamma[cb + j], sacc[4 * L + j]);
+        if (p.fb_dbias) atomicAdd(&p.fb_dbias[cb + j], sacc[8 * L + j]);
     }
 }
 
@@ -708,14 +763,15 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     else
         hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);
     if (a.ksplit > 1 && a.fb_act >= 0) {         // slabs -> epilogue backward of the layer below
-        long long rows_per_block = cdiv64(a.M, 2048);
-        const long long min_rows = cdiv64(mrcnn_epilogue_min_elems(), a.Cout);
-        if (rows_per_block < min_rows) rows_per_block = min_rows;
-        hipLaunchKernelGGL(conv_splitk_epilogue_bwd_kernel, dim3((unsigned)cdiv64(a.M, rows_per_block)), dim3(256),
-                           3 * a.Cout * sizeof(float), s, a, rows_per_block);
+        const EpiGrid g = mrcnn_epilogue_grid(a.M, a.Cout);
+        hipLaunchKernelGGL(conv_splitk_epilogue_bwd_kernel, dim3(g.row_blocks, g.chan_blocks), dim3(256), 0, s, a,
+                           g.rows_per_block, g.lg);
     } else if (a.ksplit > 1) {
         const long long n = (long long)a.M * a.Cout;
-        hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, a);
+        if (splitk_epilogue_vec_ok(a))
+            hipLaunchKernelGGL(conv_splitk_epilogue_vec_kernel, dim3((unsigned)cdiv64(n / 4, 256)), dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, a);
     }
     return mrcnn_launch_status();
 }
@@ -796,6 +852,7 @@ static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* 
     a.ons = d->out_n_stride; a.ohs = d->out_h_stride; a.ows = d->out_w_stride;
     a.M = (int)M; a.Ktot = d->KH * d->KW * d->Cin; a.nk = (a.Ktot + 31) / 32;
     a.d_ohw = make_fastdiv((unsigned)(d->OH * d->OW)); a.d_ow = make_fastdiv((unsigned)d->OW);
+    a.d_c4 = make_fastdiv((unsigned)(d->Cout >= 4 ? d->Cout / 4 : 1));
     a.fastA = (d->Cin % 32 == 0) && (d->KH * d->KW <= 64) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
     a.vecB = (d->Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
     a.dense = d->out_mode == MRCNN_OUT_NHWC && d->out_w_stride == d->Cout &&
