@@ -27,6 +27,10 @@ struct ConvArgs {
     float* fb_dgamma; float* fb_dbeta; float* fb_dbias; int fb_act;
 };
 
+// Padding taps, rows past M and columns past Cout fetch from here: loads stay unconditional (no divergent branch,
+// no conservative wait at the join).
+__device__ __attribute__((aligned(64))) float g_conv_zero_page[16];
+
 // One 32x32 accumulator tile: lane holds column n, rows mbase + (r&3) + 8*(r>>2).
 __device__ __forceinline__ void conv_epilogue_tile(const ConvArgs& p, const f32x16& acc, int mbase, int n) {
     if (n >= p.Cout) return;
@@ -90,6 +94,12 @@ __device__ __forceinline__ void conv_epilogue_tile_bwd(const ConvArgs& p, const 
     }
 }
 
+// K-steps of operand tiles held in registers ahead of the LDS stores.  1 = classic double buffering.  4 was measured
+// (whole split-K slices issued up front): no change on detect (3.96 vs 3.98 ms) or the training step -- these launches
+// sit on the ~4.8 us dependent-launch floor, not on the memory round trips of their 4-5 K-steps.
+#ifndef CONV_PREFETCH_STEPS
+#define CONV_PREFETCH_STEPS 1
+#endif
 template <int BM, int BN, int WM, int WN, bool FAST>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArgs p) {
     constexpr int NT = WM * WN * 64;
@@ -156,7 +166,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
         b_ptr[i] = p.w + (long long)krow * p.Cout + n0 + c4 * 4;
     }
 
-    f32x4 ra[AV], rb[BV];
+    constexpr int PF = (BM * BN > 64 * 128 && CONV_PREFETCH_STEPS > 2) ? 2 : CONV_PREFETCH_STEPS;   // big tiles: register budget
+    f32x4 ra[PF][AV], rb[PF][BV];
     int kh = 0, kw = 0, ci0 = 0, tap = 0;   // fast-path K-step position
     if (FAST && ks_begin > 0) {
         const int k0 = ks_begin * 32;
@@ -166,13 +177,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
         kw = tap - kh * p.KW;
     }
 
-    auto load_tiles = [&](int ks) {
+    auto load_tiles = [&](int ks, f32x4 (&ra)[AV], f32x4 (&rb)[BV]) {
         if (FAST) {
             const long long aoff = ((long long)kh * p.W + kw) * p.Cin + ci0;
 #pragma unroll
             for (int i = 0; i < AV; ++i) {
                 const bool v = (a_mask[i] >> tap) & 1ull;
-                ra[i] = v ? *(const f32x4*)(a_ptr[i] + aoff) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                ra[i] = *(const f32x4*)(v ? a_ptr[i] + aoff : g_conv_zero_page);
             }
             ci0 += 32;
             if (ci0 >= p.Cin) { ci0 = 0; ++tap; if (++kw == p.KW) { kw = 0; ++kh; } }
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
 #pragma unroll
             for (int i = 0; i < BV; ++i) {
                 if (p.vecB) {
-                    rb[i] = b_ok[i] ? *(const f32x4*)(b_ptr[i] + boff) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                    rb[i] = *(const f32x4*)(b_ok[i] ? b_ptr[i] + boff : g_conv_zero_page);
                 } else {                 // ragged Cout (RPN heads: 6 / 12 columns): scalar weight loads
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     const int nb = n0 + ((tid + i * NT) % (BN / 4)) * 4;
@@ -223,7 +234,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
             }
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](const f32x4 (&ra)[AV], const f32x4 (&rb)[BV]) {
 #pragma unroll
         for (int i = 0; i < AV; ++i) {
             int r = (tid >> 3) + i * AROWSTEP;
@@ -246,34 +257,37 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int li = lane & 31, lh = lane >> 5;
-    load_tiles(ks_begin);
-    store_tiles();
-    __syncthreads();
-    for (int ks = ks_begin; ks < ks_end; ++ks) {
-        if (ks + 1 < ks_end) load_tiles(ks + 1);
 #pragma unroll
-        for (int t4 = 0; t4 < 4; ++t4) {
-            f32x4 av[TM];
+    for (int j = 0; j < PF; ++j)
+        if (ks_begin + j < ks_end) load_tiles(ks_begin + j, ra[j], rb[j]);
+    for (int ks = ks_begin; ks < ks_end; ks += PF) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
-                av[a] = *(const f32x4*)&As[(wm * TM * 32 + a * 32 + li) * AST + lh * 16 + t4 * 4];
+        for (int j = 0; j < PF; ++j) {
+            if (ks + j < ks_end) {                                  // uniform
+                store_tiles(ra[j], rb[j]);                          // waits for step ks+j only: younger loads stay in flight
+                __syncthreads();
+                if (ks + j + PF < ks_end) load_tiles(ks + j + PF, ra[j], rb[j]);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float bv[TN];
+                for (int t4 = 0; t4 < 4; ++t4) {
+                    f32x4 av[TM];
 #pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    bv[b] = Bs[(lh * 16 + t4 * 4 + e) * BST + wn * TN * 32 + b * 32 + li];
+                    for (int a = 0; a < TM; ++a)
+                        av[a] = *(const f32x4*)&As[(wm * TM * 32 + a * 32 + li) * AST + lh * 16 + t4 * 4];
 #pragma unroll
-                for (int a = 0; a < TM; ++a)
+                    for (int e = 0; e < 4; ++e) {
+                        float bv[TN];
 #pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b], acc[a][b], 0, 0, 0);
+                        for (int b = 0; b < TN; ++b)
+                            bv[b] = Bs[(lh * 16 + t4 * 4 + e) * BST + wn * TN * 32 + b * 32 + li];
+#pragma unroll
+                        for (int a = 0; a < TM; ++a)
+#pragma unroll
+                            for (int b = 0; b < TN; ++b)
+                                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b], acc[a][b], 0, 0, 0);
+                    }
+                }
+                __syncthreads();
             }
-        }
-        __syncthreads();
-        if (ks + 1 < ks_end) {
-            store_tiles();
-            __syncthreads();
         }
     }
 
@@ -311,7 +325,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
 //     for the ds_read_b128 lane groups;
 //   B [16 k][128 n] is stored as is (512-byte rows) and read with conflict-free ds_read_b32 (lane = n).
 // Padding taps / rows past M fetch from a zero page.
-__device__ __attribute__((aligned(64))) float g_conv_zero_page[16];
 
 __device__ __forceinline__ void conv_glds16(const float* gsrc, float* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,

@@ -8,8 +8,9 @@ from caesar_mrcnn_amd.config import run_py_config
 from caesar_mrcnn_amd.model import MaskRCNN
 backbone = sys.argv[1] if len(sys.argv) > 1 else "resnet101"
 nimg = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+imgsize = int(os.environ.get("MRCNN_IMGSIZE", "256"))
 dev = torch.device("cuda", 0)
-cfg = run_py_config(num_classes=4, imgsize=256, backbone=backbone, images_per_gpu=nimg, gpu_count=1)
+cfg = run_py_config(num_classes=4, imgsize=imgsize, backbone=backbone, images_per_gpu=nimg, gpu_count=1)
 model = MaskRCNN("training", cfg, "/tmp/mrcnn_bench_logs", device=dev, seed=0)
 model.compile(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM)
 inp = model._to_device(bench.synthetic_batch(cfg, nimg, seed=1234))
