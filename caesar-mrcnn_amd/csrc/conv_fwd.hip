@@ -101,7 +101,7 @@ __device__ __forceinline__ void conv_epilogue_tile_bwd(const ConvArgs& p, const 
 #define CONV_PREFETCH_STEPS 1
 #endif
 template <int BM, int BN, int WM, int WN, bool FAST>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArgs p) {
+__device__ __forceinline__ void conv_fwd_body(const ConvArgs& p, const int block) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AST = 36;          // A row stride (floats): 32 + 4 pad -> conflict-free b128 reads
@@ -117,8 +117,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
     const int wm = wave / WN, wn = wave % WN;
     const int ntiles = (p.Cout + BN - 1) / BN;
     const int mtiles = (p.M + BM - 1) / BM;
-    const int kz = blockIdx.x / (mtiles * ntiles);
-    const int tile = blockIdx.x - kz * (mtiles * ntiles);
+    const int kz = block / (mtiles * ntiles);
+    const int tile = block - kz * (mtiles * ntiles);
     const int mtile = tile / ntiles, ntile = tile % ntiles;
     const int m0 = mtile * BM, n0 = ntile * BN;
     const int ks_begin = kz * p.ksteps;
@@ -313,6 +313,29 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArg
     if constexpr (TM >= 1 && TN >= 2) conv_epilogue_tile(p, acc[0][1], mw0, nw0 + 32);
     if constexpr (TM >= 2 && TN >= 1) conv_epilogue_tile(p, acc[1][0], mw0 + 32, nw0);
     if constexpr (TM >= 2 && TN >= 2) conv_epilogue_tile(p, acc[1][1], mw0 + 32, nw0 + 32);
+}
+
+template <int BM, int BN, int WM, int WN, bool FAST>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_kernel(const ConvArgs p) {
+    conv_fwd_body<BM, BN, WM, WN, FAST>(p, (int)blockIdx.x);
+}
+
+// Up to CONV_MULTI_MAX independent convolutions in one launch (mrcnn_conv2d_fwd_multi): the workgroups of problem g
+// are blocks first[g] .. first[g+1]-1; the split-K reductions of all problems likewise share one launch (efirst).
+#define CONV_MULTI_MAX 5
+struct ConvMultiArgs {
+    ConvArgs a[CONV_MULTI_MAX];
+    int first[CONV_MULTI_MAX + 1];
+    int efirst[CONV_MULTI_MAX + 1];
+    int evec[CONV_MULTI_MAX];
+    int n;
+};
+
+template <int BM, int BN, int WM, int WN, bool FAST>
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_fwd_multi_kernel(const ConvMultiArgs mp) {
+    int g = 0;
+    while (g + 1 < mp.n && (int)blockIdx.x >= mp.first[g + 1]) ++g;
+    conv_fwd_body<BM, BN, WM, WN, FAST>(mp.a[g], (int)blockIdx.x - mp.first[g]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -599,8 +622,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_blds_kernel(const ConvArgs p,
 }
 
 // Second pass of split-K: sum the slabs in a fixed order, then the ordinary epilogue.
-__global__ void conv_splitk_epilogue_kernel(const ConvArgs p) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void conv_splitk_epilogue_body(const ConvArgs& p, const unsigned block) {
+    const long long i = (long long)block * 256 + threadIdx.x;
     if (i >= (long long)p.M * p.Cout) return;
     const int m = (int)(i / p.Cout), n = (int)(i - (long long)m * p.Cout);
     const float a = mrcnn_slab_sum<float>(0.f, p.slab, (long long)p.M * p.Cout, i, p.ksplit);
@@ -635,8 +658,10 @@ __global__ void conv_splitk_epilogue_kernel(const ConvArgs p) {
 
 // Four channels per thread (Cout, cmod and the output strides multiples of 4, 16-byte aligned buffers, M*Cout < 2^31):
 // no 64-bit division, float4 traffic.  Same arithmetic per element as conv_splitk_epilogue_kernel.
-__global__ __launch_bounds__(256) void conv_splitk_epilogue_vec_kernel(const ConvArgs p) {
-    const unsigned i4 = blockIdx.x * 256u + threadIdx.x;
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvArgs p) { conv_splitk_epilogue_body(p, blockIdx.x); }
+
+__device__ __forceinline__ void conv_splitk_epilogue_vec_body(const ConvArgs& p, const unsigned block) {
+    const unsigned i4 = block * 256u + threadIdx.x;
     const unsigned c4 = (unsigned)p.Cout >> 2;
     if (i4 >= (unsigned)p.M * c4) return;
     const int m = (int)fast_div(i4, p.d_c4), n = (int)(i4 - (unsigned)m * c4) * 4;
@@ -682,6 +707,15 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_vec_kernel(const Con
         for (int q = 0; q < 4; ++q) y[q] = 1.f / (1.f + expf(-y[q]));
     }
     *(f32x4*)(p.out + addr) = y;
+}
+
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_vec_kernel(const ConvArgs p) { conv_splitk_epilogue_vec_body(p, blockIdx.x); }
+
+__global__ __launch_bounds__(256) void conv_splitk_epilogue_multi_kernel(const ConvMultiArgs mp) {
+    int g = 0;
+    while (g + 1 < mp.n && (int)blockIdx.x >= mp.efirst[g + 1]) ++g;
+    if (mp.evec[g]) conv_splitk_epilogue_vec_body(mp.a[g], blockIdx.x - (unsigned)mp.efirst[g]);
+    else conv_splitk_epilogue_body(mp.a[g], blockIdx.x - (unsigned)mp.efirst[g]);
 }
 
 static bool splitk_epilogue_vec_ok(const ConvArgs& a) {
@@ -818,7 +852,8 @@ static ConvPlan plan_conv(const mrcnn_conv_desc* d) {
     blocks = ((M + pl.bm - 1) / pl.bm) * ((Cout + pl.bn - 1) / pl.bn);
     pl.ksplit = 1;
     pl.ksteps = nk;
-    if (blocks < 768 && nk >= 8) {
+    static const long long split_below = getenv("MRCNN_SPLITK_BELOW") ? atoll(getenv("MRCNN_SPLITK_BELOW")) : 768;
+    if (blocks < split_below && nk >= 8) {
         long long want = (1024 + blocks - 1) / blocks;         // aim at ~4 workgroups per CU
         long long maxs = nk / 4;                               // at least 4 K-steps per slice
         long long ks = want < maxs ? want : maxs;
@@ -838,10 +873,9 @@ extern "C" size_t mrcnn_conv2d_fwd_workspace(const mrcnn_conv_desc* d) {
     return (size_t)pl.ksplit * d->N * d->OH * d->OW * d->Cout * sizeof(float);
 }
 
-static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* w,
-                         const float* bias, const float* scale, const float* shift,
-                         const float* res, float* out, float* z_out, void* workspace,
-                         size_t workspace_bytes, const mrcnn_bwd_epilogue* ep, void* stream) {
+// argument checks + everything of ConvArgs that does not depend on the launch plan
+static int conv_fill_args(const mrcnn_conv_desc* d, const float* x, const float* w, const float* bias, const float* scale,
+                          const float* shift, const float* res, float* out, float* z_out, ConvArgs& a) {
     if (!d || !x || !w || !out) return MRCNN_ERR_ARG;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 ||
         d->stride <= 0 || d->OH <= 0 || d->OW <= 0 || d->cmod <= 0)
@@ -857,7 +891,6 @@ static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* 
     long long M = (long long)d->N * d->OH * d->OW;
     if (M >= (1LL << 31) || (long long)d->KH * d->KW * d->Cin >= (1LL << 31)) return MRCNN_ERR_ARG;
 
-    ConvArgs a;
     a.x = x; a.w = w; a.bias = bias; a.scale = scale; a.shift = shift; a.res = res; a.out = out; a.z = z_out;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
     a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.OH = d->OH; a.OW = d->OW;
@@ -870,6 +903,21 @@ static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* 
     a.vecB = (d->Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
     a.dense = d->out_mode == MRCNN_OUT_NHWC && d->out_w_stride == d->Cout &&
               d->out_h_stride == (int64_t)d->OW * d->Cout && d->out_n_stride == (int64_t)d->OH * d->OW * d->Cout;
+    a.ksplit = 1; a.ksteps = a.nk; a.slab = nullptr;
+    a.fb_act = -1;
+    a.fb_out = a.fb_z = a.fb_scale = a.fb_mean = a.fb_rstd = nullptr;
+    a.fb_dgamma = a.fb_dbeta = a.fb_dbias = nullptr;
+    return MRCNN_OK;
+}
+
+static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* w,
+                         const float* bias, const float* scale, const float* shift,
+                         const float* res, float* out, float* z_out, void* workspace,
+                         size_t workspace_bytes, const mrcnn_bwd_epilogue* ep, void* stream) {
+    ConvArgs a;
+    const int rc = conv_fill_args(d, x, w, bias, scale, shift, res, out, z_out, a);
+    if (rc != MRCNN_OK) return rc;
+    const long long M = a.M;
     hipStream_t s = (hipStream_t)stream;
 
     ConvPlan pl = plan_conv(d);
@@ -879,9 +927,6 @@ static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* 
         pl.ksteps = a.nk;
     }
     a.ksplit = pl.ksplit; a.ksteps = pl.ksteps; a.slab = (float*)workspace;
-    a.fb_act = -1;
-    a.fb_out = a.fb_z = a.fb_scale = a.fb_mean = a.fb_rstd = nullptr;
-    a.fb_dgamma = a.fb_dbeta = a.fb_dbias = nullptr;
     const bool lds_dma = pl.bm == 128 && pl.bn == 128 && pl.ksplit == 1 && a.fastA && a.vecB && d->Cout % 128 == 0;
     if (ep) {                                   // fused backward epilogue: LDS-DMA kernel, dense output, plain store
         const long long xb = (long long)d->N * d->H * d->W * d->Cin * 4 + ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
@@ -933,4 +978,96 @@ extern "C" int mrcnn_conv2d_fwd(const mrcnn_conv_desc* d, const float* x, const 
                                 const float* bias, const float* scale, const float* shift,
                                 const float* res, float* out, float* z_out, void* stream) {
     return mrcnn_conv2d_fwd_ws(d, x, w, bias, scale, shift, res, out, z_out, nullptr, 0, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mrcnn_conv2d_fwd_multi: n <= 5 independent convolutions in one launch (+ one launch for their split-K reductions).
+// The reference applies the shared RPN model to the pyramid levels in a Python loop (model.py:2040-2055) and the FPN
+// smoothing convolutions one Keras layer after the other (model.py:2018-2026); on small feature maps those are a few
+// workgroups each and every dependent launch costs ~5 us, so the independent ones travel together.  Same arithmetic per
+// problem as mrcnn_conv2d_fwd_ws (same kernels, same K order within a slice; the slice count may differ).
+struct ConvMultiPlan { int bn, ks[CONV_MULTI_MAX], ksteps[CONV_MULTI_MAX]; size_t slab_off[CONV_MULTI_MAX], bytes; bool fast; };
+
+static int plan_conv_multi(const mrcnn_conv_problem* pr, int n, ConvMultiPlan& pl) {
+    if (!pr || n < 1 || n > CONV_MULTI_MAX) return MRCNN_ERR_ARG;
+    auto bn_of = [](int Cout) { return Cout <= 32 ? 32 : (Cout <= 64 ? 64 : 128); };
+    pl.bn = bn_of(pr[0].d.Cout);
+    long long tiles = 0;
+    for (int g = 0; g < n; ++g) {
+        const mrcnn_conv_desc& d = pr[g].d;
+        if (d.N <= 0 || d.OH <= 0 || d.OW <= 0 || d.Cout <= 0 || d.KH <= 0 || d.KW <= 0 || d.Cin <= 0) return MRCNN_ERR_ARG;
+        if (bn_of(d.Cout) != pl.bn) return MRCNN_ERR_UNSUPPORTED;
+        const long long M = (long long)d.N * d.OH * d.OW;
+        tiles += ((M + 63) / 64) * ((d.Cout + pl.bn - 1) / pl.bn);
+    }
+    if (tiles >= (1 << 20)) return MRCNN_ERR_UNSUPPORTED;
+    const long long want = tiles < 768 ? (1024 + tiles - 1) / tiles : 1;   // as plan_conv, on the launch as a whole
+    pl.bytes = 0;
+    for (int g = 0; g < n; ++g) {
+        const mrcnn_conv_desc& d = pr[g].d;
+        const int nk = (d.KH * d.KW * d.Cin + 31) / 32;
+        long long ks = want < nk / 4 ? want : nk / 4;
+        if (ks > 16) ks = 16;
+        pl.ks[g] = 1; pl.ksteps[g] = nk;
+        if (nk >= 8 && ks >= 2) {
+            pl.ksteps[g] = (int)((nk + ks - 1) / ks);
+            pl.ks[g] = (nk + pl.ksteps[g] - 1) / pl.ksteps[g];
+        }
+        pl.slab_off[g] = pl.bytes;
+        if (pl.ks[g] > 1) pl.bytes += (((size_t)pl.ks[g] * d.N * d.OH * d.OW * d.Cout * sizeof(float)) + 255) & ~(size_t)255;
+    }
+    return MRCNN_OK;
+}
+
+extern "C" size_t mrcnn_conv2d_fwd_multi_workspace(const mrcnn_conv_problem* problems, int n) {
+    ConvMultiPlan pl;
+    if (plan_conv_multi(problems, n, pl) != MRCNN_OK) return 0;
+    return pl.bytes;
+}
+
+template <int BN, int WN_, int WM_>
+static void launch_conv_multi(const ConvMultiArgs& mp, unsigned blocks, bool fast, hipStream_t s) {
+    if (fast) hipLaunchKernelGGL((conv_fwd_multi_kernel<64, BN, WM_, WN_, true>), dim3(blocks), dim3(WM_ * WN_ * 64), 0, s, mp);
+    else hipLaunchKernelGGL((conv_fwd_multi_kernel<64, BN, WM_, WN_, false>), dim3(blocks), dim3(WM_ * WN_ * 64), 0, s, mp);
+}
+
+extern "C" int mrcnn_conv2d_fwd_multi(const mrcnn_conv_problem* problems, int n, void* workspace, size_t workspace_bytes,
+                                      void* stream) {
+    ConvMultiPlan pl;
+    int rc = plan_conv_multi(problems, n, pl);
+    if (rc != MRCNN_OK) return rc;
+    if (pl.bytes && (!workspace || workspace_bytes < pl.bytes || (reinterpret_cast<uintptr_t>(workspace) & 15))) return MRCNN_ERR_ARG;
+    ConvMultiArgs mp;
+    mp.n = n;
+    bool fast = true;
+    long long blocks = 0, eblocks = 0;
+    for (int g = 0; g < n; ++g) {
+        const mrcnn_conv_problem& q = problems[g];
+        rc = conv_fill_args(&q.d, q.x, q.w, q.bias, q.scale, q.shift, q.res, q.out, q.z_out, mp.a[g]);
+        if (rc != MRCNN_OK) return rc;
+        ConvArgs& a = mp.a[g];
+        fast = fast && a.fastA;
+        a.ksplit = pl.ks[g]; a.ksteps = pl.ksteps[g];
+        a.slab = pl.ks[g] > 1 ? (float*)((char*)workspace + pl.slab_off[g]) : nullptr;
+        mp.first[g] = (int)blocks;
+        blocks += (long long)((a.M + 63) / 64) * ((a.Cout + pl.bn - 1) / pl.bn) * a.ksplit;
+        mp.efirst[g] = (int)eblocks;
+        mp.evec[g] = 0;
+        if (a.ksplit > 1) {
+            mp.evec[g] = splitk_epilogue_vec_ok(a) ? 1 : 0;
+            const long long ne = (long long)a.M * a.Cout;
+            eblocks += mp.evec[g] ? cdiv64(ne / 4, 256) : cdiv64(ne, 256);
+        }
+    }
+    mp.first[n] = (int)blocks; mp.efirst[n] = (int)eblocks;
+    for (int g = n; g < CONV_MULTI_MAX; ++g) { mp.first[g + 1] = (int)blocks; mp.efirst[g + 1] = (int)eblocks; mp.evec[g] = 0; }
+    if (!fast)
+        for (int g = 0; g < n; ++g) mp.a[g].fastA = 0;
+    if (blocks >= (1ll << 31) || eblocks >= (1ll << 31)) return MRCNN_ERR_UNSUPPORTED;
+    hipStream_t s = (hipStream_t)stream;
+    if (pl.bn == 32) launch_conv_multi<32, 1, 2>(mp, (unsigned)blocks, fast, s);
+    else if (pl.bn == 64) launch_conv_multi<64, 2, 2>(mp, (unsigned)blocks, fast, s);
+    else launch_conv_multi<128, 2, 2>(mp, (unsigned)blocks, fast, s);
+    if (eblocks > 0) hipLaunchKernelGGL(conv_splitk_epilogue_multi_kernel, dim3((unsigned)eblocks), dim3(256), 0, s, mp);
+    return mrcnn_launch_status();
 }

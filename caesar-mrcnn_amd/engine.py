@@ -10,6 +10,7 @@ Gradient plumbing conventions
     convolution can add an existing buffer in its epilogue (res_mode SAME, in place);
   * the ROIAlign adjoints scatter-add into zero-initialised pyramid gradients first.
 """
+import os
 import numpy as np
 import torch
 
@@ -190,6 +191,7 @@ class MaskRCNNEngine(object):
         self.fused_dgrad_epilogue = True  # data-gradient convs of the mask head apply the lower layer's epilogue backward
         self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self.aux_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self.multi_launch = os.environ.get("MRCNN_MULTI_LAUNCH", "1") != "0"     # independent small convolutions share launches
 
     def op(self, name):
         return self._ops[name]
@@ -359,6 +361,21 @@ class MaskRCNNEngine(object):
         bbox = ops.empty((B, A, 4), torch.float32, self.dev)
         shared, cls, box = self.op("rpn_conv_shared"), self.op("rpn_class_raw"), self.op("rpn_bbox_pred")
         tape, off = [], 0
+        if self.multi_launch and len(pyramid) <= 5:
+            # the levels are independent and P3..P6 are a handful of workgroups each: one launch per layer for all levels
+            ss = ops.conv2d_multi([dict(x=p, w=shared.w, bias=shared.b, act=ACT_RELU) for p in pyramid])
+            assert ss is not None                       # one weight tensor: the levels always share a launch shape
+            offs = []
+            for p in pyramid:
+                offs.append(off)
+                off += p.shape[1] * p.shape[2] * na
+            ops.conv2d_multi([dict(x=s, w=cls.w, bias=cls.b, padding="valid", out_ptr=logits.data_ptr() + o * 2 * 4,
+                                   out_strides=(A * 2, s.shape[2] * 2 * na, 2 * na)) for s, o in zip(ss, offs)])
+            ops.conv2d_multi([dict(x=s, w=box.w, bias=box.b, padding="valid", out_ptr=bbox.data_ptr() + o * 4 * 4,
+                                   out_strides=(A * 4, s.shape[2] * 4 * na, 4 * na)) for s, o in zip(ss, offs)])
+            for p, s, o in zip(pyramid, ss, offs):
+                tape.append(((p, None, s, ACT_RELU) if train else None, (s, None, None, ACT_NONE), o, p.shape[1], p.shape[2]))
+            return logits, ops.softmax_rows(logits), bbox, tape
         for p in pyramid:
             s, cs = shared.forward(p, ACT_RELU, train=train)
             H, W = p.shape[1], p.shape[2]

@@ -101,6 +101,42 @@ def conv2d_into(x, w, bias, out_view_ptr, n_stride, h_stride, w_stride, stride=1
                                       current_stream()), "mrcnn_conv2d_fwd(into)")
 
 
+def conv2d_multi(problems):
+    """Up to 5 independent convolutions in one launch (mrcnn_conv2d_fwd_multi).  Each problem is a dict:
+    x, w, and optionally bias, scale, shift, res, res_mode, stride, padding, act, z_out, and either `out` (a dense
+    tensor, allocated when missing) or `out_ptr` + `out_strides` (n, h, w strides in floats, as conv2d_into).
+    Returns the list of `out` tensors (None where out_ptr was given), or None when the problems do not share a
+    launch shape (the caller then issues them one by one)."""
+    n = len(problems)
+    arr = (_hip.ConvProblem * n)()
+    outs = []
+    for q, pr in zip(arr, problems):
+        x, w = pr["x"], pr["w"]
+        _need_cuda(x, w, pr.get("bias"), pr.get("scale"), pr.get("shift"), pr.get("res"), pr.get("out"), pr.get("z_out"))
+        d = conv_desc(tuple(x.shape), tuple(w.shape), pr.get("stride", 1), pr.get("padding", "same"), pr.get("act", ACT_NONE),
+                      pr.get("res_mode", RES_NONE))
+        out = pr.get("out")
+        if "out_ptr" in pr:
+            d.out_n_stride, d.out_h_stride, d.out_w_stride = pr["out_strides"]
+            q.out = pr["out_ptr"]
+            out = None
+        else:
+            if out is None:
+                out = empty((d.N, d.OH, d.OW, d.Cout), torch.float32, x.device)
+            q.out = ptr(out)
+        outs.append(out)
+        q.d = d
+        q.x, q.w, q.bias, q.scale, q.shift = ptr(x), ptr(w), ptr(pr.get("bias")), ptr(pr.get("scale")), ptr(pr.get("shift"))
+        q.res, q.z_out = ptr(pr.get("res")), ptr(pr.get("z_out"))
+    nbytes = _hip.lib().mrcnn_conv2d_fwd_multi_workspace(arr, n)
+    ws = workspace(nbytes, problems[0]["x"].device, "conv_splitk") if nbytes else None
+    rc = _hip.lib().mrcnn_conv2d_fwd_multi(arr, n, ptr(ws), ws.numel() if ws is not None else 0, current_stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    check(rc, "mrcnn_conv2d_fwd_multi")
+    return outs
+
+
 def deconv2x2(x, w_gemm, bias, act=ACT_RELU, out=None):
     """Conv2DTranspose(2x2, stride 2): x [N,H,W,Cin], w_gemm [Cin, 4*Cd] with column (a*2+b)*Cd+co."""
     _need_cuda(x, w_gemm, bias, out)

@@ -84,6 +84,21 @@ int mrcnn_weight_flip_transpose(const float* w, float* w_t, int KH, int KW, int 
 int mrcnn_weight_flip_transpose_batched(const float* params, float* params_t, const void* table, int n_layers,
                                         int total_tiles, void* stream);
 
+/* n <= 5 independent convolutions in ONE launch (plus one for their split-K reductions).  Replaces the Python loops
+ * of the reference that apply one layer to several small feature maps in turn: the shared RPN model over the pyramid
+ * levels (mrcnn/model.py:2040-2055, rpn_graph :916-957) and the FPN smoothing convolutions (:2018-2026).  Every problem
+ * is an ordinary mrcnn_conv2d_fwd (own descriptor, pointers and output strides); all must fall into the same output
+ * tile class (Cout <= 32, <= 64 or larger), else MRCNN_ERR_UNSUPPORTED and nothing is launched.  Results are those of
+ * n mrcnn_conv2d_fwd_ws calls (same kernels; the K-slice count may differ, i.e. fp32 summation order only).      */
+typedef struct mrcnn_conv_problem {
+    mrcnn_conv_desc d;
+    const float* x; const float* w; const float* bias; const float* scale; const float* shift; const float* res;
+    float* out; float* z_out;
+} mrcnn_conv_problem;
+size_t mrcnn_conv2d_fwd_multi_workspace(const mrcnn_conv_problem* problems, int n);
+int mrcnn_conv2d_fwd_multi(const mrcnn_conv_problem* problems, int n, void* workspace, size_t workspace_bytes,
+                           void* stream);
+
 /* Data-gradient convolution fused with the epilogue backward of the layer below (TF autodiff through Conv2D, then
  * through the lower layer's Activation / BatchNorm / bias): y = conv(dz, w_t) (+ res) is d(loss)/d(out_below); stored is
  *   dz_below = y * act'(out_below) * scale_below,   and   dbeta += sum y*act',  dgamma += sum y*act'*(z-mean)*rstd,

@@ -90,6 +90,53 @@ def test_conv_fwd(dev, case):
     torch.testing.assert_close(z.cpu(), z_ref, **F32)
 
 
+def test_conv_multi_launch_matches_oracle(dev):
+    """mrcnn_conv2d_fwd_multi: the RPN model over five pyramid levels in three launches (model.py:2040-2055) --
+    shared 3x3 + ReLU, then the two 1x1 heads written straight into the concatenated [B, A, *] buffers -- and four
+    independent convolutions with their own weights, frozen BN and pre-BN outputs (FPN smoothing shape)."""
+    ops = _ops()
+    rng = np.random.default_rng(77)
+    B, C, na = 2, 64, 3
+    sizes = [(16, 16), (8, 8), (4, 4), (2, 2), (1, 1)]
+    w = _rand(rng, 3, 3, C, 96, scale=1.0 / np.sqrt(9 * C)); b = _rand(rng, 96, scale=0.1)
+    wc = _rand(rng, 1, 1, 96, 2 * na, scale=0.1); bc = _rand(rng, 2 * na, scale=0.1)
+    xs = [_rand(rng, B, h, wd, C) for h, wd in sizes]
+    dv = lambda a: torch.tensor(a, device=dev)
+    ss = ops.conv2d_multi([dict(x=dv(x), w=dv(w), bias=dv(b), act=1) for x in xs])
+    assert ss is not None
+    A = sum(h * wd * na for h, wd in sizes)
+    logits = torch.full((B, A, 2), -9.0, device=dev)
+    off, probs, offs = 0, [], []
+    for (h, wd), s in zip(sizes, ss):
+        offs.append(off)
+        off += h * wd * na
+    ops.conv2d_multi([dict(x=s, w=dv(wc), bias=dv(bc), padding="valid", out_ptr=logits.data_ptr() + o * 2 * 4,
+                           out_strides=(A * 2, s.shape[2] * 2 * na, 2 * na)) for s, o in zip(ss, offs)])
+    torch.cuda.synchronize()
+    ref_logits = []
+    for x, s in zip(xs, ss):
+        r = torch.relu(orc.conv2d_nhwc(torch.tensor(x), torch.tensor(w), torch.tensor(b), 1, "same"))
+        torch.testing.assert_close(s.cpu(), r, **F32)
+        ref_logits.append(orc.conv2d_nhwc(r, torch.tensor(wc), torch.tensor(bc), 1, "valid").reshape(B, -1, 2))
+    torch.testing.assert_close(logits.cpu(), torch.cat(ref_logits, 1), **F32)
+    # own weights per problem, frozen BN, z_out, different Cin (K-slice counts differ per problem)
+    probs, refs = [], []
+    for i, ((h, wd), cin) in enumerate(zip(sizes[:4], (64, 128, 32, 256))):
+        x = _rand(rng, B, h, wd, cin); wi = _rand(rng, 3, 3, cin, 256, scale=1.0 / np.sqrt(9 * cin)); bi = _rand(rng, 256, scale=0.1)
+        sc = rng.uniform(.5, 1.5, 256).astype(np.float32); sh = rng.uniform(-.2, .2, 256).astype(np.float32)
+        z = torch.empty((B, h, wd, 256), device=dev)
+        probs.append(dict(x=dv(x), w=dv(wi), bias=dv(bi), scale=dv(sc), shift=dv(sh), z_out=z))
+        zr = orc.conv2d_nhwc(torch.tensor(x), torch.tensor(wi), torch.tensor(bi), 1, "same")
+        refs.append((zr, zr * torch.tensor(sc) + torch.tensor(sh)))
+    outs = ops.conv2d_multi(probs)
+    torch.cuda.synchronize()
+    for pr, o, (zr, yr) in zip(probs, outs, refs):
+        torch.testing.assert_close(pr["z_out"].cpu(), zr, **F32)
+        torch.testing.assert_close(o.cpu(), yr, **F32)
+    # different output-tile classes do not share a launch: reported, nothing launched
+    assert ops.conv2d_multi([dict(x=dv(xs[0]), w=dv(w), bias=dv(b)), dict(x=ss[0], w=dv(wc), bias=dv(bc), padding="valid")]) is None
+
+
 def test_conv_into_concat_buffer(dev):
     """RPN heads write each pyramid level straight into the concatenated [B, A, 2] buffer."""
     ops = _ops()
