@@ -239,6 +239,43 @@ class MaskRCNNEngine(object):
         self._h16[dc.name] = ops.weights_to_h16(dc.w, self.head_dtype)
         self._h16_valid = True
 
+    # ---- independent small convolutions in one launch (mrcnn_conv2d_fwd_multi) ------------------------
+    def _forward_multi(self, layers, xs, act=ACT_NONE, train=False):
+        """[ConvOp.forward(x, act) for layer, x in zip(layers, xs)] as one launch; falls back to the loop."""
+        if self.multi_launch and 1 < len(layers) <= 5:
+            probs, zs = [], []
+            for op, x in zip(layers, xs):
+                d = ops.conv_desc(tuple(x.shape), op.wshape, op.stride, op.padding, act)
+                out = ops.empty((d.N, d.OH, d.OW, d.Cout), torch.float32, x.device)
+                z = ops.empty_like(out) if (train and op.bn) else None
+                zs.append(z)
+                probs.append(dict(x=x, w=op.w, bias=op.b, scale=op.scale, shift=op.shift, stride=op.stride,
+                                  padding=op.padding, act=act, out=out, z_out=z))
+            outs = ops.conv2d_multi(probs)
+            if outs is not None:
+                return [(o, (x, z, o, act) if train else None) for o, x, z in zip(outs, xs, zs)]
+        return [op.forward(x, act, train=train) for op, x in zip(layers, xs)]
+
+    def _dgrad_multi(self, layers, dzs, ctxs, outs=None, accumulate=False):
+        """[ConvOp.dgrad(dz, ctx, out, accumulate)] for stride-1 SAME / 1x1 layers as one launch (else the loop)."""
+        outs = list(outs) if outs is not None else [None] * len(layers)
+        accs = list(accumulate) if isinstance(accumulate, (list, tuple)) else [accumulate] * len(layers)
+        ok = self.multi_launch and self.wt_valid and 1 < len(layers) <= 5 and all(
+            op.stride == 1 and (op.padding == "same" or (op.wshape[0] == 1 and op.wshape[1] == 1)) for op in layers)
+        if ok:
+            probs = []
+            for i, (op, dz, ctx) in enumerate(zip(layers, dzs, ctxs)):
+                kh, kw = op.wshape[0], op.wshape[1]
+                if outs[i] is None:
+                    assert not accs[i]
+                    outs[i] = ops.empty_like(ctx[0])
+                probs.append(dict(x=dz, w=op.wt, padding=((kh - 1) // 2, (kw - 1) // 2) if op.padding == "same" else "valid",
+                                  res=outs[i] if accs[i] else None, res_mode=RES_SAME if accs[i] else RES_NONE,
+                                  out=outs[i]))
+            if ops.conv2d_multi(probs) is not None:
+                return outs
+        return [op.dgrad(dz, ctx, out=o, accumulate=a) for op, dz, ctx, o, a in zip(layers, dzs, ctxs, outs, accs)]
+
     def join_wgrad(self):
         if self.wgrad_stream is not None:
             torch.cuda.current_stream(self.dev).wait_stream(self.wgrad_stream)
@@ -344,10 +381,11 @@ class MaskRCNNEngine(object):
         P4s, tape["fpn_c4p4"] = self.op("fpn_c4p4").forward(C4, res=P5s, res_mode=RES_UP2, train=train)
         P3s, tape["fpn_c3p3"] = self.op("fpn_c3p3").forward(C3, res=P4s, res_mode=RES_UP2, train=train)
         P2s, tape["fpn_c2p2"] = self.op("fpn_c2p2").forward(C2, res=P3s, res_mode=RES_UP2, train=train)
-        P2, tape["fpn_p2"] = self.op("fpn_p2").forward(P2s, train=train)
-        P3, tape["fpn_p3"] = self.op("fpn_p3").forward(P3s, train=train)
-        P4, tape["fpn_p4"] = self.op("fpn_p4").forward(P4s, train=train)
-        P5, tape["fpn_p5"] = self.op("fpn_p5").forward(P5s, train=train)
+        names = ("fpn_p2", "fpn_p3", "fpn_p4", "fpn_p5")
+        res = self._forward_multi([self.op(n) for n in names], [P2s, P3s, P4s, P5s], train=train)
+        (P2, P3, P4, P5) = [r[0] for r in res]
+        for n, r in zip(names, res):
+            tape[n] = r[1]
         P6 = ops.subsample2(P5)
         return [P2, P3, P4, P5, P6], tape
 
@@ -711,6 +749,30 @@ class MaskRCNNEngine(object):
         B, A = d_logits.shape[0], d_logits.shape[1]
         shared, cls, box = self.op("rpn_conv_shared"), self.op("rpn_class_raw"), self.op("rpn_bbox_pred")
         dP6 = None
+        if self.multi_launch and self.wt_valid and len(rpn_tape) == 5:
+            # level by level only what is elementwise; the data-gradient convolutions of the five levels share launches
+            n = len(rpn_tape)
+            dzl, dzb, heads = [], [], []
+            for lvl, (cs, chead, off, H, W) in enumerate(rpn_tape):
+                gl = ops.empty((B, H, W, 2 * na), torch.float32, self.dev)
+                gb = ops.empty((B, H, W, 4 * na), torch.float32, self.dev)
+                ops.copy2d(gl.data_ptr(), H * W * 2 * na * 4, d_logits.data_ptr() + off * 2 * 4, A * 2 * 4, H * W * 2 * na * 4, B)
+                ops.copy2d(gb.data_ptr(), H * W * 4 * na * 4, d_bbox.data_ptr() + off * 4 * 4, A * 4 * 4, H * W * 4 * na * 4, B)
+                dz, _ = cls.epilogue_bwd(gl, chead)
+                cls.wgrad(dz, chead, accumulate=lvl > 0)             # weights shared by the 5 levels
+                dzl.append(dz)
+                dz, _ = box.epilogue_bwd(gb, chead)
+                box.wgrad(dz, chead, accumulate=lvl > 0)
+                dzb.append(dz)
+                heads.append(chead)
+            d_s = self._dgrad_multi([cls] * n, dzl, heads)
+            self._dgrad_multi([box] * n, dzb, heads, outs=d_s, accumulate=True)
+            dzs, ctxs = [], []
+            for lvl, (cs, chead, off, H, W) in enumerate(rpn_tape):
+                dz, _ = shared.epilogue_bwd(d_s[lvl], cs)
+                shared.wgrad(dz, cs, accumulate=lvl > 0)
+                dzs.append(dz); ctxs.append(cs)
+            return self._dgrad_multi([shared] * n, dzs, ctxs, outs=list(dP[:4]) + [None], accumulate=[True] * 4 + [False])[4]
         for lvl, (cs, chead, off, H, W) in enumerate(rpn_tape):
             gl = ops.empty((B, H, W, 2 * na), torch.float32, self.dev)
             gb = ops.empty((B, H, W, 4 * na), torch.float32, self.dev)
@@ -735,22 +797,23 @@ class MaskRCNNEngine(object):
     def _trunk_bwd(self, dP, dP6, tape):
         dP2, dP3, dP4, dP5 = dP
         ops.subsample2_bwd_acc(dP6, dP5)
-        dS = {}
+        layers, dzs, cs = [], [], []
         for name, g in (("fpn_p5", dP5), ("fpn_p4", dP4), ("fpn_p3", dP3), ("fpn_p2", dP2)):
             op, c = self.op(name), tape[name]
             dz, _ = op.epilogue_bwd(g, c)
             op.wgrad(dz, c)
-            dS[name] = op.dgrad(dz, c)
-        d5s, d4s, d3s, d2s = dS["fpn_p5"], dS["fpn_p4"], dS["fpn_p3"], dS["fpn_p2"]
+            layers.append(op); dzs.append(dz); cs.append(c)
+        d5s, d4s, d3s, d2s = self._dgrad_multi(layers, dzs, cs)        # four independent 3x3 data gradients: one launch
         ops.upsample2_bwd(d2s, d3s, True)
         ops.upsample2_bwd(d3s, d4s, True)
         ops.upsample2_bwd(d4s, d5s, True)
-        dC = []
+        layers, dzs, cs = [], [], []
         for name, g in (("fpn_c2p2", d2s), ("fpn_c3p3", d3s), ("fpn_c4p4", d4s), ("fpn_c5p5", d5s)):
             op, c = self.op(name), tape[name]
             dz, _ = op.epilogue_bwd(g, c)
             op.wgrad(dz, c)
-            dC.append(op.dgrad(dz, c))
+            layers.append(op); dzs.append(dz); cs.append(c)
+        dC = self._dgrad_multi(layers, dzs, cs)                         # and the four lateral 1x1 ones
         if self.grad_ready:
             self.join_wgrad()
             self.grad_ready(*self.grad_ranges["tail"])
