@@ -191,6 +191,7 @@ class MaskRCNNEngine(object):
         self.fused_dgrad_epilogue = True  # data-gradient convs of the mask head apply the lower layer's epilogue backward
         self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self.aux_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self.sorted_roialign_bwd = os.environ.get("MRCNN_SORTED_ROIALIGN_BWD", "1") != "0"   # class-head ROIAlign adjoint in gather form
         self.multi_launch = os.environ.get("MRCNN_MULTI_LAUNCH", "1") != "0"     # independent small convolutions share launches
 
     def op(self, name):
@@ -742,7 +743,8 @@ class MaskRCNNEngine(object):
         op1.wgrad(dz, c1)
         d_pool = op1.dgrad(dz, c1)
         B, R = rois.shape[0], rois.shape[1]
-        ops.roialign_bwd(rois, d_pool.view(B, R, cfg.POOL_SIZE, cfg.POOL_SIZE, -1), dP, cfg.POOL_SIZE, area)
+        ops.roialign_bwd(rois, d_pool.view(B, R, cfg.POOL_SIZE, cfg.POOL_SIZE, -1), dP, cfg.POOL_SIZE, area,
+                         dense=self.sorted_roialign_bwd)
 
     def _rpn_bwd(self, d_logits, d_bbox, rpn_tape, dP):
         na = len(self.cfg.RPN_ANCHOR_RATIOS)

@@ -320,6 +320,38 @@ def test_roialign_fwd_bwd(dev, pool):
     torch.cuda.synchronize()
     for a, f in zip(dfm, fms):
         torch.testing.assert_close(a.cpu(), f.grad, rtol=1e-4, atol=1e-4)
+    # gather form (records bucketed by destination pixel): same adjoint, accumulating onto what the maps already hold
+    dfm2 = [torch.full_like(f, 0.25) for f in fd]
+    ops.roialign_bwd(torch.tensor(rois, device=dev), dout.to(dev), dfm2, pool, 1024.0 * 1024.0, dense=True)
+    torch.cuda.synchronize()
+    for a, f in zip(dfm2, fms):
+        torch.testing.assert_close(a.cpu() - 0.25, f.grad, rtol=1e-4, atol=1e-4)
+
+
+def test_roialign_bwd_sorted_heavy_overlap(dev):
+    """512 ROIs per image clustered on a few objects (the class head's training shape at 256^2 inputs: hundreds of
+    records per pixel, a list longer than one 32-record chunk for most pixels, zero-padded rows all on pixel (0,0))."""
+    ops = _ops()
+    rng = np.random.default_rng(99)
+    B, R, C, pool = 2, 512, 256, 7
+    fms = [torch.zeros(B, s, s, C, requires_grad=True) for s in (64, 32, 16, 8)]
+    ctr = rng.uniform(0.3, 0.7, (B, 4, 2))
+    rois = np.zeros((B, R, 4), np.float32)
+    for b in range(B):
+        for r in range(R - 20):
+            c = ctr[b, r % 4] + rng.normal(0, 0.03, 2)
+            hw = np.exp(rng.uniform(np.log(0.08), np.log(0.9), 2))
+            rois[b, r] = np.clip([c[0] - hw[0] / 2, c[1] - hw[1] / 2, c[0] + hw[0] / 2, c[1] + hw[1] / 2], 0, 1)
+    area = 256.0 * 256.0
+    ref = orc.pyramid_roi_align(rois, fms, pool, area)
+    dout = torch.tensor(_rand(rng, *ref.shape))
+    ref.backward(dout)
+    dfm = [torch.zeros(B, s, s, C, device=dev) for s in (64, 32, 16, 8)]
+    ops.roialign_bwd(torch.tensor(rois, device=dev), dout.to(dev), dfm, pool, area, dense=True)
+    torch.cuda.synchronize()
+    for a, f in zip(dfm, fms):
+        g = f.grad if f.grad is not None else torch.zeros_like(f)          # no ROI reaches P5 at this image area
+        torch.testing.assert_close(a.cpu(), g, rtol=2e-4, atol=2e-3)          # sums of several hundred terms per pixel
 
 
 @pytest.mark.parametrize("A,limit,count,thr", [(16368, 6000, 2000, 0.7), (16368, 6000, 1000, 0.7), (3000, 6000, 1000, 0.5),
