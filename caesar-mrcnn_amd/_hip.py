@@ -92,8 +92,7 @@ _SIGNATURES = {
     "mrcnn_softmax_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "mrcnn_roialign_fwd": (C.c_int, [C.POINTER(RoiAlignDesc)] + [_P] * 8),
     "mrcnn_roialign_bwd": (C.c_int, [C.POINTER(RoiAlignDesc)] + [_P] * 7),
-    "mrcnn_roialign_bwd_sorted_workspace": (C.c_size_t, [C.POINTER(RoiAlignDesc)]),
-    "mrcnn_roialign_bwd_sorted": (C.c_int, [C.POINTER(RoiAlignDesc)] + [_P] * 7 + [C.c_size_t, _P]),
+    "mrcnn_roialign_bwd_gather": (C.c_int, [C.POINTER(RoiAlignDesc)] + [_P] * 7),
     "mrcnn_proposal_workspace": (C.c_size_t, [C.POINTER(ProposalDesc)]),
     "mrcnn_proposal_fwd": (C.c_int, [C.POINTER(ProposalDesc)] + [_P] * 8 + [C.c_size_t, _P]),
     "mrcnn_detection_targets": (C.c_int, [C.POINTER(DetTargetDesc)] + [_P] * 12),

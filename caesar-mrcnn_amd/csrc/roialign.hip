@@ -143,211 +143,153 @@ extern "C" int mrcnn_roialign_bwd(const mrcnn_roialign_desc* d, const float* box
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Gather form of the adjoint (mrcnn_roialign_bwd_sorted).  In training every one of the B*R class-head ROIs
+// Gather form of the adjoint (mrcnn_roialign_bwd_gather).  In training every one of the B*R class-head ROIs
 // carries gradient and they pile up on a few thousand pyramid pixels (512 ROIs per image on 64^2 + 32^2 + 16^2
 // pixels at 256^2 inputs): the scatter form issues 4 * 256 float atomics per bin (103 M per step) with ~20-fold
-// average and several-hundred-fold peak contention per address -- 1.3 ms alone, 2.5 ms beside the mask head.
-// Here the (bin, corner) records are bucketed by destination pixel with a counting sort (histogram, scan,
-// scatter), then one wave per 32 consecutive records sums  w * dout[bin, :]  in registers and issues one row of
-// atomics per run of equal pixels: ~(pixels + chunks) * 256 atomics instead of records * 256.
-// Summation order inside a pixel follows the scatter cursor (atomics), so -- exactly like the scatter form -- the
-// result is not bitwise reproducible between runs.
-struct RoiSortArgs {
+// average and several-hundred-fold peak contention per address -- 1.3 ms alone, 2.5 ms beside the mask head, and
+// on the critical path of the step.
+// Bilinear sampling is separable, so the adjoint can be read off per destination pixel without any sorting:
+// pixel (y, x) of level l receives  sum over ROIs of level l, over the samples (py, px) whose floor or ceil row /
+// column is (y, x), of  wy * wx * dout[roi, py, px, :].  One wave per pixel: lanes test 64 ROIs of the pixel's
+// image at a time (level, then which of the P sample rows / columns touch y / x: two P-bit masks), the hits are
+// walked wave-uniformly and their rows accumulated in registers (lane = 4 channels), one row of atomics at the
+// end (the mask head's adjoint may be adding to the same maps on another stream).  Weights are the very factors of
+// the scatter form ((1 - yl) for the floor row, yl for the ceil row), so the two forms differ by summation order only.
+// A pixel under hundreds of ROIs is a long dependent chain if rows are fetched one by one, so the hits of 64 ROIs are
+// first staged as (row, weight) entries in LDS (lane-parallel, fixed (ROI, py, px) order) and then read eight rows at a
+// time; ROI_GATHER_SPLIT waves share a pixel (every 4th block of 64 ROIs each).
+struct RoiGatherArgs {
     RoiArgs r;
-    int* cursor;                         // [npix + 1]: histogram -> exclusive prefix -> bucket ends; [npix] = total
-    int* rec_pix; int* rec_bin; float* rec_w;
-    int lvl_off[5];                      // first global pixel id of P2..P5, [4] = npix
-    int npix, nbins;
+    int lvl_off[5];                      // first wave (pixel) id of P2..P5, [4] = number of pixels
 };
 
-// the four (pixel, weight) pairs of a bin; false when the sample lies outside the map (no gradient)
-__device__ __forceinline__ bool roi_bin_corners(const RoiSortArgs& q, int bin, int pix[4], float w[4]) {
+#define ROI_GATHER_CAP 256        // (row, weight) entries staged per wave and round
+#define ROI_GATHER_SPLIT 4        // waves per pixel: each takes every 4th block of 64 ROIs (hot pixels set the tail)
+
+__global__ __launch_bounds__(256) void roialign_bwd_gather_kernel(const RoiGatherArgs q) {
+    __shared__ int q_row[4][ROI_GATHER_CAP];
+    __shared__ float q_w[4][ROI_GATHER_CAP];
     const RoiArgs& p = q.r;
-    const int px = bin % p.P;
-    const int py = (bin / p.P) % p.P;
-    const int roi = bin / (p.P * p.P);
-    const int b = roi / p.R;
-    const float* bx = p.boxes + (int64_t)roi * 4;
-    const float y1 = bx[0], x1 = bx[1], y2 = bx[2], x2 = bx[3];
-    const int li = roi_level(y1, x1, y2, x2, p.image_area) - 2;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wid = blockIdx.x * 4 + wv;
+    const int pix = wid / ROI_GATHER_SPLIT, part = wid - pix * ROI_GATHER_SPLIT;
+    if (pix >= q.lvl_off[4]) return;
+    int li = 0;
+    while (li < 3 && pix >= q.lvl_off[li + 1]) ++li;
     const int H = p.H[li], W = p.W[li];
-    float in_y, in_x;
-    if (p.P > 1) {
-        const float hs = (y2 - y1) * (float)(H - 1) / (float)(p.P - 1);
-        const float ws = (x2 - x1) * (float)(W - 1) / (float)(p.P - 1);
-        in_y = y1 * (float)(H - 1) + (float)py * hs;
-        in_x = x1 * (float)(W - 1) + (float)px * ws;
-    } else {
-        in_y = 0.5f * (y1 + y2) * (float)(H - 1);
-        in_x = 0.5f * (x1 + x2) * (float)(W - 1);
-    }
-    if (in_y < 0.f || in_y > (float)(H - 1) || in_x < 0.f || in_x > (float)(W - 1) || in_y != in_y || in_x != in_x) return false;
-    const int top = (int)floorf(in_y), bot = (int)ceilf(in_y);
-    const int lef = (int)floorf(in_x), rig = (int)ceilf(in_x);
-    const float yl = in_y - (float)top, xl = in_x - (float)lef;
-    const int base = q.lvl_off[li] + b * H * W;
-    pix[0] = base + top * W + lef; w[0] = (1.f - yl) * (1.f - xl);
-    pix[1] = base + top * W + rig; w[1] = (1.f - yl) * xl;
-    pix[2] = base + bot * W + lef; w[2] = yl * (1.f - xl);
-    pix[3] = base + bot * W + rig; w[3] = yl * xl;
-    return true;
-}
-
-__global__ void roi_count_kernel(const RoiSortArgs q) {
-    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bin >= q.nbins) return;
-    int pix[4]; float w[4];
-    if (!roi_bin_corners(q, bin, pix, w)) return;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (w[k] != 0.f) atomicAdd(&q.cursor[pix[k]], 1);
-}
-
-// exclusive prefix sum of cursor[0..npix) in place, total -> cursor[npix]; one workgroup, 4 entries per thread per pass
-__global__ __launch_bounds__(1024) void roi_scan_kernel(int* cursor, int npix) {
-    __shared__ int wsum[16];
-    __shared__ int carry_s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
-    __syncthreads();
-    for (int base = 0; base < npix; base += 4096) {
-        const int i0 = base + tid * 4;
-        int v[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = i0 + k < npix ? cursor[i0 + k] : 0;
-        const int mine = v[0] + v[1] + v[2] + v[3];
-        int inc = mine;                                        // inclusive scan over the wave
+    const int local = pix - q.lvl_off[li];
+    const int b = local / (H * W);
+    const int yx = local - b * H * W;
+    const int y = yx / W, x = yx - y * W;
+    const int P = p.P;
+    const float fh = (float)(H - 1), fw = (float)(W - 1);
+    int* qr = q_row[wv];
+    float* qw = q_w[wv];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r0 = part * 64; r0 < p.R; r0 += 64 * ROI_GATHER_SPLIT) {
+        // ---- lanes test 64 ROIs: level, then which sample rows / columns have (y, x) as floor or ceil
+        const int r = r0 + lane;
+        unsigned my = 0u, mx = 0u;
+        float y0 = 0.f, hs = 0.f, x0 = 0.f, ws = 0.f;
+        if (r < p.R) {
+            const float* bx = p.boxes + ((int64_t)b * p.R + r) * 4;
+            const float y1 = bx[0], x1 = bx[1], y2 = bx[2], x2 = bx[3];
+            if (roi_level(y1, x1, y2, x2, p.image_area) - 2 == li) {
+                if (P > 1) {
+                    hs = (y2 - y1) * fh / (float)(P - 1);
+                    ws = (x2 - x1) * fw / (float)(P - 1);
+                    y0 = y1 * fh;
+                    x0 = x1 * fw;
+                } else {
+                    y0 = 0.5f * (y1 + y2) * fh;
+                    x0 = 0.5f * (x1 + x2) * fw;
+                }
+                for (int k = 0; k < P; ++k) {
+                    const float in_y = P > 1 ? y0 + (float)k * hs : y0;
+                    const float in_x = P > 1 ? x0 + (float)k * ws : x0;
+                    if (!(in_y < 0.f || in_y > fh) && ((int)floorf(in_y) == y || (int)ceilf(in_y) == y)) my |= 1u << k;
+                    if (!(in_x < 0.f || in_x > fw) && ((int)floorf(in_x) == x || (int)ceilf(in_x) == x)) mx |= 1u << k;
+                }
+            }
+        }
+        const int nx = __popc(mx);
+        const int cnt = __popc(my) * nx;
+        if (__ballot(cnt != 0) == 0ull) continue;
+        int inc = cnt;                                            // inclusive prefix over the wave
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             const int o = __shfl_up(inc, d, 64);
             if (lane >= d) inc += o;
         }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        int woff = 0;
-        for (int k = 0; k < wave; ++k) woff += wsum[k];
-        int run = carry_s + woff + inc - mine;
+        const int total = __builtin_amdgcn_readlane(inc, 63);
+        const int first = inc - cnt;                              // this lane's entries: [first, first + cnt) in (py, px) order
+        const int row0 = (((int)b * p.R + r) * P) * P;
+        for (int base = 0; base < total; base += ROI_GATHER_CAP) {
+            // ---- stage this round's (row, weight) entries in LDS (lane-parallel), fixed (ROI, py, px) order
+            if (cnt != 0 && first < base + ROI_GATHER_CAP && first + cnt > base) {
+                int e = first;
+                for (unsigned ym = my; ym; ym &= ym - 1) {
+                    if (e + nx <= base || e >= base + ROI_GATHER_CAP) { e += nx; continue; }
+                    const int py = __ffs((int)ym) - 1;
+                    const float in_y = P > 1 ? y0 + (float)py * hs : y0;
+                    const int top = (int)floorf(in_y);
+                    const float yl = in_y - (float)top;
+                    const float wy = top == y ? 1.f - yl : yl;   // floor row, else the ceil row
+                    for (unsigned xm = mx; xm; xm &= xm - 1, ++e) {
+                        if (e < base || e >= base + ROI_GATHER_CAP) continue;
+                        const int px = __ffs((int)xm) - 1;
+                        const float in_x = P > 1 ? x0 + (float)px * ws : x0;
+                        const int lef = (int)floorf(in_x);
+                        const float xl = in_x - (float)lef;
+                        const float wx = lef == x ? 1.f - xl : xl;
+                        qr[e - base] = row0 + py * P + px;
+                        qw[e - base] = wy * wx;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- eight rows in flight per batch
+            const int n = total - base < ROI_GATHER_CAP ? total - base : ROI_GATHER_CAP;
+            for (int i = 0; i < n; i += 8) {
+                f32x4 g[8]; float w[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (i0 + k < npix) cursor[i0 + k] = run;
-            run += v[k];
-        }
-        __syncthreads();
-        if (tid == 1023) carry_s = run;
-        __syncthreads();
-    }
-    if (tid == 0) cursor[npix] = carry_s;
-}
-
-__global__ void roi_scatter_kernel(const RoiSortArgs q) {
-    const int bin = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bin >= q.nbins) return;
-    int pix[4]; float w[4];
-    if (!roi_bin_corners(q, bin, pix, w)) return;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (w[k] != 0.f) {
-            const int pos = atomicAdd(&q.cursor[pix[k]], 1);
-            q.rec_pix[pos] = pix[k]; q.rec_bin[pos] = bin; q.rec_w[pos] = w[k];
-        }
-}
-
-// C == 256: lane owns channels 4*lane .. 4*lane+3
-__global__ __launch_bounds__(256) void roi_gather_kernel(const RoiSortArgs q) {
-    const int lane = threadIdx.x & 63;
-    const int chunk = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int total = q.cursor[q.npix];
-    const int r0 = chunk * 32;
-    if (r0 >= total) return;
-    const int n = total - r0 < 32 ? total - r0 : 32;
-    int my_pix = -1, my_bin = 0; float my_w = 0.f;
-    if (lane < n) { my_pix = q.rec_pix[r0 + lane]; my_bin = q.rec_bin[r0 + lane]; my_w = q.rec_w[r0 + lane]; }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    int cur = -1;
-    auto flush = [&]() {
-        if (cur < 0) return;
-        int li = 0;
-        while (li < 3 && cur >= q.lvl_off[li + 1]) ++li;
-        float* dst = q.r.dfm[li] + (int64_t)(cur - q.lvl_off[li]) * 256 + lane * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            if (acc[e] != 0.f) atomicAdd(dst + e, acc[e]);
-    };
-    for (int i = 0; i < n; i += 4) {
-        f32x4 v[4]; int pix[4]; float w[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = i + u < n ? i + u : n - 1;          // uniform
-            const int bin = __builtin_amdgcn_readlane(my_bin, j);
-            pix[u] = __builtin_amdgcn_readlane(my_pix, j);
-            w[u] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_w), j));
-            v[u] = *(const f32x4*)(q.r.dout + (int64_t)bin * 256 + lane * 4);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (i + u < n) {
-                if (pix[u] != cur) {
-                    flush();
-                    acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    cur = pix[u];
+                for (int u = 0; u < 8; ++u) {
+                    const int j = i + u < n ? i + u : n - 1;
+                    w[u] = i + u < n ? qw[j] : 0.f;
+                    g[u] = *(const f32x4*)(p.dout + (int64_t)qr[j] * 256 + lane * 4);
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] += w[u] * v[u][e];
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += w[u] * g[u][e];
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    flush();
+    float* dst = p.dfm[li] + (int64_t)local * 256 + lane * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (acc[e] != 0.f) atomicAdd(dst + e, acc[e]);
 }
 
-static bool roi_sorted_plan(const mrcnn_roialign_desc* d, long long& npix, long long& nbins, int lvl_off[5]) {
-    if (!d || d->B <= 0 || d->R <= 0 || d->P <= 0 || d->C != 256) return false;
-    npix = 0;
-    for (int i = 0; i < 4; ++i) {
-        if (d->H[i] <= 0 || d->W[i] <= 0) return false;
-        lvl_off[i] = (int)npix;
-        npix += (long long)d->B * d->H[i] * d->W[i];
-    }
-    nbins = (long long)d->B * d->R * d->P * d->P;
-    if (npix >= (1ll << 30) || nbins * 4 >= (1ll << 30) || nbins * 256 >= (1ll << 40)) return false;
-    lvl_off[4] = (int)npix;
-    return true;
-}
-
-extern "C" size_t mrcnn_roialign_bwd_sorted_workspace(const mrcnn_roialign_desc* d) {
-    long long npix, nbins; int off[5];
-    if (!roi_sorted_plan(d, npix, nbins, off)) return 0;
-    return (size_t)(((npix + 1) * 4 + 255) & ~255ll) + (size_t)nbins * 4 * 12;
-}
-
-extern "C" int mrcnn_roialign_bwd_sorted(const mrcnn_roialign_desc* d, const float* boxes, const float* dout, float* dfm2,
-                                         float* dfm3, float* dfm4, float* dfm5, void* workspace, size_t workspace_bytes,
-                                         void* stream) {
-    RoiSortArgs q = {};
+extern "C" int mrcnn_roialign_bwd_gather(const mrcnn_roialign_desc* d, const float* boxes, const float* dout, float* dfm2,
+                                         float* dfm3, float* dfm4, float* dfm5, void* stream) {
+    RoiGatherArgs q = {};
     int rc = fill_roi_args(d, q.r);
     if (rc) return rc;
     if (!boxes || !dout || !dfm2 || !dfm3 || !dfm4 || !dfm5) return MRCNN_ERR_ARG;
-    long long npix, nbins;
-    if (!roi_sorted_plan(d, npix, nbins, q.lvl_off)) return MRCNN_ERR_UNSUPPORTED;
-    const size_t need = mrcnn_roialign_bwd_sorted_workspace(d);
-    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15) ||
-        (reinterpret_cast<uintptr_t>(dout) & 15))
-        return MRCNN_ERR_ARG;
+    if (d->C != 256 || d->P > 32 || (reinterpret_cast<uintptr_t>(dout) & 15)) return MRCNN_ERR_UNSUPPORTED;
+    long long npix = 0;
+    for (int i = 0; i < 4; ++i) {
+        q.lvl_off[i] = (int)npix;
+        npix += (long long)d->B * d->H[i] * d->W[i];
+    }
+    if (npix >= (1ll << 30) || (long long)d->B * d->R * d->P * d->P >= (1ll << 30)) return MRCNN_ERR_UNSUPPORTED;
+    q.lvl_off[4] = (int)npix;
     q.r.boxes = boxes; q.r.dout = dout; q.r.dfm[0] = dfm2; q.r.dfm[1] = dfm3; q.r.dfm[2] = dfm4; q.r.dfm[3] = dfm5;
-    q.npix = (int)npix; q.nbins = (int)nbins;
-    char* ws = (char*)workspace;
-    const size_t cur_bytes = (size_t)(((npix + 1) * 4 + 255) & ~255ll);
-    q.cursor = (int*)ws;
-    q.rec_pix = (int*)(ws + cur_bytes);
-    q.rec_bin = q.rec_pix + nbins * 4;
-    q.rec_w = (float*)(q.rec_bin + nbins * 4);
-    hipStream_t s = (hipStream_t)stream;
-    rc = mrcnn_fill_zero(q.cursor, cur_bytes, stream);
-    if (rc) return rc;
-    const unsigned gb = (unsigned)cdiv64(nbins, 256);
-    hipLaunchKernelGGL(roi_count_kernel, dim3(gb), dim3(256), 0, s, q);
-    hipLaunchKernelGGL(roi_scan_kernel, dim3(1), dim3(1024), 0, s, q.cursor, q.npix);
-    hipLaunchKernelGGL(roi_scatter_kernel, dim3(gb), dim3(256), 0, s, q);
-    const long long chunks = cdiv64(nbins * 4, 32);
-    hipLaunchKernelGGL(roi_gather_kernel, dim3((unsigned)cdiv64(chunks, 4)), dim3(256), 0, s, q);
+    hipLaunchKernelGGL(roialign_bwd_gather_kernel, dim3((unsigned)cdiv64(npix * ROI_GATHER_SPLIT, 4)), dim3(256), 0, (hipStream_t)stream, q);
     return mrcnn_launch_status();
 }

@@ -359,18 +359,15 @@ def roialign(boxes, fms, pool, image_area, want_levels=False):
 
 def roialign_bwd(boxes, dout, dfms, pool, image_area, dense=False):
     """Scatter-add dout [B,R,pool,pool,C] into the (already initialised) gradient maps dfms.  dense=True: every ROI
-    carries gradient -- use the gather form (records bucketed by pixel) when the shape allows."""
+    carries gradient -- use the gather form (one wave per pyramid pixel) when the shape allows."""
     _need_cuda(boxes, dout, *dfms)
     d = _roi_desc(boxes, dfms, pool, image_area)
     if dense:
-        nbytes = _hip.lib().mrcnn_roialign_bwd_sorted_workspace(C.byref(d))
-        if nbytes:
-            ws = workspace(nbytes, boxes.device, "roialign_sorted")
-            rc = _hip.lib().mrcnn_roialign_bwd_sorted(C.byref(d), ptr(boxes), ptr(dout), ptr(dfms[0]), ptr(dfms[1]),
-                                                      ptr(dfms[2]), ptr(dfms[3]), ptr(ws), ws.numel(), current_stream())
-            if rc != ERR_UNSUPPORTED:
-                check(rc, "mrcnn_roialign_bwd_sorted")
-                return
+        rc = _hip.lib().mrcnn_roialign_bwd_gather(C.byref(d), ptr(boxes), ptr(dout), ptr(dfms[0]), ptr(dfms[1]), ptr(dfms[2]),
+                                                  ptr(dfms[3]), current_stream())
+        if rc != ERR_UNSUPPORTED:
+            check(rc, "mrcnn_roialign_bwd_gather")
+            return
     check(_hip.lib().mrcnn_roialign_bwd(C.byref(d), ptr(boxes), ptr(dout), ptr(dfms[0]), ptr(dfms[1]), ptr(dfms[2]),
                                         ptr(dfms[3]), current_stream()), "mrcnn_roialign_bwd")
 

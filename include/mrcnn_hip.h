@@ -185,14 +185,13 @@ int mrcnn_roialign_bwd(const mrcnn_roialign_desc* d, const float* boxes, const f
                        float* dfm2, float* dfm3, float* dfm4, float* dfm5, void* stream);
 
 /* Same adjoint in gather form for the case where every ROI carries gradient (the class head in training: TF autodiff
- * of tf.image.crop_and_resize at mrcnn/model.py:505): the (bin, corner) records are bucketed by destination pixel
- * (counting sort in `workspace`), summed per pixel in registers, and one row of atomics per pixel run is issued instead
- * of one per record.  C must be 256 (else MRCNN_ERR_UNSUPPORTED, nothing launched); same values as
- * mrcnn_roialign_bwd up to fp32 summation order.                                                                   */
-size_t mrcnn_roialign_bwd_sorted_workspace(const mrcnn_roialign_desc* d);
-int mrcnn_roialign_bwd_sorted(const mrcnn_roialign_desc* d, const float* boxes, const float* dout, float* dfm2,
-                              float* dfm3, float* dfm4, float* dfm5, void* workspace, size_t workspace_bytes,
-                              void* stream);
+ * of tf.image.crop_and_resize at mrcnn/model.py:505).  Bilinear sampling is separable, so each destination pixel reads
+ * off its contributions directly: one wave per pyramid pixel walks the ROIs of its image and level, finds the sample
+ * rows / columns whose floor or ceil is that pixel, and accumulates  wy*wx*dout[roi,py,px,:]  in registers -- one row of
+ * atomics per pixel instead of four per bin, no sorting, fixed summation order.  C must be 256 and P <= 32 (else
+ * MRCNN_ERR_UNSUPPORTED, nothing launched); same values as mrcnn_roialign_bwd up to fp32 summation order.          */
+int mrcnn_roialign_bwd_gather(const mrcnn_roialign_desc* d, const float* boxes, const float* dout, float* dfm2,
+                              float* dfm3, float* dfm4, float* dfm5, void* stream);
 
 /* ProposalLayer (mrcnn/model.py:329-406): per image, scores = rpn_probs[:, 1]; top-k(min(pre_nms, A),
  * sorted, ties -> lower index); decode with deltas*std; clip to [0,1]; greedy NMS (IoU > thr

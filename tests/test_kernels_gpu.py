@@ -320,7 +320,7 @@ def test_roialign_fwd_bwd(dev, pool):
     torch.cuda.synchronize()
     for a, f in zip(dfm, fms):
         torch.testing.assert_close(a.cpu(), f.grad, rtol=1e-4, atol=1e-4)
-    # gather form (records bucketed by destination pixel): same adjoint, accumulating onto what the maps already hold
+    # gather form (one wave per destination pixel): same adjoint, accumulating onto what the maps already hold
     dfm2 = [torch.full_like(f, 0.25) for f in fd]
     ops.roialign_bwd(torch.tensor(rois, device=dev), dout.to(dev), dfm2, pool, 1024.0 * 1024.0, dense=True)
     torch.cuda.synchronize()
@@ -328,9 +328,9 @@ def test_roialign_fwd_bwd(dev, pool):
         torch.testing.assert_close(a.cpu() - 0.25, f.grad, rtol=1e-4, atol=1e-4)
 
 
-def test_roialign_bwd_sorted_heavy_overlap(dev):
+def test_roialign_bwd_gather_heavy_overlap(dev):
     """512 ROIs per image clustered on a few objects (the class head's training shape at 256^2 inputs: hundreds of
-    records per pixel, a list longer than one 32-record chunk for most pixels, zero-padded rows all on pixel (0,0))."""
+    contributions per pixel, zero-padded rows all on pixel (0,0))."""
     ops = _ops()
     rng = np.random.default_rng(99)
     B, R, C, pool = 2, 512, 256, 7
