@@ -191,7 +191,7 @@ class MaskRCNNEngine(object):
         self.fused_dgrad_epilogue = True  # data-gradient convs of the mask head apply the lower layer's epilogue backward
         self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self.aux_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
-        self.sorted_roialign_bwd = os.environ.get("MRCNN_SORTED_ROIALIGN_BWD", "1") != "0"   # class-head ROIAlign adjoint in gather form
+        self.gather_roialign_bwd = os.environ.get("MRCNN_GATHER_ROIALIGN_BWD", "1") != "0"   # class-head ROIAlign adjoint in gather form
         self.multi_launch = os.environ.get("MRCNN_MULTI_LAUNCH", "1") != "0"     # independent small convolutions share launches
 
     def op(self, name):
@@ -708,6 +708,8 @@ class MaskRCNNEngine(object):
                                      ((kh - 1) // 2, (kw - 1) // 2), ACT_NONE)
             d = ops.cast_from_h16(d16, 1.0 / S)
         B, R = rois.shape[0], rois.shape[1]
+        # scatter form here: the gather form measured 2 ms slower on the positive rows (14x14 samples of ~150 overlapping
+        # positives: >1000 rows on the hottest pixels) and the dense head relies on the skipping of exactly-zero rows
         ops.roialign_bwd(rois, d.view(B, R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1), dP, cfg.MASK_POOL_SIZE, area)
 
     def _dgrad_ep(self, dz, wt, padding, below, below_ctx):
@@ -744,7 +746,7 @@ class MaskRCNNEngine(object):
         d_pool = op1.dgrad(dz, c1)
         B, R = rois.shape[0], rois.shape[1]
         ops.roialign_bwd(rois, d_pool.view(B, R, cfg.POOL_SIZE, cfg.POOL_SIZE, -1), dP, cfg.POOL_SIZE, area,
-                         dense=self.sorted_roialign_bwd)
+                         dense=self.gather_roialign_bwd)
 
     def _rpn_bwd(self, d_logits, d_bbox, rpn_tape, dP):
         na = len(self.cfg.RPN_ANCHOR_RATIOS)
