@@ -101,12 +101,44 @@ def conv2d_into(x, w, bias, out_view_ptr, n_stride, h_stride, w_stride, stride=1
                                       current_stream()), "mrcnn_conv2d_fwd(into)")
 
 
+def _conv2d_problem(pr):
+    """One problem of conv2d_multi as an ordinary launch."""
+    if "out_ptr" in pr:
+        x, w = pr["x"], pr["w"]
+        _need_cuda(x, w, pr.get("bias"))
+        d = conv_desc(tuple(x.shape), tuple(w.shape), pr.get("stride", 1), pr.get("padding", "same"), pr.get("act", ACT_NONE))
+        d.out_n_stride, d.out_h_stride, d.out_w_stride = pr["out_strides"]
+        nbytes = _hip.lib().mrcnn_conv2d_fwd_workspace(C.byref(d))
+        ws = workspace(nbytes, x.device, "conv_splitk") if nbytes else None
+        check(_hip.lib().mrcnn_conv2d_fwd_ws(C.byref(d), ptr(x), ptr(w), ptr(pr.get("bias")), ptr(pr.get("scale")),
+                                             ptr(pr.get("shift")), None, pr["out_ptr"], None, ptr(ws),
+                                             ws.numel() if ws is not None else 0, current_stream()), "mrcnn_conv2d_fwd(into)")
+        return None
+    return conv2d(pr["x"], pr["w"], pr.get("bias"), pr.get("scale"), pr.get("shift"), pr.get("res"), pr.get("stride", 1),
+                  pr.get("padding", "same"), pr.get("act", ACT_NONE), pr.get("res_mode", RES_NONE), out=pr.get("out"),
+                  z_out=pr.get("z_out"))
+
+
 def conv2d_multi(problems):
     """Up to 5 independent convolutions in one launch (mrcnn_conv2d_fwd_multi).  Each problem is a dict:
     x, w, and optionally bias, scale, shift, res, res_mode, stride, padding, act, z_out, and either `out` (a dense
     tensor, allocated when missing) or `out_ptr` + `out_strides` (n, h, w strides in floats, as conv2d_into).
     Returns the list of `out` tensors (None where out_ptr was given), or None when the problems do not share a
     launch shape (the caller then issues them one by one)."""
+    # problems large enough for the 128x128 LDS-DMA kernel (>= 640 tiles) fill the chip on their own and run faster
+    # there than on the 64-row tiles of the shared launch: they go out individually, the small rest travels together
+    def big(pr):
+        x, w = pr["x"], pr["w"]
+        d = conv_desc(tuple(x.shape), tuple(w.shape), pr.get("stride", 1), pr.get("padding", "same"))
+        return d.Cout % 128 == 0 and d.Cin % 32 == 0 and ((d.N * d.OH * d.OW + 127) // 128) * (d.Cout // 128) >= 640
+    flags = [big(pr) for pr in problems]
+    if any(flags):
+        small = [pr for pr, f in zip(problems, flags) if not f]
+        so = conv2d_multi(small) if len(small) > 1 else None
+        if so is None:
+            so = [_conv2d_problem(pr) for pr in small]
+        small_outs = iter(so)
+        return [_conv2d_problem(pr) if f else next(small_outs) for pr, f in zip(problems, flags)]
     n = len(problems)
     arr = (_hip.ConvProblem * n)()
     outs = []
