@@ -27,6 +27,11 @@ class ConvProblem(C.Structure):
     _fields_ = [("d", ConvDesc)] + [(n, C.c_void_p) for n in ("x", "w", "bias", "scale", "shift", "res", "out", "z_out")]
 
 
+class WgradProblem(C.Structure):
+    """mrcnn_wgrad_problem (include/mrcnn_hip.h)."""
+    _fields_ = [("d", ConvDesc), ("x", C.c_void_p), ("dy", C.c_void_p), ("dw", C.c_void_p), ("accumulate", C.c_int32)]
+
+
 class RoiAlignDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("R", C.c_int32), ("P", C.c_int32), ("C", C.c_int32),
                 ("H", C.c_int32 * 4), ("W", C.c_int32 * 4), ("image_area", C.c_float)]
@@ -73,6 +78,8 @@ _SIGNATURES = {
     "mrcnn_conv2d_fwd_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "mrcnn_conv2d_fwd_multi_workspace": (C.c_size_t, [C.POINTER(ConvProblem), C.c_int]),
     "mrcnn_conv2d_fwd_multi": (C.c_int, [C.POINTER(ConvProblem), C.c_int, _P, C.c_size_t, _P]),
+    "mrcnn_conv2d_wgrad_multi_workspace": (C.c_size_t, [C.POINTER(WgradProblem), C.c_int]),
+    "mrcnn_conv2d_wgrad_multi": (C.c_int, [C.POINTER(WgradProblem), C.c_int, _P, C.c_size_t, _P]),
     "mrcnn_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, C.c_size_t, C.c_int, _P]),
     "mrcnn_conv2d_wgrad_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "mrcnn_weight_flip_transpose": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

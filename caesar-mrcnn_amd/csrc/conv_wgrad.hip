@@ -302,7 +302,8 @@ typedef __attribute__((address_space(3))) void* wgrad_lds_ptr;
 #define WGRAD_OOB_OFFSET 0x80000000u
 
 template <int BP, bool TABLE>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_blds_kernel(const WgradArgs p, const unsigned x_shift, const unsigned x_records) {
+__device__ __forceinline__ void conv_wgrad_blds_body(const WgradArgs& p, const unsigned x_shift, const unsigned x_records,
+                                                     const int block) {
     constexpr int BI = 128, BN = 128, TM = 2, TN = 2;
     constexpr int XF = BP * BI, YF = BP * BN;
     constexpr int NP = XF / 256;                              // 1 KiB pieces per tile (two pixel rows each)
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_blds_kernel(const WgradArgs
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int ntiles = p.Cout / BN, itiles = p.Ktot / BI;
-    int bid = blockIdx.x;
+    int bid = block;
     const int ntile = bid % ntiles; bid /= ntiles;
     const int itile = bid % itiles;
     const int split = bid / itiles;
@@ -441,6 +442,44 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_blds_kernel(const WgradArgs
     store_tile(acc[1][1], ib + 32, nb + 32);
 }
 
+template <int BP, bool TABLE>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_blds_kernel(const WgradArgs p, const unsigned x_shift, const unsigned x_records) {
+    conv_wgrad_blds_body<BP, TABLE>(p, x_shift, x_records, (int)blockIdx.x);
+}
+
+// Up to WGRAD_MULTI_MAX weight gradients in one launch (mrcnn_conv2d_wgrad_multi): the three convolutions of a
+// bottleneck block.  Workgroups first[g] .. first[g+1]-1 belong to problem g; the slab reductions share a launch too.
+#define WGRAD_MULTI_MAX 4
+struct WgradMultiArgs {
+    WgradArgs a[WGRAD_MULTI_MAX];
+    unsigned x_shift[WGRAD_MULTI_MAX], x_records[WGRAD_MULTI_MAX];
+    int first[WGRAD_MULTI_MAX + 1];
+    float* dw[WGRAD_MULTI_MAX];
+    int rfirst[WGRAD_MULTI_MAX + 1];      // reduction launch: blocks of 256 float4
+    int n;
+};
+
+template <int BP>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_blds_multi_kernel(const WgradMultiArgs mp) {
+    int g = 0;
+    while (g + 1 < mp.n && (int)blockIdx.x >= mp.first[g + 1]) ++g;
+    conv_wgrad_blds_body<BP, false>(mp.a[g], mp.x_shift[g], mp.x_records[g], (int)blockIdx.x - mp.first[g]);
+}
+
+__global__ void wgrad_reduce_multi_kernel(const WgradMultiArgs mp) {
+    int g = 0;
+    while (g + 1 < mp.n && (int)blockIdx.x >= mp.rfirst[g + 1]) ++g;
+    const WgradArgs& p = mp.a[g];
+    if (p.splits <= 1) return;
+    const long long n4 = (long long)p.Ktot * p.Cout / 4;
+    const long long i = (long long)(blockIdx.x - mp.rfirst[g]) * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (p.acc) s = *(const f32x4*)(mp.dw[g] + 4 * i);
+    *(f32x4*)(mp.dw[g] + 4 * i) = mrcnn_slab_sum<f32x4>(s, p.out, 4 * n4, 4 * i, p.splits);
+
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, float* dw, long long n, int splits, int acc) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -469,7 +508,8 @@ static WgradPlan plan_wgrad(const mrcnn_conv_desc* d) {
     pl.bn = d->Cout >= 128 ? 128 : (d->Cout >= 64 ? 64 : 32);
     const long long tiles = (long long)((Ktot + pl.bi - 1) / pl.bi) * ((d->Cout + pl.bn - 1) / pl.bn);
     long long splits = 1024 / (tiles > 0 ? tiles : 1);
-    const long long max_splits = (M + 255) / 256;       // at least 256 pixels (8 steps) per split
+    static const long long min_px = getenv("MRCNN_WGRAD_MIN_PIXELS") ? atoll(getenv("MRCNN_WGRAD_MIN_PIXELS")) : 128;
+    const long long max_splits = (M + min_px - 1) / min_px;       // at least min_px pixels per split
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;
@@ -564,6 +604,94 @@ extern "C" int mrcnn_conv2d_wgrad(const mrcnn_conv_desc* d, const float* x, cons
             hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, workspace, dw, n,
                                pl.splits, beta_acc);
     }
+    return mrcnn_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// mrcnn_conv2d_wgrad_multi: the weight gradients of up to 4 layers in one launch (+ one for their slab reductions).
+// On the small feature maps of the backbone a weight gradient is 16-36 output tiles with a few hundred pixels to
+// contract: ~30 us of mostly latency per launch plus its reduction, three per bottleneck block, and together they
+// had become the longest chain of the backward pass (knock-out run: 2 ms of the step).  LDS-DMA kernel only.
+struct WgradMultiPlan { int splits[WGRAD_MULTI_MAX], chunk[WGRAD_MULTI_MAX]; size_t slab_off[WGRAD_MULTI_MAX], bytes; };
+
+static bool plan_wgrad_multi(const mrcnn_wgrad_problem* pr, int n, WgradMultiPlan& pl) {
+    if (!pr || n < 1 || n > WGRAD_MULTI_MAX) return false;
+    long long tiles = 0;
+    for (int g = 0; g < n; ++g) {
+        const mrcnn_conv_desc& d = pr[g].d;
+        if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.Cin <= 0 || d.Cout <= 0 || d.KH <= 0 || d.KW <= 0 || d.stride <= 0 ||
+            d.OH <= 0 || d.OW <= 0)
+            return false;
+        const long long M = (long long)d.N * d.OH * d.OW;
+        const long long Ktot = (long long)d.KH * d.KW * d.Cin;
+        if (d.Cin % 128 || d.Cout % 128 || d.KH * d.KW > 64 || M >= WGRAD_TABLE_MIN_PIXELS) return false;
+        const long long xbytes = (long long)d.N * d.H * d.W * d.Cin * 4;
+        const long long shift = ((long long)d.pad_t * d.W + d.pad_l) * d.Cin * 4;
+        if (xbytes + shift + 16LL * d.H * d.W * d.Cin * 4 >= 0x7FFFFFF0LL || M * d.Cout * 4 >= 0x7FFFFFF0LL) return false;
+        tiles += (Ktot / 128) * (d.Cout / 128);
+    }
+    const long long want = 1024 / (tiles > 0 ? tiles : 1);
+    pl.bytes = 0;
+    for (int g = 0; g < n; ++g) {
+        const mrcnn_conv_desc& d = pr[g].d;
+        const long long M = (long long)d.N * d.OH * d.OW;
+        long long splits = want;
+        const long long max_splits = (M + 127) / 128;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        if (splits > 64) splits = 64;
+        const long long chunk = ((M + splits - 1) / splits + 31) / 32 * 32;
+        splits = (M + chunk - 1) / chunk;
+        pl.splits[g] = (int)splits; pl.chunk[g] = (int)chunk;
+        pl.slab_off[g] = pl.bytes;
+        if (splits > 1) pl.bytes += (((size_t)splits * d.KH * d.KW * d.Cin * d.Cout * sizeof(float)) + 255) & ~(size_t)255;
+    }
+    return true;
+}
+
+extern "C" size_t mrcnn_conv2d_wgrad_multi_workspace(const mrcnn_wgrad_problem* problems, int n) {
+    WgradMultiPlan pl;
+    if (!plan_wgrad_multi(problems, n, pl)) return 0;
+    return pl.bytes + 256;
+}
+
+extern "C" int mrcnn_conv2d_wgrad_multi(const mrcnn_wgrad_problem* problems, int n, float* workspace, size_t workspace_bytes,
+                                        void* stream) {
+    WgradMultiPlan pl;
+    if (!plan_wgrad_multi(problems, n, pl) || mrcnn_force_flat_glds()) return MRCNN_ERR_UNSUPPORTED;
+    if (pl.bytes && (!workspace || workspace_bytes < pl.bytes || (reinterpret_cast<uintptr_t>(workspace) & 15))) return MRCNN_ERR_WORKSPACE;
+    WgradMultiArgs mp;
+    mp.n = n;
+    long long blocks = 0, rblocks = 0;
+    for (int g = 0; g < n; ++g) {
+        const mrcnn_wgrad_problem& q = problems[g];
+        const mrcnn_conv_desc* d = &q.d;
+        if (!q.x || !q.dy || !q.dw) return MRCNN_ERR_ARG;
+        if ((reinterpret_cast<uintptr_t>(q.x) | reinterpret_cast<uintptr_t>(q.dy) | reinterpret_cast<uintptr_t>(q.dw)) & 15)
+            return MRCNN_ERR_UNSUPPORTED;
+        const long long M = (long long)d->N * d->OH * d->OW;
+        WgradArgs& a = mp.a[g];
+        a.x = q.x; a.dy = q.dy;
+        a.out = pl.splits[g] > 1 ? (float*)((char*)workspace + pl.slab_off[g]) : q.dw;
+        a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
+        a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.OH = d->OH; a.OW = d->OW;
+        a.M = (int)M; a.Ktot = d->KH * d->KW * d->Cin; a.fast = 1; a.splits = pl.splits[g]; a.chunk = pl.chunk[g];
+        a.acc = q.accumulate;
+        a.d_ohw = make_fastdiv((unsigned)(d->OH * d->OW)); a.d_ow = make_fastdiv((unsigned)d->OW);
+        a.table = nullptr;
+        const long long xbytes = (long long)d->N * d->H * d->W * d->Cin * 4;
+        const long long shift = ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
+        mp.x_shift[g] = (unsigned)shift; mp.x_records[g] = (unsigned)(xbytes + shift);
+        mp.dw[g] = q.dw;
+        mp.first[g] = (int)blocks;
+        blocks += (long long)(a.Ktot / 128) * (a.Cout / 128) * a.splits;
+        mp.rfirst[g] = (int)rblocks;
+        if (a.splits > 1) rblocks += cdiv64((long long)a.Ktot * a.Cout / 4, 256);
+    }
+    for (int g = n; g <= WGRAD_MULTI_MAX; ++g) { mp.first[g] = (int)blocks; mp.rfirst[g] = (int)rblocks; }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((conv_wgrad_blds_multi_kernel<WGRAD_BP>), dim3((unsigned)blocks), dim3(256), 0, s, mp);
+    if (rblocks > 0) hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, mp);
     return mrcnn_launch_status();
 }
 

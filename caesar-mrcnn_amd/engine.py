@@ -79,6 +79,10 @@ class ConvOp(object):
     def wgrad(self, dz, ctx, accumulate=False):
         self.model.wgrad_async(ctx[0], dz, self.wshape, self.stride, self.padding, self.dw, accumulate)
 
+    def wgrad_item(self, dz, ctx, accumulate=False):
+        """The arguments of this layer's weight gradient, for MaskRCNNEngine.wgrad_group."""
+        return (ctx[0], dz, self.wshape, self.stride, self.padding, self.dw, accumulate)
+
     def dgrad(self, dz, ctx, out=None, accumulate=False):
         """dx = adjoint of the convolution applied to dz.  `out` (shape of x) receives the result;
         accumulate=True adds to what `out` already holds (in place)."""
@@ -214,6 +218,27 @@ class MaskRCNNEngine(object):
             ops.conv2d_wgrad(x, dz, wshape, stride, padding, dw=dw, accumulate=accumulate)
         dz.record_stream(ws)
         x.record_stream(ws)
+
+    def wgrad_group(self, items):
+        """Weight gradients of several layers (ConvOp.wgrad_item) behind one event: one shared launch when they all
+        fit the LDS-DMA kernel (the three convolutions of a bottleneck block on the small feature maps), else one by one."""
+        ws = self.wgrad_stream
+
+        def run():
+            if not (self.multi_launch and 1 < len(items) <= 4 and ops.conv2d_wgrad_multi(items)):
+                for x, dz, wshape, stride, padding, dw, acc in items:
+                    ops.conv2d_wgrad(x, dz, wshape, stride, padding, dw=dw, accumulate=acc)
+        if ws is None:
+            run()
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(ws):
+            ws.wait_event(ev)
+            run()
+        for x, dz, *_ in items:
+            dz.record_stream(ws)
+            x.record_stream(ws)
 
     def wgrad_h16_async(self, x, dz, wshape, dw, multiplier):
         ws = self.wgrad_stream
@@ -860,22 +885,22 @@ class MaskRCNNEngine(object):
 
     def _block_bwd(self, blk, d_out, ctxs, acc_buf):
         ca, cb, cc, c1c = ctxs
-        dz, dy = blk.c2c.epilogue_bwd(d_out, cc, want_dy=True)
-        blk.c2c.wgrad(dz, cc)
+        dzc, dy = blk.c2c.epilogue_bwd(d_out, cc, want_dy=True)
         # 2c -> 2b -> 2a: each data-gradient convolution (or its split-K reduction) applies the epilogue backward of
         # the layer below (mrcnn_conv2d_dgrad_ep)
         if not self.wt_valid:
             ops.weight_flip_transpose(blk.c2c.w, blk.c2c.wt)
             ops.weight_flip_transpose(blk.c2b.w, blk.c2b.wt)
-        dz = self._dgrad_ep(dz, blk.c2c.wt, "valid", blk.c2b, cb)
-        blk.c2b.wgrad(dz, cb)
-        dza = self._dgrad_ep(dz, blk.c2b.wt, (1, 1), blk.c2a, ca)
-        blk.c2a.wgrad(dza, ca)
+        dzb = self._dgrad_ep(dzc, blk.c2c.wt, "valid", blk.c2b, cb)
+        dza = self._dgrad_ep(dzb, blk.c2b.wt, (1, 1), blk.c2a, ca)
+        # the block's weight gradients travel together (they trail the data gradients on their stream anyway)
+        items = [blk.c2c.wgrad_item(dzc, cc), blk.c2b.wgrad_item(dzb, cb), blk.c2a.wgrad_item(dza, ca)]
         if blk.c1 is None:
+            self.wgrad_group(items)
             # identity shortcut: dx = dy + dgrad_2a (in place on dy)
             return blk.c2a.dgrad(dza, ca, out=dy, accumulate=True)
         dz1, _ = blk.c1.epilogue_bwd(dy, c1c)
-        blk.c1.wgrad(dz1, c1c)
+        self.wgrad_group(items + [blk.c1.wgrad_item(dz1, c1c)])
         if acc_buf is not None:
             dx = blk.c1.dgrad(dz1, c1c, out=acc_buf, accumulate=True)
         else:

@@ -264,6 +264,26 @@ def conv2d_wgrad(x, dy, w_shape, stride=1, padding="same", dw=None, accumulate=F
     return dw
 
 
+def conv2d_wgrad_multi(items):
+    """The weight gradients of up to 4 layers in one launch (mrcnn_conv2d_wgrad_multi).  items: [(x, dy, w_shape, stride,
+    padding, dw, accumulate)].  Returns False (nothing launched) when a layer does not fit the shared kernel."""
+    n = len(items)
+    arr = (_hip.WgradProblem * n)()
+    for q, (x, dy, w_shape, stride, padding, dw, accumulate) in zip(arr, items):
+        _need_cuda(x, dy, dw)
+        q.d = conv_desc(tuple(x.shape), tuple(w_shape), stride, padding)
+        q.x, q.dy, q.dw, q.accumulate = ptr(x), ptr(dy), ptr(dw), 1 if accumulate else 0
+    nbytes = _hip.lib().mrcnn_conv2d_wgrad_multi_workspace(arr, n)
+    if nbytes == 0:
+        return False
+    ws = workspace(nbytes, items[0][0].device, "wgrad")
+    rc = _hip.lib().mrcnn_conv2d_wgrad_multi(arr, n, ptr(ws), ws.numel(), current_stream())
+    if rc == ERR_UNSUPPORTED:
+        return False
+    check(rc, "mrcnn_conv2d_wgrad_multi")
+    return True
+
+
 def flip_table(entries, device):
     """entries: [(offset_floats, KH, KW, Cin, Cout)] -> (device table, n_layers, total_tiles) for
     weight_flip_transpose_batched."""

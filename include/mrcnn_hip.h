@@ -99,6 +99,20 @@ size_t mrcnn_conv2d_fwd_multi_workspace(const mrcnn_conv_problem* problems, int 
 int mrcnn_conv2d_fwd_multi(const mrcnn_conv_problem* problems, int n, void* workspace, size_t workspace_bytes,
                            void* stream);
 
+/* The weight gradients of up to 4 layers in one launch (+ one for their slab reductions): TF autodiff of the three
+ * Conv2D layers of a bottleneck block (mrcnn/model.py:99-172) on the small feature maps, where each is a few dozen
+ * output tiles with a few hundred pixels to contract.  Every problem is an ordinary mrcnn_conv2d_wgrad (accumulate !=
+ * 0 adds to dw); all must fit the LDS-DMA kernel (Cin, Cout multiples of 128, fewer than 65 536 output pixels,
+ * 16-byte aligned buffers), else MRCNN_ERR_UNSUPPORTED (workspace query: 0) and nothing is launched.             */
+typedef struct mrcnn_wgrad_problem {
+    mrcnn_conv_desc d;
+    const float* x; const float* dy; float* dw;
+    int32_t accumulate;
+} mrcnn_wgrad_problem;
+size_t mrcnn_conv2d_wgrad_multi_workspace(const mrcnn_wgrad_problem* problems, int n);
+int mrcnn_conv2d_wgrad_multi(const mrcnn_wgrad_problem* problems, int n, float* workspace, size_t workspace_bytes,
+                             void* stream);
+
 /* Data-gradient convolution fused with the epilogue backward of the layer below (TF autodiff through Conv2D, then
  * through the lower layer's Activation / BatchNorm / bias): y = conv(dz, w_t) (+ res) is d(loss)/d(out_below); stored is
  *   dz_below = y * act'(out_below) * scale_below,   and   dbeta += sum y*act',  dgamma += sum y*act'*(z-mean)*rstd,

@@ -475,10 +475,12 @@ def test_graph_replay_with_multiworkgroup_topk_512(dev):
 
 
 def test_overfit_one_batch_then_detect_it(dev):
-    """End to end: 120 full steps (forward, backward, clipnorm, SGD-momentum) on one synthetic batch drive the total
-    loss down by > 10x, and the inference graph with the trained weights then finds the training objects (a detection
-    with box IoU > 0.5 for at least a third of the ground-truth boxes; the float atomics make the trajectory -- and which
-    of the objects are found -- vary from run to run, typically 4-5 of 6, so the bar is set well below that)."""
+    """End to end: 180 full steps (forward, backward, clipnorm, SGD-momentum; 120 at lr 0.002, 60 at 0.0004) on one
+    synthetic batch drive the total loss down by > 10x, and the inference graph with the trained weights then finds the
+    training objects (a detection with box IoU > 0.5 for at least a third of the ground-truth boxes).  The float atomics
+    make the trajectory vary from run to run; at constant lr 0.002 the loss keeps jittering around 0.5 and the objects
+    found ranged from 0 to 5 of 6 over repeated runs, with the final low-rate phase it settles near 0.35 and 4-5 of 6 are
+    found every time (10 of 10 runs), so the bar sits well below that."""
     import bench
     from caesar_mrcnn_amd.config import run_py_config
     from caesar_mrcnn_amd.model import MaskRCNN
@@ -489,9 +491,9 @@ def test_overfit_one_batch_then_detect_it(dev):
     inp = model._to_device(batch, rand_keys=keys)
     eng = model.engine
     first = last = None
-    for s in range(120):
+    for s in range(180):
         losses = eng.forward_backward(*inp)
-        eng.apply_gradients(0.002, cfg.LEARNING_MOMENTUM, 1)
+        eng.apply_gradients(0.002 if s < 120 else 0.0004, cfg.LEARNING_MOMENTUM, 1)
         if s == 0:
             first = float(losses.sum())
     last = float(losses.sum())

@@ -224,6 +224,36 @@ def test_conv_wgrad_and_dgrad(dev, case):
         torch.testing.assert_close(dx.cpu(), x.grad, **F32)
 
 
+def test_conv_wgrad_multi_launch(dev):
+    """mrcnn_conv2d_wgrad_multi: the weight gradients of a bottleneck block (1x1, 3x3, 1x1, and the stride-2 1x1 shortcut
+    of a stage's first block) in one launch, plain and accumulating; a layer that does not fit (Cout = 64) is refused."""
+    ops = _ops()
+    rng = np.random.default_rng(4242)
+    N, H, W = 3, 9, 7                                   # M = 189: pixel tail inside a 16-row piece
+    layers = [(256, 128, 1, 1, "valid", H, W), (128, 128, 3, 1, "same", H, W), (128, 512, 1, 1, "valid", H, W),
+              (256, 512, 1, 2, "valid", 2 * H, 2 * W)]
+    items, refs = [], []
+    for cin, cout, k, stride, padding, h, w_ in layers:
+        x = torch.tensor(_rand(rng, N, h, w_, cin))
+        w = torch.tensor(_rand(rng, k, k, cin, cout, scale=1.0 / np.sqrt(k * k * cin)), requires_grad=True)
+        y = orc.conv2d_nhwc(x, w, None, stride, padding)
+        dy = torch.tensor(_rand(rng, *y.shape))
+        y.backward(dy)
+        refs.append(w.grad)
+        items.append((x.to(dev), dy.to(dev), tuple(w.shape), stride, padding, torch.full(tuple(w.shape), 0.5, device=dev), False))
+    assert ops.conv2d_wgrad_multi(items)
+    torch.cuda.synchronize()
+    for it, r in zip(items, refs):
+        torch.testing.assert_close(it[5].cpu(), r, rtol=5e-4, atol=5e-4 * float(r.abs().max()))
+    acc = [it[:6] + (True,) for it in items]
+    assert ops.conv2d_wgrad_multi(acc)
+    torch.cuda.synchronize()
+    for it, r in zip(items, refs):
+        torch.testing.assert_close(it[5].cpu(), 2 * r, rtol=5e-4, atol=1e-3 * float(r.abs().max()))
+    x = torch.tensor(_rand(rng, N, H, W, 256), device=dev); dy = torch.tensor(_rand(rng, N, H, W, 64), device=dev)
+    assert not ops.conv2d_wgrad_multi([items[0], (x, dy, (1, 1, 256, 64), 1, "valid", torch.zeros(1, 1, 256, 64, device=dev), False)])
+
+
 @pytest.mark.parametrize("M,C,act,bn", [(500, 256, 1, True), (1000, 6, 0, False), (3000, 4, 2, False),
                                          (77, 2048, 1, True), (4096, 64, 1, True)])
 def test_epilogue_bwd(dev, M, C, act, bn):
