@@ -846,8 +846,8 @@ class MaskRCNNEngine(object):
         for name, g in (("fpn_p5", dP5), ("fpn_p4", dP4), ("fpn_p3", dP3), ("fpn_p2", dP2)):
             op, c = self.op(name), tape[name]
             dz, _ = op.epilogue_bwd(g, c)
-            op.wgrad(dz, c)
             layers.append(op); dzs.append(dz); cs.append(c)
+        self.wgrad_group([op.wgrad_item(dz, c) for op, dz, c in zip(layers, dzs, cs)])
         d5s, d4s, d3s, d2s = self._dgrad_multi(layers, dzs, cs)        # four independent 3x3 data gradients: one launch
         ops.upsample2_bwd(d2s, d3s, True)
         ops.upsample2_bwd(d3s, d4s, True)
@@ -856,8 +856,8 @@ class MaskRCNNEngine(object):
         for name, g in (("fpn_c2p2", d2s), ("fpn_c3p3", d3s), ("fpn_c4p4", d4s), ("fpn_c5p5", d5s)):
             op, c = self.op(name), tape[name]
             dz, _ = op.epilogue_bwd(g, c)
-            op.wgrad(dz, c)
             layers.append(op); dzs.append(dz); cs.append(c)
+        self.wgrad_group([op.wgrad_item(dz, c) for op, dz, c in zip(layers, dzs, cs)])
         dC = self._dgrad_multi(layers, dzs, cs)                         # and the four lateral 1x1 ones
         if self.grad_ready:
             self.join_wgrad()
