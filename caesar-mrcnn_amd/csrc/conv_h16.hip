@@ -409,63 +409,77 @@ __global__ void cast_to_h16_kernel(const float* __restrict__ src, T* dst, long l
 // Backward of  out = act(scale * (conv + bias) + shift)  on 16-bit tensors (mrcnn_epilogue_bwd in 16 bits): reads the
 // upstream gradient, the activated output and the pre-BN value z, writes dz (16 bit) and accumulates the channel sums
 // dgamma / dbeta / dbias in float32, multiplied by `gmul` (1 / loss scale) -- dz itself stays scaled.
+// A workgroup owns 2^lg groups of 8 channels (16-byte loads; blockIdx.y) and a range of rows (blockIdx.x); its 256 >> lg
+// row lanes walk the rows four at a time with all loads of a batch issued before the first store (dz_out may alias
+// dout).  Channel sums: registers -> LDS -> one global atomic per channel per workgroup (a narrow channel slice keeps
+// those few).
+#define EPI16_U 4
 template <typename T>
 __global__ __launch_bounds__(256) void epilogue_bwd_h16_kernel(const T* __restrict__ dout, const T* __restrict__ out,
                                                                const T* __restrict__ z, const float* __restrict__ scale,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                T* dz_out, float* dgamma, float* dbeta, float* dbias, long long M,
-                                                               int C, int act, long long rows_per_block, float gmul) {
-    extern __shared__ float sacc[];   // [3][C]
-    for (int c = threadIdx.x; c < 3 * C; c += 256) sacc[c] = 0.f;
+                                                               int C, int act, long long rows_per_block, int lg, float gmul) {
+    __shared__ float sacc[3 * 8 * 256];   // [3][8L]
+    const int L = 1 << lg, R = 256 >> lg;
+    for (int c = threadIdx.x; c < 24 * L; c += 256) sacc[c] = 0.f;
     __syncthreads();
-    const int c4n = C >> 2;
-    const int L = c4n < 256 ? c4n : 256;
-    const int R = 256 / L;
-    const int rsub = threadIdx.x / L, lane = threadIdx.x % L;
+    const int rsub = threadIdx.x >> lg, lane = threadIdx.x & (L - 1);
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > M) r1 = M;
-    typedef T t4 __attribute__((ext_vector_type(4)));
-    for (int cg = lane; cg < c4n; cg += L) {
-        const int c = cg * 4;
-        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, mu = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
-        if (scale) sc = *(const f32x4*)(scale + c);
-        if (dgamma) { mu = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c); }
-        f32x4 a_db = {0.f, 0.f, 0.f, 0.f}, a_dg = a_db, a_bias = a_db;
-        for (long long r = r0 + rsub; r < r1; r += R) {
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    const int c = (blockIdx.y * L + lane) * 8;
+    float sc[8], mu[8], rs[8], a_db[8], a_dg[8], a_bias[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        sc[k] = scale ? scale[c + k] : 1.f;
+        mu[k] = dgamma ? mean[c + k] : 0.f;
+        rs[k] = dgamma ? rstd[c + k] : 0.f;
+        a_db[k] = a_dg[k] = a_bias[k] = 0.f;
+    }
+    for (long long rb = r0 + rsub; rb < r1; rb += (long long)R * EPI16_U) {
+        t8 gg[EPI16_U], oo[EPI16_U], zz[EPI16_U];
+#pragma unroll
+        for (int u = 0; u < EPI16_U; ++u) {
+            long long r = rb + (long long)u * R;
+            if (r >= r1) r = r1 - 1;                           // clamped: in range, result discarded below
             const long long e = r * C + c;
-            const t4 gv = *(const t4*)(dout + e);
-            f32x4 g = {(float)gv[0], (float)gv[1], (float)gv[2], (float)gv[3]};
-            if (act == MRCNN_ACT_RELU) {
-                const t4 o = *(const t4*)(out + e);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) g[k] = (float)o[k] > 0.f ? g[k] : 0.f;
-            }
-            t4 dzv;
-            f32x4 dz;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { dz[k] = g[k] * sc[k]; dzv[k] = (T)dz[k]; }
-            *(t4*)(dz_out + e) = dzv;
-            if (dgamma) {
-                const t4 zz = *(const t4*)(z + e);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) a_dg[k] += g[k] * ((float)zz[k] - mu[k]) * rs[k];
-            }
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { a_db[k] += g[k]; a_bias[k] += dz[k]; }
+            gg[u] = *(const t8*)(dout + e);
+            if (act == MRCNN_ACT_RELU) oo[u] = *(const t8*)(out + e);
+            if (dgamma) zz[u] = *(const t8*)(z + e);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (dbeta || dgamma) atomicAdd(&sacc[c + k], a_db[k]);
-            if (dgamma) atomicAdd(&sacc[C + c + k], a_dg[k]);
-            if (dbias) atomicAdd(&sacc[2 * C + c + k], a_bias[k]);
+        for (int u = 0; u < EPI16_U; ++u) {
+            const long long r = rb + (long long)u * R;
+            if (r >= r1) break;
+            const long long e = r * C + c;
+            t8 dzv;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float g = (float)gg[u][k];
+                if (act == MRCNN_ACT_RELU) g = (float)oo[u][k] > 0.f ? g : 0.f;
+                const float dz = g * sc[k];
+                dzv[k] = (T)dz;
+                if (dgamma) a_dg[k] += g * ((float)zz[u][k] - mu[k]) * rs[k];
+                a_db[k] += g;
+                a_bias[k] += dz;
+            }
+            *(t8*)(dz_out + e) = dzv;
         }
     }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        if (dbeta || dgamma) atomicAdd(&sacc[lane * 8 + k], a_db[k]);
+        if (dgamma) atomicAdd(&sacc[8 * L + lane * 8 + k], a_dg[k]);
+        if (dbias) atomicAdd(&sacc[16 * L + lane * 8 + k], a_bias[k]);
+    }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        if (dbeta) atomicAdd(&dbeta[c], sacc[c] * gmul);
-        if (dgamma) atomicAdd(&dgamma[c], sacc[C + c] * gmul);
-        if (dbias) atomicAdd(&dbias[c], sacc[2 * C + c] * gmul);
+    const int cb = blockIdx.y * 8 * L;
+    for (int j = threadIdx.x; j < 8 * L; j += 256) {
+        if (dbeta) atomicAdd(&dbeta[cb + j], sacc[j] * gmul);
+        if (dgamma) atomicAdd(&dgamma[cb + j], sacc[8 * L + j] * gmul);
+        if (dbias) atomicAdd(&dbias[cb + j], sacc[16 * L + j] * gmul);
     }
 }
 
@@ -842,18 +856,23 @@ extern "C" int mrcnn_epilogue_bwd_h16(int dtype, const void* dout, const void* o
     if (!dout || !dz_out || M <= 0 || C < 16 || C > 4096 || (C & (C - 1)) || !h16_dtype_ok(dtype)) return MRCNN_ERR_ARG;
     if ((act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) || (act == MRCNN_ACT_RELU && !out)) return MRCNN_ERR_ARG;
     if (dgamma && (!z || !mean || !rstd)) return MRCNN_ERR_ARG;
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!al(dout) || !al(out) || !al(z) || !al(dz_out)) return MRCNN_ERR_ARG;
+    const int c8n = C >> 3;                                   // C is a power of two >= 16
+    int lg = 0;
+    while ((2 << lg) <= (c8n < 16 ? c8n : 16)) ++lg;           // 16 lanes x 8 channels per row at most
+    const long long R = 256 >> lg;
     long long rows_per_block = cdiv64(M, 2048);
-    const long long min_rows = cdiv64(4096, C);
-    if (rows_per_block < min_rows) rows_per_block = min_rows;
-    const unsigned grid = (unsigned)cdiv64(M, rows_per_block);
+    rows_per_block = cdiv64(rows_per_block, R * EPI16_U) * R * EPI16_U;   // whole batches
+    const dim3 grid((unsigned)cdiv64(M, rows_per_block), (unsigned)(c8n >> lg));
     if (dtype == MRCNN_DTYPE_F16)
-        hipLaunchKernelGGL(epilogue_bwd_h16_kernel<_Float16>, dim3(grid), dim3(256), 3 * C * sizeof(float), (hipStream_t)stream,
+        hipLaunchKernelGGL(epilogue_bwd_h16_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const _Float16*)dout, (const _Float16*)out, (const _Float16*)z, scale, mean, rstd, (_Float16*)dz_out,
-                           dgamma, dbeta, dbias, (long long)M, C, act, rows_per_block, grad_multiplier);
+                           dgamma, dbeta, dbias, (long long)M, C, act, rows_per_block, lg, grad_multiplier);
     else
-        hipLaunchKernelGGL(epilogue_bwd_h16_kernel<__bf16>, dim3(grid), dim3(256), 3 * C * sizeof(float), (hipStream_t)stream,
+        hipLaunchKernelGGL(epilogue_bwd_h16_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const __bf16*)dout, (const __bf16*)out, (const __bf16*)z, scale, mean, rstd, (__bf16*)dz_out, dgamma,
-                           dbeta, dbias, (long long)M, C, act, rows_per_block, grad_multiplier);
+                           dbeta, dbias, (long long)M, C, act, rows_per_block, lg, grad_multiplier);
     return mrcnn_launch_status();
 }
 
