@@ -479,7 +479,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_blds_kernel(const ConvArgs p,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int ntiles = p.Cout / BN;
-    const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x % ntiles;
+    const int tiles = ((p.M + BM - 1) / BM) * ntiles;
+    const int kz = p.ksplit > 1 ? (int)blockIdx.x / tiles : 0;          // split-K slice (mid-size layers)
+    const int tile = (int)blockIdx.x - kz * tiles;
+    const int mtile = tile / ntiles, ntile = tile % ntiles;
     const int m0 = mtile * BM, n0 = ntile * BN;
     const int ohw = p.OH * p.OW;
 
@@ -515,6 +518,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_blds_kernel(const ConvArgs p,
     for (int jj = 0; jj < 2; ++jj) b_voff[jj] = (unsigned)((((wave + jj * 4) * 2 + (lane >> 5)) * p.Cout + (lane & 31) * 4) * 4);
 
     int kh = 0, kw = 0, ci0 = 0, tap = 0;
+    const int ks_first = kz * p.ksteps;                         // in K-steps of BK; 0 without split-K
+    if (ks_first > 0) {
+        const int taps = p.KH * p.KW;
+        const int chunk = ks_first / taps;
+        tap = ks_first - chunk * taps;
+        ci0 = chunk * BK;
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
+    }
     auto stage = [&](float* ab) {                               // ab: LDS buffer (A tile, then B tile)
         float* bb = ab + AF;
         const unsigned soff_a = (unsigned)(((kh * p.W + kw) * p.Cin + ci0) * 4);
@@ -570,7 +582,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_blds_kernel(const ConvArgs p,
         }
     };
 
-    const int nk = p.Ktot / BK;
+    const int nk_all = p.Ktot / BK;
+    const int nk = p.ksplit > 1 ? (ks_first + p.ksteps < nk_all ? p.ksteps : nk_all - ks_first) : nk_all;
     stage(lds);
     __syncthreads();
     for (int ks = 0; ks < nk; ks += 2) {
@@ -584,6 +597,21 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_blds_kernel(const ConvArgs p,
         }
     }
     const int mw0 = m0 + wm * 64 + 4 * lh, nw0 = n0 + wn * 64 + li;
+    if (p.ksplit > 1) {                                         // partial sums -> slab kz; the reduction kernel applies the epilogue
+        float* slab = p.slab + (long long)kz * p.M * p.Cout;
+        auto put = [&](const f32x16& c, int mbase, int n) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mbase + (r & 3) + 8 * (r >> 2);
+                if (m < p.M) slab[(long long)m * p.Cout + n] = c[r];
+            }
+        };
+        put(acc[0][0], mw0, nw0);
+        put(acc[0][1], mw0, nw0 + 32);
+        put(acc[1][0], mw0 + 32, nw0);
+        put(acc[1][1], mw0 + 32, nw0 + 32);
+        return;
+    }
     if (p.fb_act >= 0) {
         // fused backward epilogue: column sums of this workgroup (2 row waves x 2 lane halves per column) meet in LDS,
         // then one atomic per channel and sum
@@ -802,6 +830,8 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_bwd_kernel(const Con
     }
 }
 
+static void launch_splitk_reduction(const ConvArgs& a, hipStream_t s);
+
 template <int BM, int BN, int WM, int WN>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
     const int mt = (a.M + BM - 1) / BM, nt = (a.Cout + BN - 1) / BN;
@@ -809,6 +839,12 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
         hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, true>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);
     else
         hipLaunchKernelGGL((conv_fwd_kernel<BM, BN, WM, WN, false>), dim3((unsigned)(mt * nt * a.ksplit)), dim3(WM * WN * 64), 0, s, a);
+    launch_splitk_reduction(a, s);
+    return mrcnn_launch_status();
+}
+
+// second pass of a split-K launch: slab sum + epilogue (or the backward epilogue of the layer below)
+static void launch_splitk_reduction(const ConvArgs& a, hipStream_t s) {
     if (a.ksplit > 1 && a.fb_act >= 0) {         // slabs -> epilogue backward of the layer below
         const EpiGrid g = mrcnn_epilogue_grid(a.M, a.Cout);
         hipLaunchKernelGGL(conv_splitk_epilogue_bwd_kernel, dim3(g.row_blocks, g.chan_blocks), dim3(256), 0, s, a,
@@ -820,19 +856,18 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
         else
             hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, s, a);
     }
-    return mrcnn_launch_status();
 }
 
 // 128-row tiles only when they give every CU several workgroups (256 CUs x 5 resident): fewer, and the chip idles
 #ifndef CONV_BIG_TILE_MIN_BLOCKS
 #define CONV_BIG_TILE_MIN_BLOCKS 640
 #endif
-struct ConvPlan { int bm, bn, ksplit, ksteps; };
+struct ConvPlan { int bm, bn, ksplit, ksteps; bool dma_split; };
 
 // Tile + split-K choice.  Large problems: 128-row tiles, no split.  Small feature maps (C3..C5, P3..P6
 // at 256^2 inputs) have only 4..128 output tiles, far fewer than the 256 CUs, so the K loop is cut into
 // up to 16 slices that run as separate workgroups (slabs summed by conv_splitk_epilogue_kernel).
-static ConvPlan plan_conv(const mrcnn_conv_desc* d) {
+static ConvPlan plan_conv(const mrcnn_conv_desc* d, bool allow_dma_split = true) {
     ConvPlan pl;
     const long long M = (long long)d->N * d->OH * d->OW;
     const int Cout = d->Cout;
@@ -848,6 +883,25 @@ static ConvPlan plan_conv(const mrcnn_conv_desc* d) {
         pl.bn = 128;
         pl.bm = (((M + 127) / 128) * ((Cout + 127) / 128) >= CONV_BIG_TILE_MIN_BLOCKS) ? 128 : 64;
         if (pl.bm == 64 && ((M + 63) / 64) * ((Cout + 127) / 128) < 128) pl.bn = 64;   // more, smaller tiles
+    }
+    pl.dma_split = false;
+    // mid-size layers (too few 128x128 tiles to fill the chip, enough K to cut): LDS-DMA kernel with split-K --
+    // each slice at least 16 K-steps of 16; MRCNN_DMA_SPLIT_MIN_TILES=0 switches it off (A/B)
+    static const long long dma_min_tiles = getenv("MRCNN_DMA_SPLIT_MIN_TILES") ? atoll(getenv("MRCNN_DMA_SPLIT_MIN_TILES")) : 96;
+    const long long t128 = ((M + 127) / 128) * (Cout / 128);
+    const int nk16 = d->KH * d->KW * d->Cin / 16;
+    if (allow_dma_split && dma_min_tiles > 0 && pl.bm == 64 && Cout % 128 == 0 && d->Cin % 32 == 0 && d->KH * d->KW <= 64 &&
+        t128 >= dma_min_tiles && t128 < CONV_BIG_TILE_MIN_BLOCKS && nk16 >= 32) {
+        long long ks = (1024 + t128 - 1) / t128;
+        if (ks > nk16 / 16) ks = nk16 / 16;
+        if (ks > 16) ks = 16;
+        if (ks >= 2) {
+            pl.bm = 128; pl.bn = 128; pl.dma_split = true;
+            pl.ksteps = (int)((nk16 + ks - 1) / ks);
+            pl.ksteps += pl.ksteps & 1;                         // the loop is unrolled over the two LDS buffers
+            pl.ksplit = (nk16 + pl.ksteps - 1) / pl.ksteps;
+            return pl;
+        }
     }
     blocks = ((M + pl.bm - 1) / pl.bm) * ((Cout + pl.bn - 1) / pl.bn);
     pl.ksplit = 1;
@@ -920,8 +974,15 @@ static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* 
     const long long M = a.M;
     hipStream_t s = (hipStream_t)stream;
 
-    ConvPlan pl = plan_conv(d);
-    const size_t need = pl.ksplit > 1 ? (size_t)pl.ksplit * M * d->Cout * sizeof(float) : 0;
+    const long long xbytes_all = (long long)d->N * d->H * d->W * d->Cin * 4 + ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
+    const bool buf_ok = a.fastA && a.vecB && xbytes_all < 0x7FFFFFF0LL && (long long)a.Ktot * d->Cout * 4 < 0x7FFFFFF0LL &&
+                        !mrcnn_force_flat_glds();
+    ConvPlan pl = plan_conv(d, buf_ok);
+    size_t need = pl.ksplit > 1 ? (size_t)pl.ksplit * M * d->Cout * sizeof(float) : 0;
+    if (pl.dma_split && (!workspace || workspace_bytes < need)) {  // sized for another plan: fall back to the 64-row tiles
+        pl = plan_conv(d, false);
+        need = pl.ksplit > 1 ? (size_t)pl.ksplit * M * d->Cout * sizeof(float) : 0;
+    }
     if (need && (!workspace || workspace_bytes < need)) {        // no room: run unsplit
         pl.ksplit = 1;
         pl.ksteps = a.nk;
@@ -941,6 +1002,15 @@ static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* 
         if (ep->dgamma && (!ep->z || !ep->mean || !ep->rstd)) return MRCNN_ERR_ARG;
         a.fb_act = ep->act; a.fb_out = ep->out; a.fb_z = ep->z; a.fb_scale = ep->scale; a.fb_mean = ep->mean; a.fb_rstd = ep->rstd;
         a.fb_dgamma = ep->dgamma; a.fb_dbeta = ep->dbeta; a.fb_dbias = ep->dbias;
+    }
+    if (pl.dma_split && pl.ksplit > 1) {        // mid-size layer: LDS-DMA tiles, K cut into slices, slabs reduced by a second launch
+        const int mt = (a.M + 127) / 128, nt = a.Cout / 128;
+        const long long xbytes = (long long)d->N * d->H * d->W * d->Cin * 4;
+        const long long shift = ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
+        hipLaunchKernelGGL(conv_fwd_blds_kernel, dim3((unsigned)(mt * nt * a.ksplit)), dim3(256), 0, s, a, (unsigned)shift,
+                           (unsigned)(xbytes + shift));
+        launch_splitk_reduction(a, s);
+        return mrcnn_launch_status();
     }
     if (lds_dma) {
         const int mt = (a.M + 127) / 128, nt = a.Cout / 128;
