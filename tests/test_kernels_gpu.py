@@ -655,7 +655,8 @@ def test_conv_dgrad_fused_with_epilogue_backward_splitk(dev):
     """The same entry point on a small feature map: the split-K slab reduction carries the backward epilogue."""
     ops = _ops()
     rng = np.random.default_rng(91)
-    for (N, H, W, Cin, Cout, k) in ((4, 16, 16, 1024, 256, 1), (4, 16, 16, 256, 256, 3), (2, 8, 8, 512, 2048, 1)):
+    # the last shape (98 x 2 tiles of 128 x 128, 144 K-steps of 16) takes the LDS-DMA kernel with split-K
+    for (N, H, W, Cin, Cout, k) in ((4, 16, 16, 1024, 256, 1), (4, 16, 16, 256, 256, 3), (2, 8, 8, 512, 2048, 1), (64, 14, 14, 256, 256, 3)):
         dz = torch.tensor(_rand(rng, N, H, W, Cin), device=dev)
         wt = torch.tensor(_rand(rng, k, k, Cin, Cout, scale=1.0 / np.sqrt(k * k * Cin)), device=dev)
         below_out = torch.relu(torch.tensor(_rand(rng, N, H, W, Cout), device=dev))
