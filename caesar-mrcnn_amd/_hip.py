@@ -141,6 +141,10 @@ def lib():
             raise HipPathError(
                 "libmrcnn_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'`; there is no CPU fallback for the hot path." % LIB_PATH)
+        # torch first: its wheel carries its own HIP runtime, and the streams / device pointers we are handed belong
+        # to that one.  Loaded before torch, this library would pull in the system runtime instead and every launch
+        # on a torch stream would fail (seen as status -2 from the first kernel when build() and smoke() share a process).
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(l, name)   # AttributeError here == symbol missing == broken build
