@@ -908,7 +908,8 @@ static ConvPlan plan_conv(const mrcnn_conv_desc* d, bool allow_dma_split = true)
     pl.ksteps = nk;
     static const long long split_below = getenv("MRCNN_SPLITK_BELOW") ? atoll(getenv("MRCNN_SPLITK_BELOW")) : 768;
     if (blocks < split_below && nk >= 8) {
-        long long want = (1024 + blocks - 1) / blocks;         // aim at ~4 workgroups per CU
+        static const long long target = getenv("MRCNN_SPLITK_TARGET") ? atoll(getenv("MRCNN_SPLITK_TARGET")) : 512;
+        long long want = (target + blocks - 1) / blocks;         // ~2 workgroups per CU: more slices cost more slab traffic than they hide latency
         long long maxs = nk / 4;                               // at least 4 K-steps per slice
         long long ks = want < maxs ? want : maxs;
         if (ks > 16) ks = 16;
