@@ -9,6 +9,8 @@ backbone = sys.argv[1] if len(sys.argv) > 1 else "resnet101"
 size = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
 cfg = run_py_config(backbone=backbone, imgsize=size, mode="inference")
 m = MaskRCNN("inference", cfg, "/tmp/x", device=torch.device("cuda:0"))
+if os.environ.get("MRCNN_HEAD_DTYPE"):                       # opt-in 16-bit mask head (float16 | bfloat16)
+    m.engine.head_dtype = getattr(torch, os.environ["MRCNN_HEAD_DTYPE"])
 x = torch.rand(1, size, size, 3, device="cuda") * 255
 w = torch.tensor([[0., 0., 1., 1.]], device="cuda")
 for fn, name in ((m.engine.infer, "eager"), (m.engine.infer_graphed, "graph")):
