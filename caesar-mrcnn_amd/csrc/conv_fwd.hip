@@ -471,7 +471,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_glds_kernel(const ConvArgs p)
 typedef __attribute__((address_space(3))) void* conv_lds_ptr;
 #define CONV_OOB_OFFSET 0xFFFFFFF0u
 
-__global__ __launch_bounds__(256, 2) void conv_fwd_blds_kernel(const ConvArgs p, const unsigned x_shift, const unsigned x_records) {
+// SPLIT (mid-size layers: K cut into slices, partial sums to slabs) is a compile-time variant so that the unsplit
+// kernel keeps its 96 VGPRs (5 workgroups per CU); with the slice bookkeeping in the same body it grew to 123.
+template <bool SPLIT>
+__device__ __forceinline__ void conv_fwd_blds_body(const ConvArgs& p, const unsigned x_shift, const unsigned x_records) {
     constexpr int BM = 128, BN = 128, BK = 16, TM = 2, TN = 2;
     constexpr int AF = BM * BK, BF = BK * BN;                  // floats per tile (8 KiB each)
     __shared__ __attribute__((aligned(16))) float lds[2 * (AF + BF)];
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_blds_kernel(const ConvArgs p,
     const int wm = wave >> 1, wn = wave & 1;
     const int ntiles = p.Cout / BN;
     const int tiles = ((p.M + BM - 1) / BM) * ntiles;
-    const int kz = p.ksplit > 1 ? (int)blockIdx.x / tiles : 0;          // split-K slice (mid-size layers)
+    const int kz = SPLIT ? (int)blockIdx.x / tiles : 0;                 // split-K slice (mid-size layers)
     const int tile = (int)blockIdx.x - kz * tiles;
     const int mtile = tile / ntiles, ntile = tile % ntiles;
     const int m0 = mtile * BM, n0 = ntile * BN;
@@ -518,8 +521,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_blds_kernel(const ConvArgs p,
     for (int jj = 0; jj < 2; ++jj) b_voff[jj] = (unsigned)((((wave + jj * 4) * 2 + (lane >> 5)) * p.Cout + (lane & 31) * 4) * 4);
 
     int kh = 0, kw = 0, ci0 = 0, tap = 0;
-    const int ks_first = kz * p.ksteps;                         // in K-steps of BK; 0 without split-K
-    if (ks_first > 0) {
+    const int ks_first = SPLIT ? kz * p.ksteps : 0;             // in K-steps of BK
+    if (SPLIT && ks_first > 0) {
         const int taps = p.KH * p.KW;
         const int chunk = ks_first / taps;
         tap = ks_first - chunk * taps;
@@ -583,7 +586,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_blds_kernel(const ConvArgs p,
     };
 
     const int nk_all = p.Ktot / BK;
-    const int nk = p.ksplit > 1 ? (ks_first + p.ksteps < nk_all ? p.ksteps : nk_all - ks_first) : nk_all;
+    const int nk = SPLIT ? (ks_first + p.ksteps < nk_all ? p.ksteps : nk_all - ks_first) : nk_all;
     stage(lds);
     __syncthreads();
     for (int ks = 0; ks < nk; ks += 2) {
@@ -597,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_blds_kernel(const ConvArgs p,
         }
     }
     const int mw0 = m0 + wm * 64 + 4 * lh, nw0 = n0 + wn * 64 + li;
-    if (p.ksplit > 1) {                                         // partial sums -> slab kz; the reduction kernel applies the epilogue
+    if constexpr (SPLIT) {                                      // partial sums -> slab kz; the reduction kernel applies the epilogue
         float* slab = p.slab + (long long)kz * p.M * p.Cout;
         auto put = [&](const f32x16& c, int mbase, int n) {
 #pragma unroll
@@ -647,6 +650,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_blds_kernel(const ConvArgs p,
     conv_epilogue_tile(p, acc[0][1], mw0, nw0 + 32);
     conv_epilogue_tile(p, acc[1][0], mw0 + 32, nw0);
     conv_epilogue_tile(p, acc[1][1], mw0 + 32, nw0 + 32);
+}
+
+__global__ __launch_bounds__(256, 2) void conv_fwd_blds_kernel(const ConvArgs p, const unsigned x_shift, const unsigned x_records) {
+    conv_fwd_blds_body<false>(p, x_shift, x_records);
+}
+
+__global__ __launch_bounds__(256, 2) void conv_fwd_blds_splitk_kernel(const ConvArgs p, const unsigned x_shift, const unsigned x_records) {
+    conv_fwd_blds_body<true>(p, x_shift, x_records);
 }
 
 // Second pass of split-K: sum the slabs in a fixed order, then the ordinary epilogue.
@@ -1008,7 +1019,7 @@ static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* 
         const int mt = (a.M + 127) / 128, nt = a.Cout / 128;
         const long long xbytes = (long long)d->N * d->H * d->W * d->Cin * 4;
         const long long shift = ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
-        hipLaunchKernelGGL(conv_fwd_blds_kernel, dim3((unsigned)(mt * nt * a.ksplit)), dim3(256), 0, s, a, (unsigned)shift,
+        hipLaunchKernelGGL(conv_fwd_blds_splitk_kernel, dim3((unsigned)(mt * nt * a.ksplit)), dim3(256), 0, s, a, (unsigned)shift,
                            (unsigned)(xbytes + shift));
         launch_splitk_reduction(a, s);
         return mrcnn_launch_status();
