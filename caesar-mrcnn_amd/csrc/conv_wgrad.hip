@@ -409,16 +409,25 @@ __device__ __forceinline__ void conv_wgrad_blds_body(const WgradArgs& p, const u
     };
 
     if (m_begin < m_end) {
+        // Table entries are fetched one half-step ahead of the stage() that consumes them, UNCONDITIONALLY (index
+        // clamped into the table, which carries BP rows past M): a fetch under `if (more rows)` makes the entries a
+        // conditional loop-carried value, the compiler copies the freshly loaded registers at the join, and the wait
+        // those copies need (vmcnt(0): younger than the LDS-DMA just issued) stalled every step until the next
+        // tile's DMA had landed -- no overlap of DMA and MFMA left (the table variant ran at 79 % MFMA-busy).
+        auto fetch_at = [&](int mb) { fetch(mb < p.M ? mb : p.M); };
         fetch(m_begin);
         stage(lds, m_begin);
-        if (m_begin + BP < m_end) fetch(m_begin + BP);
+        fetch_at(m_begin + BP);
         __syncthreads();
         for (int mb = m_begin; mb < m_end; mb += 2 * BP) {
-            if (mb + BP < m_end) { stage(lds + (XF + YF), mb + BP); if (mb + 2 * BP < m_end) fetch(mb + 2 * BP); }
+            const bool has1 = mb + BP < m_end;
+            if (has1) stage(lds + (XF + YF), mb + BP);
+            fetch_at(mb + 2 * BP);
             compute(std::integral_constant<int, 0>{});
             __syncthreads();
-            if (mb + BP < m_end) {
-                if (mb + 2 * BP < m_end) { stage(lds, mb + 2 * BP); if (mb + 3 * BP < m_end) fetch(mb + 3 * BP); }
+            if (has1 && mb + 2 * BP < m_end) stage(lds, mb + 2 * BP);
+            fetch_at(mb + 3 * BP);
+            if (has1) {
                 compute(std::integral_constant<int, 1>{});
                 __syncthreads();
             }
