@@ -628,16 +628,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(const WgradH16Ar
     };
 
     if (m_begin < m_end) {
+        // unconditional, clamped table prefetch (see conv_wgrad_blds_body: a conditional fetch costs a vmcnt(0) wait
+        // right behind every DMA issue)
+        auto fetch_at = [&](int mb) { fetch(mb < p.M ? mb : p.M); };
         fetch(m_begin);
         stage(lds, m_begin);
-        if (m_begin + BP < m_end) fetch(m_begin + BP);
+        fetch_at(m_begin + BP);
         __syncthreads();
         for (int mb = m_begin; mb < m_end; mb += 2 * BP) {
-            if (mb + BP < m_end) { stage(lds + (XB + YB), mb + BP); if (mb + 2 * BP < m_end) fetch(mb + 2 * BP); }
+            const bool has1 = mb + BP < m_end;
+            if (has1) stage(lds + (XB + YB), mb + BP);
+            fetch_at(mb + 2 * BP);
             compute(std::integral_constant<int, 0>{});
             __syncthreads();
-            if (mb + BP < m_end) {
-                if (mb + 2 * BP < m_end) { stage(lds, mb + 2 * BP); if (mb + 3 * BP < m_end) fetch(mb + 3 * BP); }
+            if (has1 && mb + 2 * BP < m_end) stage(lds, mb + 2 * BP);
+            fetch_at(mb + 3 * BP);
+            if (has1) {
                 compute(std::integral_constant<int, 1>{});
                 __syncthreads();
             }
