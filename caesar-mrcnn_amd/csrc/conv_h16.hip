@@ -517,7 +517,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(const WgradH16Ar
     constexpr int BI = 256, BN = 128, BP = 32, TM = 4, TN = 2;
     constexpr int XROW = BI * 2, YROW = BN * 2;                 // bytes per pixel row
     constexpr int XB = BP * XROW, YB = BP * YROW;               // 16 KiB + 8 KiB per buffer
-    __shared__ __attribute__((aligned(16))) char lds[2 * (XB + YB)];
+    // two separately declared buffers: the compiler then knows that the LDS-DMA into one cannot alias the transposed
+    // reads of the other and leaves the DMA in flight during the MFMAs (with one array it waited vmcnt(0) before the reads)
+    __shared__ __attribute__((aligned(16))) char lds0[XB + YB];
+    __shared__ __attribute__((aligned(16))) char lds1[XB + YB];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -588,36 +591,36 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(const WgradH16Ar
     const int prow = 8 * (lane >> 5) + q;
     // a * 32 channels = 4 chunks: the XOR touches chunk bits 2..3 only when q != 0, so "+ a * 64 bytes" is not uniform;
     // keep one base per a (4) and per b (2) instead of immediates
-    const char* x_rda[TM];
-    const char* y_rdb[TN];
+    int x_rda[TM];                                            // byte offsets inside a buffer
+    int y_rdb[TN];
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
         const int c = xcol + a * 32;
-        x_rda[a] = lds + prow * XROW + ((((c >> 3) ^ (q << 2)) & 31) << 4) + (c & 7) * 2;
+        x_rda[a] = prow * XROW + ((((c >> 3) ^ (q << 2)) & 31) << 4) + (c & 7) * 2;
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
         const int c = ycol + b * 32;
-        y_rdb[b] = lds + XB + prow * YROW + ((((c >> 3) ^ (q << 2)) & 15) << 4) + (c & 7) * 2;
+        y_rdb[b] = XB + prow * YROW + ((((c >> 3) ^ (q << 2)) & 15) << 4) + (c & 7) * 2;
     }
 
     auto compute = [&](auto curc) {
-        constexpr int BO = decltype(curc)::value * (XB + YB);
+        const char* const buf = decltype(curc)::value ? lds1 : lds0;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             v8 av[TM], bv[TN];
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 union { s16x4 h[2]; v8 v; } u;
-                u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_tr_ptr)(x_rda[a] + BO + kk * 16 * XROW));
-                u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_tr_ptr)(x_rda[a] + BO + kk * 16 * XROW + 4 * XROW));
+                u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_tr_ptr)(buf + x_rda[a] + kk * 16 * XROW));
+                u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_tr_ptr)(buf + x_rda[a] + kk * 16 * XROW + 4 * XROW));
                 av[a] = u.v;
             }
 #pragma unroll
             for (int b = 0; b < TN; ++b) {
                 union { s16x4 h[2]; v8 v; } u;
-                u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_tr_ptr)(y_rdb[b] + BO + kk * 16 * YROW));
-                u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_tr_ptr)(y_rdb[b] + BO + kk * 16 * YROW + 4 * YROW));
+                u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_tr_ptr)(buf + y_rdb[b] + kk * 16 * YROW));
+                u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_tr_ptr)(buf + y_rdb[b] + kk * 16 * YROW + 4 * YROW));
                 bv[b] = u.v;
             }
 #pragma unroll
@@ -632,16 +635,16 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(const WgradH16Ar
         // right behind every DMA issue)
         auto fetch_at = [&](int mb) { fetch(mb < p.M ? mb : p.M); };
         fetch(m_begin);
-        stage(lds, m_begin);
+        stage(lds0, m_begin);
         fetch_at(m_begin + BP);
         __syncthreads();
         for (int mb = m_begin; mb < m_end; mb += 2 * BP) {
             const bool has1 = mb + BP < m_end;
-            if (has1) stage(lds + (XB + YB), mb + BP);
+            if (has1) stage(lds1, mb + BP);
             fetch_at(mb + 2 * BP);
             compute(std::integral_constant<int, 0>{});
             __syncthreads();
-            if (has1 && mb + 2 * BP < m_end) stage(lds, mb + 2 * BP);
+            if (has1 && mb + 2 * BP < m_end) stage(lds0, mb + 2 * BP);
             fetch_at(mb + 3 * BP);
             if (has1) {
                 compute(std::integral_constant<int, 1>{});
