@@ -54,7 +54,8 @@ class RpnTargetDesc(C.Structure):
 
 
 class BwdEpilogue(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("out", "z", "scale", "mean", "rstd", "dgamma", "dbeta", "dbias")] + [("act", C.c_int32)]
+    _fields_ = [(n, C.c_void_p) for n in ("out", "z", "scale", "mean", "rstd", "dgamma", "dbeta", "dbias")] + [
+        ("act", C.c_int32), ("dy", C.c_void_p)]
 
 
 class DetectionDesc(C.Structure):

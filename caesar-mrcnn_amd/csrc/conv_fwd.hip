@@ -25,6 +25,7 @@ struct ConvArgs {
     // activated output of the layer below; that layer's epilogue backward is applied before the store
     const float* fb_out; const float* fb_z; const float* fb_scale; const float* fb_mean; const float* fb_rstd;
     float* fb_dgamma; float* fb_dbeta; float* fb_dbias; int fb_act;
+    float* fb_dy;                      // optional: y * act' as a second output (split-K reduction only)
 };
 
 // Padding taps, rows past M and columns past Cout fetch from here: loads stay unconditional (no divergent branch,
@@ -818,6 +819,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_bwd_kernel(const Con
 #pragma unroll
             for (int q = 0; q < 4; ++q) dz[q] = g[q] * sc[q];
             *(f32x4*)(p.out + e) = dz;
+            if (p.fb_dy) *(f32x4*)(p.fb_dy + e) = g;
             if (p.fb_dgamma) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a_dg[q] += g[q] * (zz[u][q] - mu[q]) * rs[q];
@@ -973,6 +975,7 @@ static int conv_fill_args(const mrcnn_conv_desc* d, const float* x, const float*
     a.fb_act = -1;
     a.fb_out = a.fb_z = a.fb_scale = a.fb_mean = a.fb_rstd = nullptr;
     a.fb_dgamma = a.fb_dbeta = a.fb_dbias = nullptr;
+    a.fb_dy = nullptr;
     return MRCNN_OK;
 }
 
@@ -1007,13 +1010,15 @@ static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* 
         auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         const bool split_ok = pl.ksplit > 1 && pow2c && al(out) && al(res) && al(ep->out) && al(ep->z) && al(ep->scale) &&
                               al(ep->mean) && al(ep->rstd);
-        const bool dma_ok = lds_dma && xb < 0x7FFFFFF0LL && !mrcnn_force_flat_glds();
+        const bool dma_ok = lds_dma && xb < 0x7FFFFFF0LL && !mrcnn_force_flat_glds() && !ep->dy;   // second output: split-K path only
         if (!(dma_ok || split_ok) || !a.dense || bias || scale || z_out || d->act != MRCNN_ACT_NONE || d->res_mode == MRCNN_RES_UP2)
             return MRCNN_ERR_UNSUPPORTED;
         if ((ep->act != MRCNN_ACT_NONE && ep->act != MRCNN_ACT_RELU) || (ep->act == MRCNN_ACT_RELU && !ep->out)) return MRCNN_ERR_ARG;
         if (ep->dgamma && (!ep->z || !ep->mean || !ep->rstd)) return MRCNN_ERR_ARG;
         a.fb_act = ep->act; a.fb_out = ep->out; a.fb_z = ep->z; a.fb_scale = ep->scale; a.fb_mean = ep->mean; a.fb_rstd = ep->rstd;
         a.fb_dgamma = ep->dgamma; a.fb_dbeta = ep->dbeta; a.fb_dbias = ep->dbias;
+        a.fb_dy = ep->dy;
+        if (ep->dy && (reinterpret_cast<uintptr_t>(ep->dy) & 15)) return MRCNN_ERR_ARG;
     }
     if (pl.dma_split && pl.ksplit > 1) {        // mid-size layer: LDS-DMA tiles, K cut into slices, slabs reduced by a second launch
         const int mt = (a.M + 127) / 128, nt = a.Cout / 128;

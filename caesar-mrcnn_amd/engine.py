@@ -869,10 +869,19 @@ class MaskRCNNEngine(object):
                 blk = stage[bi]
                 # the first block of stage s+1 consumes C_s, whose FPN gradient is already in dC[si-1]
                 acc_buf = dC[si - 1] if (bi == 0 and si > 0) else None
-                d_out = self._block_bwd(blk, d_out, tape[id(blk)], acc_buf)
+                # the block before this one in the forward order: its output epilogue backward (ReLU mask, BN of its 2c
+                # convolution) rides on this block's last data gradient when that is a split-K layer
+                below = None
+                if bi > 0:
+                    below = (stage[bi - 1], tape[id(stage[bi - 1])][2])
+                elif si > 0:
+                    prev = self.stages[si - 1][-1]
+                    below = (prev, tape[id(prev)][2])
+                d_out = self._block_bwd(blk, d_out, tape[id(blk)], acc_buf, below)
             if self.grad_ready:
                 self.join_wgrad()
                 self.grad_ready(*self.grad_ranges[si + 2])
+        assert not isinstance(d_out, tuple)             # the first block of the network has no block below it
         am, pre_shape = tape["pool"]
         d_relu = ops.maxpool3x3s2_bwd(d_out, am, pre_shape)
         c1 = self.op("conv1")
@@ -883,9 +892,15 @@ class MaskRCNNEngine(object):
             self.grad_ready(*self.grad_ranges["head"])
             self.grad_ready(*self.grad_ranges["bn"])
 
-    def _block_bwd(self, blk, d_out, ctxs, acc_buf):
+    def _block_bwd(self, blk, d_out, ctxs, acc_buf, below=None):
+        """Backward of one bottleneck block.  ``d_out``: gradient w.r.t. the block output, or the pair (dz of the 2c
+        convolution, gradient after the output ReLU) when the block after it already applied this block's output
+        epilogue backward (see ``below``).  Returns the gradient w.r.t. the block input, or such a pair for ``below``."""
         ca, cb, cc, c1c = ctxs
-        dzc, dy = blk.c2c.epilogue_bwd(d_out, cc, want_dy=True)
+        if isinstance(d_out, tuple):
+            dzc, dy = d_out
+        else:
+            dzc, dy = blk.c2c.epilogue_bwd(d_out, cc, want_dy=True)
         # 2c -> 2b -> 2a: each data-gradient convolution (or its split-K reduction) applies the epilogue backward of
         # the layer below (mrcnn_conv2d_dgrad_ep)
         if not self.wt_valid:
@@ -897,15 +912,33 @@ class MaskRCNNEngine(object):
         items = [blk.c2c.wgrad_item(dzc, cc), blk.c2b.wgrad_item(dzb, cb), blk.c2a.wgrad_item(dza, ca)]
         if blk.c1 is None:
             self.wgrad_group(items)
-            # identity shortcut: dx = dy + dgrad_2a (in place on dy)
-            return blk.c2a.dgrad(dza, ca, out=dy, accumulate=True)
+            # identity shortcut: dx = dy + dgrad_2a
+            fused = self._final_dgrad_fused(blk, dza, dy, below)
+            return fused if fused is not None else blk.c2a.dgrad(dza, ca, out=dy, accumulate=True)   # in place on dy
         dz1, _ = blk.c1.epilogue_bwd(dy, c1c)
         self.wgrad_group(items + [blk.c1.wgrad_item(dz1, c1c)])
         if acc_buf is not None:
             dx = blk.c1.dgrad(dz1, c1c, out=acc_buf, accumulate=True)
         else:
             dx = blk.c1.dgrad(dz1, c1c)
-        return blk.c2a.dgrad(dza, ca, out=dx, accumulate=True)
+        fused = self._final_dgrad_fused(blk, dza, dx, below)
+        return fused if fused is not None else blk.c2a.dgrad(dza, ca, out=dx, accumulate=True)
+
+    def _final_dgrad_fused(self, blk, dza, acc, below):
+        """dx = dgrad_2a(dza) + acc with the output epilogue backward of the block below fused into the split-K reduction:
+        returns (dz of below's 2c convolution, masked gradient for below's shortcut), or None when that data gradient is not
+        a dense stride-1 split-K layer (the caller then takes the two-launch route)."""
+        if below is None or not self.fused_dgrad_epilogue or not self.wt_valid or blk.c2a.stride != 1:
+            return None
+        pblk, pcc = below
+        op = pblk.c2c
+        _, z, out, act = pcc
+        if op.bn is None or act != ACT_RELU:
+            return None
+        dy_below = ops.empty_like(acc)
+        got = ops.conv2d_dgrad_ep(dza, blk.c2a.wt, "valid", out, z, op.scale, op.mean, op.rstd, op.dgamma, op.dbeta, op.db, act,
+                                  res=acc, dy_out=dy_below)
+        return None if got is None else (got, dy_below)
 
     # =========================================================================================
     #  optimiser (MaskRCNN.compile, model.py:2255-2291)

@@ -71,14 +71,16 @@ def conv2d(x, w, bias=None, scale=None, shift=None, res=None, stride=1, padding=
 ERR_UNSUPPORTED = -4
 
 
-def conv2d_dgrad_ep(dz, w_t, padding, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, act, res=None, out=None):
+def conv2d_dgrad_ep(dz, w_t, padding, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, act, res=None, out=None,
+                    dy_out=None):
     """Data-gradient convolution (stride 1) fused with the epilogue backward of the layer below; returns dz_below, or
     None when the layer is too small for the fused kernel (the caller then uses conv2d + epilogue_bwd)."""
-    _need_cuda(dz, w_t, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, res, out)
+    _need_cuda(dz, w_t, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, res, out, dy_out)
     d = conv_desc(tuple(dz.shape), tuple(w_t.shape), 1, padding, ACT_NONE, RES_SAME if res is not None else RES_NONE)
     ep = _hip.BwdEpilogue()
     ep.out, ep.z, ep.scale, ep.mean, ep.rstd = ptr(below_out), ptr(below_z), ptr(scale), ptr(mean), ptr(rstd)
     ep.dgamma, ep.dbeta, ep.dbias, ep.act = ptr(dgamma), ptr(dbeta), ptr(dbias), act
+    ep.dy = ptr(dy_out)                                # optional: y * act' (gradient a residual branch below receives)
     if out is None:
         out = empty((d.N, d.OH, d.OW, d.Cout), torch.float32, dz.device)
     nbytes = _hip.lib().mrcnn_conv2d_fwd_workspace(C.byref(d))

@@ -126,6 +126,9 @@ typedef struct mrcnn_bwd_epilogue {
     const float* out; const float* z; const float* scale; const float* mean; const float* rstd;
     float* dgamma; float* dbeta; float* dbias;
     int32_t act;                 /* MRCNN_ACT_NONE or MRCNN_ACT_RELU of the layer below */
+    float* dy;                   /* optional second output y*act' (what a residual branch of the layer below receives: the
+                                    block-output gradient of a bottleneck block); split-K layers only, else
+                                    MRCNN_ERR_UNSUPPORTED */
 } mrcnn_bwd_epilogue;
 int mrcnn_conv2d_dgrad_ep(const mrcnn_conv_desc* d, const float* dz, const float* w_t, const float* res,
                           float* dz_below, const mrcnn_bwd_epilogue* ep, void* workspace, size_t workspace_bytes,
