@@ -320,7 +320,7 @@ template <typename T, int CP>
 __global__ void mask_out_bwd_h16_kernel(const float* __restrict__ dmask, const float* __restrict__ mask, const T* __restrict__ up,
                                         const float* __restrict__ wm, T* dzg, float* dWm, float* dbm, float* dbd, long long npix,
                                         int H, int W, int Cd, int C, float lscale) {
-    constexpr int PPB = 128;
+    constexpr int PPB = 512;                    // 128 made the per-workgroup atomics (Cd*C + Cd + C of them) the bottleneck
     __shared__ __attribute__((aligned(16))) float sdz[PPB * CP];
     const int ci = threadIdx.x;
     const long long p0 = (long long)blockIdx.x * PPB;
@@ -822,7 +822,7 @@ extern "C" int mrcnn_mask_out_fwd_h16(int dtype, const void* up, const float* w_
 template <typename T>
 static void launch_mask_out_bwd_h16(const float* dm, const float* m, const void* up, const float* wm, void* dzg, float* dw, float* dbm,
                                     float* dbd, long long npix, int H, int W, int Cd, int C, float ls, hipStream_t s) {
-    const dim3 grid((unsigned)cdiv64(npix, 128)), block(Cd);
+    const dim3 grid((unsigned)cdiv64(npix, 512)), block(Cd);
     if (C <= 4)
         hipLaunchKernelGGL((mask_out_bwd_h16_kernel<T, 4>), grid, block, 0, s, dm, m, (const T*)up, wm, (T*)dzg, dw, dbm, dbd, npix, H, W, Cd, C, ls);
     else if (C <= 8)

@@ -373,7 +373,7 @@ extern "C" int mrcnn_pixel_unshuffle2(const float* src, float* dst, int N, int H
 // instead of five passes (sigmoid epilogue, 1x1 wgrad, 1x1 dgrad, ReLU epilogue, pixel unshuffle).
 // One thread per deconv channel, a workgroup walks `ppb` consecutive pixels of the [M, H, W] output grid.
 #define MOB_MAXC 16
-#define MOB_PPB 128
+#define MOB_PPB 512
 template <int CP>      // CP = C rounded up to 4 / 8 / 16
 __global__ void mask_out_bwd_kernel(const float* __restrict__ dmask, const float* __restrict__ mask,
                                     const float* __restrict__ up, const float* __restrict__ wm, float* dzg, float* dWm,
