@@ -657,17 +657,23 @@ class MaskRCNNEngine(object):
             with torch.cuda.stream(aux):
                 aux.wait_event(ev)
                 self._class_head_bwd(d_logits, d_mbbox, ctx_cls, rois, dP, area)
-            self._mask_head_bwd(d_mmask, ctx_mask, rois_m, dP, area)
+                # the RPN backward needs nothing from the heads: it follows the class head on this stream, beside the
+                # (much longer) mask head.  Its data gradients add to dP with plain read-modify-writes, so the mask head's
+                # ROIAlign adjoint (atomics on the same maps, last thing on the main stream) waits for this event.
+                dP6 = self._rpn_bwd(d_rpn_logits, d_rpn_bbox, rpn_tape, dP)
+                ev_aux = torch.cuda.Event()
+                ev_aux.record(aux)
+            self._mask_head_bwd(d_mmask, ctx_mask, rois_m, dP, area, before_adjoint=ev_aux)
             main.wait_stream(aux)
-            d_logits.record_stream(aux)
-            d_mbbox.record_stream(aux)
+            for t in (d_logits, d_mbbox, d_rpn_logits, d_rpn_bbox):
+                t.record_stream(aux)
         else:
             self._mask_head_bwd(d_mmask, ctx_mask, rois_m, dP, area)
             self._class_head_bwd(d_logits, d_mbbox, ctx_cls, rois, dP, area)
+            dP6 = self._rpn_bwd(d_rpn_logits, d_rpn_bbox, rpn_tape, dP)
         if self.grad_ready:                      # ~2/3 of the gradient bytes (FC1 alone is 51 MB) are final here,
             self.join_wgrad()
-            self.grad_ready(*self.grad_ranges["heads"])     # with the whole RPN/FPN/backbone backward left to hide them
-        dP6 = self._rpn_bwd(d_rpn_logits, d_rpn_bbox, rpn_tape, dP)
+            self.grad_ready(*self.grad_ranges["heads"])     # with the whole FPN/backbone backward left to hide them
         self._trunk_bwd(dP, dP6, tape)
         if keep_outputs:
             self.last = {"rpn_class_logits": rpn_logits, "rpn_class": rpn_probs, "rpn_bbox": rpn_bbox,
@@ -677,7 +683,7 @@ class MaskRCNNEngine(object):
         return losses
 
     # ---- head backward --------------------------------------------------------------------------
-    def _mask_head_bwd(self, d_mmask, ctxs, rois, dP, area):
+    def _mask_head_bwd(self, d_mmask, ctxs, rois, dP, area, before_adjoint=None):
         """Backward of build_fpn_mask_graph on the rows the forward ran on: ``rois`` is [B, R, 4] with R = T
         (all train ROIs) or the positive quota (see forward_backward); d_mmask is always [B, T, ...]."""
         B, T, R = d_mmask.shape[0], d_mmask.shape[1], rois.shape[1]
@@ -687,9 +693,9 @@ class MaskRCNNEngine(object):
             row = int(np.prod(d_mmask.shape[2:])) * 4
             g = ops.empty((B, R) + tuple(d_mmask.shape[2:]), torch.float32, self.dev)
             ops.copy2d(g.data_ptr(), R * row, d_mmask.data_ptr(), T * row, R * row, B)
-        self._mask_head_bwd_rows(g.view((B * R,) + tuple(g.shape[2:])), ctxs, rois, dP, area)
+        self._mask_head_bwd_rows(g.view((B * R,) + tuple(g.shape[2:])), ctxs, rois, dP, area, before_adjoint)
 
-    def _mask_head_bwd_rows(self, g, ctxs, rois, dP, area):
+    def _mask_head_bwd_rows(self, g, ctxs, rois, dP, area, before_adjoint=None):
         cfg = self.cfg
         c1, c2, c3, c4, cdec, cm = ctxs
         mop, dc = self.op("mrcnn_mask"), self.op("mrcnn_mask_deconv")
@@ -749,6 +755,8 @@ class MaskRCNNEngine(object):
                                      ((kh - 1) // 2, (kw - 1) // 2), ACT_NONE)
             d = ops.cast_from_h16(d16, 1.0 / S)
         B, R = rois.shape[0], rois.shape[1]
+        if before_adjoint is not None:
+            torch.cuda.current_stream(self.dev).wait_event(before_adjoint)
         # scatter form here: the gather form measured 2 ms slower on the positive rows (14x14 samples of ~150 overlapping
         # positives: >1000 rows on the hottest pixels) and the dense head relies on the skipping of exactly-zero rows
         ops.roialign_bwd(rois, d.view(B, R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1), dP, cfg.MASK_POOL_SIZE, area)
