@@ -474,6 +474,36 @@ def test_graph_replay_with_multiworkgroup_topk_512(dev):
     assert np.abs(eager["rpn_rois"]).sum() > 0
 
 
+def test_training_step_with_an_image_without_ground_truth(dev):
+    """Edge case: one tile of the batch holds no object (all-zero GT rows; the reference's generator skips such images,
+    model.py:1786, but DetectionTargetLayer defines the result: with no GT box every proposal is a negative and the
+    negative quota is int(r * 0) - 0 = 0, so the image contributes no ROI at all).  The step must run, agree with the
+    oracle on all five losses and leave finite gradients."""
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _small_cfg("custom", 128)
+    w = _weights(cfg, 11)
+    model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+    inputs, keys = _train_inputs(cfg, 2, 5)
+    images, meta, rpn_match, rpn_bbox_t, gt_cls, gt_boxes, gt_masks = inputs
+    gt_cls[1] = 0; gt_boxes[1] = 0; gt_masks[1] = False
+    rpn_match[1] = 0
+    neg = np.random.RandomState(1).choice(rpn_match.shape[1], cfg.RPN_TRAIN_ANCHORS_PER_IMAGE, replace=False)
+    rpn_match[1, neg, 0] = -1                                  # negatives only, as build_rpn_targets gives without GT
+    rpn_bbox_t[1] = 0
+    losses = model.train_on_batch(inputs, rand_keys=keys, apply=False, keep_outputs=True)
+    torch.cuda.synchronize()
+    last = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in model.engine.last.items() if k != "pyramid"}
+    counts = np.asarray(last["counts"])
+    assert counts[0, 0] > 0 and counts[1].tolist() == [0, 0], counts
+    assert bool(torch.isfinite(model.engine.grads).all())
+    o = orc.OracleMaskRCNN(cfg, w)
+    forced = {k: last[k] for k in ("rois", "target_class_ids", "target_bbox", "target_mask")}
+    with torch.no_grad():
+        ref = o.forward_training(images, rpn_match, rpn_bbox_t.astype(np.float32), gt_cls, gt_boxes, gt_masks,
+                                 meta[:, 12:].astype(np.int32), orc.get_anchors(cfg, images.shape[1:]), keys, forced=forced)
+    np.testing.assert_allclose(losses.cpu().numpy(), np.array([float(l) for l in ref["losses"]]), rtol=2e-3, atol=1e-5)
+
+
 def test_overfit_one_batch_then_detect_it(dev):
     """End to end: 180 full steps (forward, backward, clipnorm, SGD-momentum; 120 at lr 0.002, 60 at 0.0004) on one
     synthetic batch drive the total loss down by > 10x, and the inference graph with the trained weights then finds the
