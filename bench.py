@@ -89,6 +89,7 @@ def cpu_baseline(cfg, weights, batch, cores):
 
 
 TRAFFIC_PER_LAUNCH = {1024: None, 2048: 1.810e9}   # mask-head conv, PMC passes: profiles/r01_pmc_conv_traffic.md
+TRAFFIC_WGRAD_PER_LAUNCH = {1024: None, 2048: 4.55e9}   # its weight gradient (same file)
 
 
 def measure(args, backbone, nimg, rank, local_rank, world, full):
@@ -254,7 +255,23 @@ def _roofline_leg(res, ops, torch, dev, nimg, cfg):
                        "traffic": TRAFFIC_PER_LAUNCH.get(M_rois),
                        "kernel": "conv_fwd_blds_kernel, 128x128 tile (mask-head 3x3 conv, M=%d N=256 K=2304, "
                                  "%.1f GFLOP/launch, %.3f ms/launch)" % (M_rois * 196, flops / 1e9, k_ms)}
-    del xm, om
+    # the second dominant kernel: the weight gradient of the same layer (5 launches per step), same accounting
+    dym = torch.randn((M_rois, 14, 14, 256), device=dev)
+    dwm = torch.empty((3, 3, 256, 256), device=dev)
+    for _ in range(3):
+        ops.conv2d_wgrad(xm, dym, (3, 3, 256, 256), 1, "same", dw=dwm)
+    e0.record()
+    for _ in range(reps):
+        ops.conv2d_wgrad(xm, dym, (3, 3, 256, 256), 1, "same", dw=dwm)
+    e1.record()
+    torch.cuda.synchronize()
+    w_ms = e0.elapsed_time(e1) / reps
+    w_ach = flops / (w_ms * 1e-3) / 1e12
+    res["roofline_wgrad"] = {"bound": "mfma", "achieved": round(w_ach, 2), "peak": peak, "unit": "TFLOP/s",
+                             "frac": round(w_ach / peak, 4), "traffic": TRAFFIC_WGRAD_PER_LAUNCH.get(M_rois),
+                             "kernel": "conv_wgrad_blds_kernel<16,true> + pixel table + slab reduction (same layer, "
+                                       "%.1f GFLOP/launch, %.3f ms/launch)" % (flops / 1e9, w_ms)}
+    del xm, om, dym
 
 
 def main():
@@ -319,6 +336,8 @@ def main():
             "losses_last_step": [round(v, 5) for v in r["losses"]],
             "roofline": r["roofline"],
         }
+        if "roofline_wgrad" in r:
+            out["roofline_wgrad"] = r["roofline_wgrad"]
         if second is not None:
             out["config1_resnet50_nimg2"] = {
                 "workload": "BASELINE.json configs[1]: resnet50+FPN %dx%d, nimg_per_gpu=2, 1 GPU train + detect" % (args.imgsize, args.imgsize),
