@@ -905,7 +905,8 @@ static ConvPlan plan_conv(const mrcnn_conv_desc* d, bool allow_dma_split = true)
     const int nk16 = d->KH * d->KW * d->Cin / 16;
     if (allow_dma_split && dma_min_tiles > 0 && pl.bm == 64 && Cout % 128 == 0 && d->Cin % 32 == 0 && d->KH * d->KW <= 64 &&
         t128 >= dma_min_tiles && t128 < CONV_BIG_TILE_MIN_BLOCKS && nk16 >= 32) {
-        long long ks = (1024 + t128 - 1) / t128;
+        static const long long dma_target = getenv("MRCNN_DMA_SPLIT_TARGET") ? atoll(getenv("MRCNN_DMA_SPLIT_TARGET")) : 768;
+        long long ks = (dma_target + t128 - 1) / t128;
         if (ks > nk16 / 16) ks = nk16 / 16;
         if (ks > 16) ks = 16;
         if (ks >= 2) {
