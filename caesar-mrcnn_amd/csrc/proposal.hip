@@ -338,6 +338,14 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(const PropArgs p) {
         unsigned long long alive = ~remc;
         if (valid_n < 64) alive &= (1ull << valid_n) - 1ull;
         unsigned long long kept = 0ull;
+        // No alive candidate of this chunk overlaps another alive one (the usual case away from object clusters): the
+        // greedy scan would keep them all, one find-first-set round per box -- take them at once.
+        const bool clean = __ballot(((alive >> lane) & 1ull) && (diag & alive) != 0ull) == 0ull;
+        if (clean && __popcll(alive) <= maxk - total) {
+            kept = alive;
+            total += __popcll(alive);
+            alive = 0ull;
+        }
         while (alive && total < maxk) {
             const int t = __ffsll((long long)alive) - 1;
             kept |= 1ull << t;
