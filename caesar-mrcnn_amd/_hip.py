@@ -139,6 +139,13 @@ def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
+            # not built yet (fresh checkout on a box with the toolchain): build once, in-tree; still no fallback
+            try:
+                from . import build as _build
+                _build.build(verbose=False)
+            except Exception:
+                pass
+        if not os.path.exists(LIB_PATH):
             raise HipPathError(
                 "libmrcnn_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
                 "g.build()'`; there is no CPU fallback for the hot path." % LIB_PATH)
