@@ -589,6 +589,8 @@ class MaskRCNNEngine(object):
                 ops.fill_zero(self.grads)
                 if not self.wt_valid:
                     self.refresh_wt()
+                if self.head_dtype is not None:
+                    self._ensure_h16()                 # 16-bit weight images of the mask head: first needed after the trunk
             prep_ev = torch.cuda.Event()
             prep_ev.record(self.wgrad_stream)
         else:
@@ -620,6 +622,8 @@ class MaskRCNNEngine(object):
             ops.copy2d(rois_m.data_ptr(), quota * 16, rois.data_ptr(), T * 16, quota * 16, B)
         else:
             rois_m = rois
+        if prep_ev is not None and self.head_dtype is not None:
+            main.wait_event(prep_ev)                    # the mask head reads the 16-bit weight images prepared on the side stream
         if aux is not None:
             ev = torch.cuda.Event()
             ev.record(main)
