@@ -102,6 +102,7 @@ _SIGNATURES = {
     "mrcnn_roialign_bwd": (C.c_int, [C.POINTER(RoiAlignDesc)] + [_P] * 7),
     "mrcnn_roialign_bwd_gather": (C.c_int, [C.POINTER(RoiAlignDesc)] + [_P] * 7),
     "mrcnn_proposal_workspace": (C.c_size_t, [C.POINTER(ProposalDesc)]),
+    "mrcnn_proposal_status_offset": (C.c_size_t, [C.POINTER(ProposalDesc), _P, C.POINTER(C.c_size_t)]),
     "mrcnn_proposal_fwd": (C.c_int, [C.POINTER(ProposalDesc)] + [_P] * 8 + [C.c_size_t, _P]),
     "mrcnn_detection_targets": (C.c_int, [C.POINTER(DetTargetDesc)] + [_P] * 12),
     "mrcnn_conv2d_fwd_h16": (C.c_int, [C.POINTER(ConvDesc), C.c_int] + [_P] * 8),

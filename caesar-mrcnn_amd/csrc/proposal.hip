@@ -49,7 +49,8 @@ struct PropArgs {
 #define PRE_TIE (2 * PRE_BINS + 256)               // word offsets inside pre_ws
 #define PRE_COUNTER (PRE_TIE + PRE_MAXG)
 #define PRE_NCAND (PRE_COUNTER + 1)
-#define PRE_WORDS (PRE_NCAND + 1)
+#define PRE_ERR (PRE_NCAND + 1)                     // stores refused by a bounds guard (0 on a healthy run; host-readable)
+#define PRE_WORDS (PRE_ERR + 1)
 
 // bin d of hist[0..nbins) with count(bins > d) < need <= count(bins >= d); *left = need - count(bins > d)
 __device__ int pre_find_bin(const unsigned* __restrict__ hist, int nbins, unsigned need, unsigned* left, unsigned* s_part, int* s_res) {
@@ -163,8 +164,14 @@ __global__ __launch_bounds__(PRE_THREADS) void topk_collect_kernel(const PropArg
         __syncthreads();
         unsigned before = base, tot = 0;
         for (int w = 0; w < PRE_THREADS / 64; ++w) { if (w < (tid >> 6)) before += s_wsum[w]; tot += s_wsum[w]; }
-        if (gt || (eq && before + wrank < need_eq))
-            cand[atomicAdd(&pre[PRE_COUNTER], 1u)] = ((unsigned long long)(~u) << 32) | (unsigned)a;
+        if (gt || (eq && before + wrank < need_eq)) {
+            // the slot comes from a counter in global memory: never trust it as an index.  A counter that did not start
+            // at zero (or inconsistent histograms) would otherwise walk off the candidate array; the refused store is
+            // counted, and select_sort_decode_kernel sees PRE_COUNTER != K and runs its own selection instead.
+            const unsigned slot = atomicAdd(&pre[PRE_COUNTER], 1u);
+            if (slot < (unsigned)SORT_CAP) cand[slot] = ((unsigned long long)(~u) << 32) | (unsigned)a;
+            else atomicAdd(&pre[PRE_ERR], 1u);
+        }
         base += tot;
         __syncthreads();
     }
@@ -178,8 +185,11 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
     const float* sc = p.probs + (int64_t)b * p.A * 2 + 1;     // foreground probability, stride 2
     const int A = p.A, K = p.K;
 
-    const unsigned ncand = p.pre_groups ? p.pre_ws[(int64_t)b * PRE_WORDS + PRE_NCAND] : ~0u;
-    const bool preselected = ncand <= SORT_CAP;     // workgroup-uniform: the pre-selection's candidates only need sorting
+    // the pre-selection must have delivered exactly the K keys it announced; anything else (counter not reset, refused
+    // stores) is discarded and this workgroup selects for itself -- slower, never wrong and never out of bounds
+    const unsigned* pre = p.pre_ws + (int64_t)b * PRE_WORDS;
+    const unsigned ncand = p.pre_groups ? pre[PRE_NCAND] : ~0u;
+    const bool preselected = p.pre_groups && ncand == (unsigned)K && pre[PRE_COUNTER] == (unsigned)K;   // workgroup-uniform
 
     // ---- radix select: largest K keys ------------------------------------------------------------
     if (tid == 0) { s_prefix = 0; s_need = (unsigned)K; }
@@ -233,8 +243,8 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
             eq = u == T;
         }
         if (gt || (eq && !ordered)) {
-            unsigned slot = atomicAdd(&s_count, 1u);
-            keys[slot] = ((unsigned long long)(~u) << 32) | (unsigned)a;
+            unsigned slot = atomicAdd(&s_count, 1u);          // < K by construction of the radix select; guarded all the same
+            if (slot < (unsigned)SORT_CAP) keys[slot] = ((unsigned long long)(~u) << 32) | (unsigned)a;
         }
         if (ordered) {
             // block-wide exclusive rank of `eq` in index order
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
             for (int w = 0; w < (tid >> 6); ++w) before += s_wsum[w];
             if (eq && before + wrank < need_eq) {
                 unsigned slot = atomicAdd(&s_count, 1u);
-                keys[slot] = ((unsigned long long)(~u) << 32) | (unsigned)a;
+                if (slot < (unsigned)SORT_CAP) keys[slot] = ((unsigned long long)(~u) << 32) | (unsigned)a;
             }
             __syncthreads();
             if (tid == 0) {
@@ -403,6 +413,19 @@ extern "C" size_t mrcnn_proposal_workspace(const mrcnn_proposal_desc* d) {
                            PRE_WORDS * sizeof(unsigned)) + 512;
 }
 
+// Where the selection's health words live, for a host that has synchronised anyway (tests, debugging): byte offset from
+// `workspace` of image 0's {collected, announced, refused} uint32 triple, *stride_bytes between images.  Healthy run:
+// collected == announced == K (or both 0 when A < 32 768: no multi-workgroup selection), refused == 0.
+extern "C" size_t mrcnn_proposal_status_offset(const mrcnn_proposal_desc* d, const void* workspace, size_t* stride_bytes) {
+    if (!d || !workspace) return 0;
+    const size_t K = (size_t)prop_k(d), nw = (K + 63) / 64;
+    const uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 255) & ~(uintptr_t)255;
+    const uintptr_t pre = base + (size_t)d->B * (K * 4 * sizeof(float) + K * nw * sizeof(unsigned long long) +
+                                                 SORT_CAP * sizeof(unsigned long long));
+    if (stride_bytes) *stride_bytes = PRE_WORDS * sizeof(unsigned);
+    return (size_t)(pre - reinterpret_cast<uintptr_t>(workspace)) + PRE_COUNTER * sizeof(unsigned);
+}
+
 extern "C" int mrcnn_proposal_fwd(const mrcnn_proposal_desc* d, const float* rpn_probs, const float* rpn_bbox,
                                   const float* anchors, float* rois, int32_t* top_idx, int32_t* keep_idx,
                                   int32_t* num_keep, void* workspace, size_t workspace_bytes, void* stream) {
@@ -428,7 +451,12 @@ extern "C" int mrcnn_proposal_fwd(const mrcnn_proposal_desc* d, const float* rpn
         const int chunk = (d->A + a.pre_groups - 1) / a.pre_groups;
         const dim3 grid(a.pre_groups, d->B);
         const int nz = d->B * PRE_WORDS;            // a kernel, not a memset node: the call may be inside a graph capture
-        hipLaunchKernelGGL(topk_zero_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, s, a.pre_ws, nz);
+        // MRCNN_PROPOSAL_SKIP_ZERO=1 (tests only) leaves the previous call's counters in place: the fault-injection
+        // twin of "the reset did not happen", which the guards above must survive with the exact result
+        const char* sz = getenv("MRCNN_PROPOSAL_SKIP_ZERO");      // read per call: the test flips it between two calls
+        const bool skip_zero = sz && sz[0] == '1';
+        if (!skip_zero)
+            hipLaunchKernelGGL(topk_zero_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, s, a.pre_ws, nz);
         for (int pass = 0; pass < 3; ++pass) hipLaunchKernelGGL(topk_hist_kernel, grid, dim3(PRE_THREADS), 0, s, a, pass);
         hipLaunchKernelGGL(topk_ties_kernel, grid, dim3(PRE_THREADS), 0, s, a, chunk);
         hipLaunchKernelGGL(topk_collect_kernel, grid, dim3(PRE_THREADS), 0, s, a, chunk);

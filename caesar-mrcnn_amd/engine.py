@@ -190,6 +190,7 @@ class MaskRCNNEngine(object):
         self.head_dtype = None
         self.loss_scale = 4096.0
         self._h16 = {}
+        self._h16_store = {}            # dtype -> {layer: (W^T image, data-gradient image)}, stable addresses
         self._h16_valid = False
         self.fused_mask_out_bwd = True  # single-pass backward of the mask-head output stage
         self.fused_dgrad_epilogue = True  # data-gradient convs of the mask head apply the lower layer's epilogue backward
@@ -257,12 +258,13 @@ class MaskRCNNEngine(object):
         """16-bit operand images (W^T and the rotated data-gradient image) of the mask-head convolutions."""
         if self._h16_valid and self._h16.get("dtype") == self.head_dtype:
             return
-        self._h16 = {"dtype": self.head_dtype}
-        for i in range(1, 5):
-            op = self.op("mrcnn_mask_conv%d" % i)
-            self._h16[op.name] = ops.weights_to_h16(op.w, self.head_dtype)
-        dc = self.op("mrcnn_mask_deconv")              # GEMM matrix [Cin, 4*Cd]: forward W^T and the data-gradient image
-        self._h16[dc.name] = ops.weights_to_h16(dc.w, self.head_dtype)
+        # one set of images per dtype, allocated once and refreshed IN PLACE: captured HIP graphs (infer_graphed) hold
+        # their addresses, so a weight update must never move them
+        imgs = self._h16_store.setdefault(self.head_dtype, {})
+        names = ["mrcnn_mask_conv%d" % i for i in range(1, 5)] + ["mrcnn_mask_deconv"]   # deconv: GEMM matrix [Cin, 4*Cd]
+        for name in names:
+            imgs[name] = ops.weights_to_h16(self.op(name).w, self.head_dtype, out=imgs.get(name))
+        self._h16 = dict(imgs, dtype=self.head_dtype)
         self._h16_valid = True
 
     # ---- independent small convolutions in one launch (mrcnn_conv2d_fwd_multi) ------------------------
@@ -526,8 +528,10 @@ class MaskRCNNEngine(object):
         """infer() replayed from a HIP graph (one capture per input shape): the ~450 launches of a
         batch-1 detect pass are host-bound when issued one by one.  `images` / `windows_norm` may be host
         or device tensors; they are copied into the graph's static input buffers."""
-        key = (tuple(images.shape), tuple(windows_norm.shape), id(self.cfg))
+        key = (tuple(images.shape), tuple(windows_norm.shape), id(self.cfg), self.head_dtype)
         entry = self._infer_graphs.get(key)
+        if self.head_dtype is not None:
+            self._ensure_h16()      # outside the graph: the 16-bit weight images follow set_weights / apply_gradients in place
         if entry is None:
             sx = ops.empty(tuple(images.shape), torch.float32, self.dev)
             sw = ops.empty(tuple(windows_norm.shape), torch.float32, self.dev)

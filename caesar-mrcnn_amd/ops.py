@@ -454,6 +454,23 @@ def proposals(rpn_probs, rpn_bbox, anchors, pre_nms_limit, proposal_count, nms_t
     return rois
 
 
+def proposal_status(rpn_probs, pre_nms_limit, proposal_count):
+    """Health words of the last proposals() call of this shape on the current stream (synchronises):
+    int32 [B, 3] = keys collected, keys announced, stores refused by the bounds guard of the multi-workgroup
+    selection (mrcnn_proposal_status_offset)."""
+    B, A = rpn_probs.shape[0], rpn_probs.shape[1]
+    d = _hip.ProposalDesc()
+    d.B, d.A, d.pre_nms_limit, d.proposal_count = B, A, pre_nms_limit, proposal_count
+    ws = workspace(_hip.lib().mrcnn_proposal_workspace(C.byref(d)), rpn_probs.device, "proposal")
+    stride = C.c_size_t(0)
+    off = _hip.lib().mrcnn_proposal_status_offset(C.byref(d), ptr(ws), C.byref(stride))
+    torch.cuda.synchronize()
+    words = ws.cpu().numpy()
+    import numpy as np
+    return np.stack([np.frombuffer(words[off + b * stride.value: off + b * stride.value + 12].tobytes(), np.uint32)
+                     for b in range(B)]).astype(np.int64)
+
+
 def detection_targets(proposals_, gt_class_ids, gt_boxes, gt_masks, rand_keys, train_rois, positive_ratio,
                       bbox_std_dev, mask_shape, use_mini_mask=False):
     _need_cuda(proposals_, gt_class_ids, gt_boxes, gt_masks, rand_keys)
@@ -605,12 +622,17 @@ def mask_out_bwd(d_mask, mask, up, w_mask, dw_mask, db_mask, db_deconv):
 _H16 = {torch.float16: 0, torch.bfloat16: 1}
 
 
-def weights_to_h16(w, dtype=torch.float16, want_dgrad=True):
-    """float32 HWIO kernel -> (W^T [Cout, KH*KW*Cin], data-gradient image [Cin, KH*KW*Cout]) in `dtype`."""
+def weights_to_h16(w, dtype=torch.float16, want_dgrad=True, out=None):
+    """float32 HWIO kernel -> (W^T [Cout, KH*KW*Cin], data-gradient image [Cin, KH*KW*Cout]) in `dtype`.
+    `out` = a pair returned by an earlier call: refreshed in place (addresses captured in HIP graphs stay valid)."""
     _need_cuda(w)
     KH, KW, Cin, Cout = w.shape
-    wf = torch.empty((Cout, KH * KW * Cin), dtype=dtype, device=w.device)
-    wd = torch.empty((Cin, KH * KW * Cout), dtype=dtype, device=w.device) if want_dgrad else None
+    if out is not None:
+        wf, wd = out
+        assert wf.dtype == dtype and tuple(wf.shape) == (Cout, KH * KW * Cin)
+    else:
+        wf = torch.empty((Cout, KH * KW * Cin), dtype=dtype, device=w.device)
+        wd = torch.empty((Cin, KH * KW * Cout), dtype=dtype, device=w.device) if want_dgrad else None
     check(_hip.lib().mrcnn_weights_to_h16(ptr(w), ptr(wf), ptr(wd), KH, KW, Cin, Cout, _H16[dtype], current_stream()),
           "mrcnn_weights_to_h16")
     return wf, wd

@@ -226,6 +226,12 @@ int mrcnn_proposal_fwd(const mrcnn_proposal_desc* d, const float* rpn_probs, con
                        const float* anchors, float* rois, int32_t* top_idx, int32_t* keep_idx,
                        int32_t* num_keep, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Health words of the multi-workgroup top-k selection (A >= 32 768), for a host that has synchronised anyway: returns
+ * the byte offset from `workspace` of image 0's three uint32 {keys collected, keys announced, stores refused by the
+ * bounds guard}; *stride_bytes = distance between images.  A healthy call leaves collected == announced == K and
+ * refused == 0; anything else makes the sort kernel discard the pre-selection and select by itself (same result).  */
+size_t mrcnn_proposal_status_offset(const mrcnn_proposal_desc* d, const void* workspace, size_t* stride_bytes);
+
 /* DetectionTargetLayer (mrcnn/model.py:570-763) for one batch.  rand_keys [B, R] uniform floats
  * replace tf.random.shuffle: candidates are taken in increasing key order (ties -> lower index).
  * gt_masks is the reference layout [B, MH, MW, G] (uint8 0/1).  Outputs are zero padded to T.       */

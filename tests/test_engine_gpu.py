@@ -168,7 +168,7 @@ def test_training_step_staged(dev, backbone, size, dice):
         np.testing.assert_array_equal(last["rois"][b], r_rois)
         np.testing.assert_array_equal(last["target_class_ids"][b], r_cls)
         np.testing.assert_allclose(last["target_bbox"][b], r_bb, rtol=1e-5, atol=1e-5)
-        assert np.mean(last["target_mask"][b] != r_m) < 1e-3
+        np.testing.assert_array_equal(last["target_mask"][b], r_m)       # byte work: exact (see test_detection_targets)
         npos += P
     assert npos > 0, "scene produced no positive ROIs; the mask/bbox losses would be untested"
     # (b) differentiable part on identical ROIs / targets
@@ -341,6 +341,85 @@ def test_cfg2_full_size_training_step_r50_256(dev):
         if err > 5e-3:
             bad.append((name, err, scale))
     assert not bad, bad[:8]
+
+
+def test_cfg3_r101_256_nimg4_training_step(dev):
+    """BASELINE configs[2], the per-rank workload of the 8-GPU data-parallel job (and bench.py's headline workload):
+    ResNet-101+FPN 256x256, nimg_per_gpu = 4, 512 train ROIs, 2000 proposals.  Losses and every parameter gradient
+    against the oracle's autograd (mrcnn/model.py:1935-2166, :2255-2291), with the mask head run densely (all 2048
+    ROI rows, the headline leg) and on the positive quota only (product default): one oracle pass serves both,
+    because the sampled ROIs / targets are fed to it ("forced") and are identical in the two modes."""
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _full_cfg("resnet101", 256, nimg=4)
+    B = 4
+    w = _weights(cfg, 53)
+    inputs, keys = _train_inputs(cfg, B, 57)
+    images, meta, rpn_match, rpn_bbox_t, gt_cls, gt_boxes, gt_masks = inputs
+    runs = {}
+    for mode in ("dense", "sparse"):
+        model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+        eng = model.engine
+        eng.sparse_mask_bwd = mode == "sparse"
+        losses = model.train_on_batch(inputs, rand_keys=keys, apply=False, keep_outputs=True)
+        torch.cuda.synchronize()
+        last = {k: v.cpu().numpy() for k, v in eng.last.items() if torch.is_tensor(v)}
+        eng.apply_gradients(0.0, 0.0, world_size=1)          # lr 0: adds the L2 term, leaves the clipped gradient in place
+        torch.cuda.synchronize()
+        runs[mode] = (losses.cpu().numpy(), eng.get_weights(grads=True), last)
+        del model, eng
+        torch.cuda.empty_cache()
+    last = runs["dense"][2]
+    assert int(last["counts"][:, 0].sum()) > 0
+    for k in ("rois", "target_class_ids", "target_bbox", "target_mask"):
+        np.testing.assert_array_equal(runs["sparse"][2][k], last[k])
+    o = orc.OracleMaskRCNN(cfg, w, requires_grad=True)
+    forced = {k: last[k] for k in ("rois", "target_class_ids", "target_bbox", "target_mask")}
+    ref = o.forward_training(images, rpn_match, rpn_bbox_t.astype(np.float32), gt_cls, gt_boxes, gt_masks,
+                             meta[:, 12:].astype(np.int32), orc.get_anchors(cfg, images.shape[1:]), keys, forced=forced)
+    o.total_loss(ref["losses"]).backward()
+    want = [float(l.detach()) for l in ref["losses"]]
+    for mode, (losses, g, _) in runs.items():
+        np.testing.assert_allclose(losses, want, rtol=2e-3, atol=1e-5, err_msg=mode)
+        bad = []
+        for name in o.w:
+            if name not in g or o.w[name].grad is None:
+                continue
+            rg = o.w[name].grad.numpy()
+            scale = max(float(np.abs(rg).max()), 1e-8)
+            err = float(np.abs(g[name] - rg).max()) / scale
+            if err > 5e-3:
+                bad.append((name, err, scale))
+        assert not bad, (mode, bad[:8])
+
+
+def test_cfg4_graph_replay_equals_eager_1024(dev):
+    """configs[3] shape through the HIP graph: ResNet-101, 1024x1024 (A = 261 888 -> multi-workgroup top-k), captured
+    once and replayed; every replay must return exactly the eager result, and the top-k health words must show a clean
+    selection (collected == announced == 6000, nothing refused).  This is the replay that ended in a memory fault in
+    round 1: run once, not in a loop."""
+    from caesar_mrcnn_amd import ops
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _full_cfg("resnet101", 1024, mode="inference", nimg=1)
+    model = MaskRCNN("inference", cfg, "/tmp/mrcnn_logs", device=dev, seed=7)
+    rng = np.random.default_rng(11)
+    x = torch.tensor(rng.uniform(0, 255, (1, 1024, 1024, 3)).astype(np.float32), device=dev)
+    win = torch.tensor([[0., 0., 1., 1.]], device=dev)
+    keys = ("rpn_rois", "detections", "mrcnn_mask", "mrcnn_class")
+    out = model.engine.infer(x, win)
+    eager = {k: out[k].cpu().numpy().copy() for k in keys}
+    assert np.abs(eager["rpn_rois"]).sum() > 0
+    st = ops.proposal_status(out["rpn_class"], cfg.PRE_NMS_LIMIT, cfg.POST_NMS_ROIS_INFERENCE)
+    assert st.tolist() == [[6000, 6000, 0]], st
+    for rep in range(3):
+        out = model.engine.infer_graphed(x, win)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert np.array_equal(out[k].cpu().numpy(), eager[k]), (k, rep)
+    # a second input through the same graph (static input buffers are refilled, nothing else changes)
+    x2 = torch.tensor(rng.uniform(0, 255, (1, 1024, 1024, 3)).astype(np.float32), device=dev)
+    e2 = model.engine.infer(x2, win)["detections"].cpu().numpy().copy()
+    g2 = model.engine.infer_graphed(x2, win)["detections"].cpu().numpy()
+    assert np.array_equal(e2, g2)
 
 
 def test_cfg4_r101_1024_tile_inference_staged(dev):

@@ -190,3 +190,36 @@ def test_deconv_and_mask_output_stage_h16(dev, dtype):
     assert err <= TOL[dtype], err
     for a, r in ((dw, ref_dw), (dbm, ref_dbm), (dbd, ref_dbd)):
         torch.testing.assert_close(a, r, rtol=1e-4, atol=1e-4 * float(r.abs().max()))
+
+
+def test_graph_replay_follows_weight_updates_h16(dev):
+    """HIP-graph inference with the 16-bit mask head: a replay after set_weights (or a training step) must use the new
+    weights.  The 16-bit weight images are refreshed in place outside the graph, so their captured addresses stay
+    valid; the precision switch is part of the graph key (replaying a float32 capture with head_dtype set, or the
+    reverse, would silently run the wrong precision)."""
+    import test_engine_gpu as T
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = T._small_cfg("custom", 128, mode="inference")
+    w1, w2 = T._weights(cfg, 3), T._weights(cfg, 4)
+    model = MaskRCNN("inference", cfg, "/tmp/mrcnn_logs", device=dev, weights=w1)
+    eng = model.engine
+    eng.head_dtype = torch.float16
+    rng = np.random.default_rng(2)
+    x = torch.tensor(rng.uniform(0, 255, (1, 128, 128, 3)).astype(np.float32), device=dev)
+    win = torch.tensor([[0., 0., 1., 1.]], device=dev)
+    keys = ("detections", "mrcnn_mask")
+    e1 = {k: eng.infer(x, win)[k].cpu().numpy().copy() for k in keys}
+    g1 = {k: v.cpu().numpy().copy() for k, v in eng.infer_graphed(x, win).items() if k in keys}
+    for k in keys:
+        assert np.array_equal(e1[k], g1[k]), k
+    eng.set_weights(w2)                                      # invalidates the 16-bit images
+    e2 = {k: eng.infer(x, win)[k].cpu().numpy().copy() for k in keys}
+    eng.set_weights(w2)                                      # again, so that the replay itself has to refresh them
+    g2 = {k: v.cpu().numpy().copy() for k, v in eng.infer_graphed(x, win).items() if k in keys}
+    assert not np.array_equal(e1["mrcnn_mask"], e2["mrcnn_mask"])
+    for k in keys:
+        assert np.array_equal(e2[k], g2[k]), k
+    eng.head_dtype = None                                    # float32 again: must not replay the 16-bit capture
+    e3 = eng.infer(x, win)["mrcnn_mask"].cpu().numpy().copy()
+    g3 = eng.infer_graphed(x, win)["mrcnn_mask"].cpu().numpy()
+    assert np.array_equal(e3, g3) and not np.array_equal(e3, e2["mrcnn_mask"])
