@@ -261,3 +261,49 @@ def compute_recall(pred_boxes, gt_boxes, iou):
     iou_max, iou_arg = np.max(ov, axis=1), np.argmax(ov, axis=1)
     positive_ids = np.where(iou_max >= iou)[0]
     return len(set(iou_arg[positive_ids])) / gt_boxes.shape[0], positive_ids
+
+
+def compute_matches(gt_boxes, gt_class_ids, gt_masks, pred_boxes, pred_class_ids, pred_scores, pred_masks,
+                    iou_threshold=0.5, score_threshold=0.0):
+    """Greedy one-to-one matching of predictions (best score first) to ground truth by MASK IoU
+    (mrcnn/utils.py:725-785).  A prediction takes the unmatched GT instance of highest IoU -- candidates are walked
+    in descending IoU, the walk ends at the first IoU below the threshold -- provided the class ids agree; a class
+    mismatch ends that prediction's search.  Returns (gt_match [G], pred_match [N] as float arrays of indices or -1
+    in score order, overlaps [N, G])."""
+    keep_g = np.any(gt_boxes != 0, axis=1)
+    n_gt = int(keep_g.sum())
+    gt_masks = gt_masks[..., :n_gt]
+    n_pred = int(np.any(pred_boxes != 0, axis=1).sum())
+    order = np.argsort(pred_scores[:n_pred])[::-1]
+    pred_class_ids = pred_class_ids[order]
+    overlaps = compute_overlaps_masks(pred_masks[..., order], gt_masks)
+    gt_match = np.full(n_gt, -1.0)
+    pred_match = np.full(n_pred, -1.0)
+    for i in range(n_pred):
+        ranked = np.argsort(overlaps[i])[::-1]
+        below = np.flatnonzero(overlaps[i, ranked] < score_threshold)
+        if below.size:
+            ranked = ranked[:below[0]]
+        for j in ranked:
+            if gt_match[j] >= 0:
+                continue
+            if overlaps[i, j] < iou_threshold:
+                break
+            if pred_class_ids[i] == gt_class_ids[j]:
+                gt_match[j], pred_match[i] = i, j
+                break
+    return gt_match, pred_match, overlaps
+
+
+def compute_ap(gt_boxes, gt_class_ids, gt_masks, pred_boxes, pred_class_ids, pred_scores, pred_masks, iou_threshold=0.5):
+    """VOC-style average precision at one IoU threshold (mrcnn/utils.py:788-828): precision / recall after every
+    prediction in score order, precision made non-increasing from the right, area under the stepped curve."""
+    gt_match, pred_match, overlaps = compute_matches(gt_boxes, gt_class_ids, gt_masks, pred_boxes, pred_class_ids,
+                                                     pred_scores, pred_masks, iou_threshold)
+    hits = np.cumsum(pred_match > -1)
+    precisions = np.concatenate([[0], hits / (np.arange(len(pred_match)) + 1), [0]])
+    recalls = np.concatenate([[0], hits.astype(np.float32) / len(gt_match), [1]])
+    precisions = np.maximum.accumulate(precisions[::-1])[::-1]
+    steps = np.flatnonzero(recalls[:-1] != recalls[1:]) + 1
+    mAP = np.sum((recalls[steps] - recalls[steps - 1]) * precisions[steps])
+    return mAP, precisions, recalls, overlaps

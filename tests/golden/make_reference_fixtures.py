@@ -177,6 +177,71 @@ def main():
     # tile grids (pure Python in the reference)
     out["tiles_a"] = np.array(U.generate_tiles(0, 999, 0, 799, 256, 256, 0.5, 1.0))
     out["tiles_b"] = np.array(U.generate_tiles(10, 521, 5, 300, 128, 100, 1.0, 0.75))
+    # ---- round 2 additions ---------------------------------------------------------------------------------
+    import hashlib
+    # 1024x1024 anchors (configs[3]): too large to store -- SHA-256 of the float64 bytes + head / tail / sums
+    shapes = M.compute_backbone_shapes(cfg, (1024, 1024, 3))
+    a = U.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS, shapes, cfg.BACKBONE_STRIDES,
+                                   cfg.RPN_ANCHOR_STRIDE)
+    out["backbone_shapes_1024"] = shapes
+    out["anchors_px_1024_head"], out["anchors_px_1024_tail"] = a[:64], a[-64:]
+    out["anchors_px_1024_sum"] = np.array([a.shape[0], a.sum(), np.abs(a).sum()])
+    out["anchors_px_1024_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+    an = U.norm_boxes(a, (1024, 1024))
+    out["anchors_norm_1024_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(an).tobytes()).digest(), np.uint8)
+    # NMS with pairs whose IoU equals the threshold exactly (0.5 and 0.25 are exact in float32): "iou > threshold"
+    # keeps both boxes at equality, suppresses just above it
+    eb = np.array([[0, 0, 10, 10], [0, 0, 10, 5],            # IoU 50/100 = 0.5
+                   [20, 20, 30, 30], [20, 20, 25, 25],       # IoU 25/100 = 0.25
+                   [40, 40, 50, 50], [40, 40, 50, 46],       # IoU 0.6
+                   [60, 60, 70, 70], [60, 60, 70, 70]], np.float32)   # duplicate
+    es = np.array([0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.3, 0.2], np.float32)
+    out["nms_eq_boxes"], out["nms_eq_scores"] = eb, es
+    for thr, tag in ((0.5, "50"), (0.25, "25"), (0.6, "60")):
+        out["nms_eq_keep_" + tag] = U.non_max_suppression(eb, es, thr)
+    # evaluation: compute_matches / compute_ap (mask IoU matching, VOC-style AP)
+    H = 48
+    gtm = np.zeros((H, H, 6), bool)
+    gtb = np.zeros((6, 4), np.int32)
+    gtc = np.array([1, 2, 3, 1, 2, 0], np.int32)
+    for g in range(5):                                       # 6th GT row stays zero padding
+        y, x = rng.randint(0, H - 14, 2); h, w_ = rng.randint(5, 14, 2)
+        gtm[y:y + h, x:x + w_, g] = True
+        gtb[g] = [y, x, y + h, x + w_]
+    n_pred = 9
+    pm_ = np.zeros((H, H, n_pred), bool)
+    pb_ = np.zeros((n_pred, 4), np.int32)
+    pc_ = np.zeros(n_pred, np.int32)
+    for k in range(n_pred):
+        g = k % 5
+        dy, dx = rng.randint(-3, 4, 2)
+        y1, x1, y2, x2 = gtb[g]
+        y1, x1 = max(0, y1 + dy), max(0, x1 + dx)
+        y2, x2 = min(H, y2 + dy), min(H, x2 + dx)
+        pm_[y1:y2, x1:x2, k] = True
+        pb_[k] = [y1, x1, y2, x2]
+        pc_[k] = gtc[g] if k != 3 else (gtc[g] % 3) + 1     # one wrong class
+    ps_ = rng.uniform(0.05, 1, n_pred).astype(np.float32)
+    out["ev_gt_boxes"], out["ev_gt_ids"], out["ev_gt_masks"] = gtb, gtc, gtm
+    out["ev_pred_boxes"], out["ev_pred_ids"], out["ev_pred_scores"], out["ev_pred_masks"] = pb_, pc_, ps_, pm_
+    out["ev_overlaps_masks"] = U.compute_overlaps_masks(pm_, gtm[..., :5])
+    for thr, tag in ((0.5, "50"), (0.75, "75")):
+        gm, pmatch, ov = U.compute_matches(gtb, gtc, gtm, pb_, pc_, ps_, pm_, iou_threshold=thr)
+        out["ev_gt_match_" + tag], out["ev_pred_match_" + tag], out["ev_overlaps_" + tag] = gm, pmatch, ov
+        ap, prec, rec, _ = U.compute_ap(gtb, gtc, gtm, pb_, pc_, ps_, pm_, iou_threshold=thr)
+        out["ev_ap_" + tag], out["ev_precisions_" + tag], out["ev_recalls_" + tag] = np.array(ap), prec, rec
+    # mrcnn/graph.py: connected components in the reference's depth-first order
+    from mrcnn.graph import Graph
+    for tag, nv, ne in (("a", 12, 9), ("b", 30, 40), ("c", 7, 0)):
+        edges = np.array([rng.choice(nv, 2, replace=False) for _ in range(ne)], np.int64).reshape(ne, 2)
+        gph = Graph(nv)
+        for v, w_ in edges:
+            gph.addEdge(int(v), int(w_))
+        cc = gph.connectedComponents()
+        out["graph_%s_n" % tag] = np.array(nv)
+        out["graph_%s_edges" % tag] = edges
+        out["graph_%s_cc_flat" % tag] = np.array([v for c in cc for v in c], np.int64)
+        out["graph_%s_cc_len" % tag] = np.array([len(c) for c in cc], np.int64)
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "with", len(out), "arrays")
 

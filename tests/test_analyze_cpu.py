@@ -1,7 +1,8 @@
 """Host-side post-processing of detect results (scope row f3; mrcnn/analyze.py:1162-1496, 1866-2030).
-Pure CPU: a stub stands in for MaskRCNN.detect.  skimage / sklearn / networkx are absent here, so the
-restated third-party helpers are checked against their published semantics on hand-built cases
-(parity unpinned against the libraries themselves)."""
+Pure CPU: a stub stands in for MaskRCNN.detect.  skimage is absent here, so its restated helpers (contours, labelling)
+are checked against their published semantics on hand-built cases (parity unpinned against the library); the clique
+enumeration is pinned against networkx.find_cliques and the Jaccard index against sklearn.metrics.jaccard_score, both
+importable in this image (skipped where they are not)."""
 import json
 import os
 
@@ -146,3 +147,32 @@ def test_split_masks_and_no_detection(tmp_path):
     an = analyze.Analyzer(_StubModel(empty), cfg)
     assert an.predict(np.zeros((64, 64, 3), np.uint8), image_id="y") == 0 and an.masks_final == [] and an.results == {}
     assert not os.path.exists("out_y.json")
+
+
+def test_maximal_cliques_match_networkx():
+    """analyze.py:1332-1362 builds an nx.Graph with add_edge and takes list(nx.find_cliques(g)); the clique ORDER is
+    irrelevant downstream (cliques are re-sorted by their best score, analyze.py:1378), so sets of sets are compared."""
+    nx = pytest.importorskip("networkx")
+    rng = np.random.default_rng(5)
+    for n, p in ((6, 0.5), (12, 0.3), (25, 0.2), (40, 0.12), (9, 1.0)):
+        edges = [(i, j) for i in range(n) for j in range(i + 1, n) if rng.uniform() < p]
+        g = nx.Graph()
+        adj = {}
+        for v, w in edges:
+            g.add_edge(v, w)
+            adj.setdefault(v, set()).add(w)
+            adj.setdefault(w, set()).add(v)
+        ref = {frozenset(c) for c in nx.find_cliques(g)}
+        got = analyze.maximal_cliques(adj)
+        assert len(got) == len(ref) and {frozenset(c) for c in got} == ref
+
+
+def test_mask_iou_matches_sklearn_jaccard():
+    """analyze.py:29 imports sklearn.metrics.jaccard_score for mask overlaps (average='binary' on the flattened boolean masks, analyze.py:1271)."""
+    skm = pytest.importorskip("sklearn.metrics")
+    rng = np.random.default_rng(9)
+    for _ in range(5):
+        a = rng.uniform(size=(24, 24)) < 0.4
+        b = rng.uniform(size=(24, 24)) < 0.5
+        ref = skm.jaccard_score(a.ravel(), b.ravel())
+        assert abs(analyze.mask_iou(a, b) - ref) < 1e-12

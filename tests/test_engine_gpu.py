@@ -74,9 +74,17 @@ def _train_inputs(cfg, B, seed):
     return [images, meta, rpn_match, rpn_bbox, gt_cls, gt_boxes, gt_masks], keys
 
 
-def _weights(cfg, seed):
+def _weights(cfg, seed, damp=None):
+    """damp: factor on the BatchNorm gamma that closes every bottleneck branch.  ResNet-101 sums 33 residual branches;
+    with unit-scale random branches the activations grow ~2x in variance per block and the RPN saturates (all proposals
+    clip to the full tile, no positive ROI): 0.25 keeps the trunk's output in range so that every branch of the training
+    graph carries signal."""
     from caesar_mrcnn_amd.params import ParamLayout, init_weights, deconv_gemm_to_keras
     w = init_weights(ParamLayout(cfg), seed=seed, perturb_bn=True)
+    if damp is not None:
+        for k in w:
+            if k.endswith("_branch2c/gamma"):
+                w[k] = w[k] * np.float32(damp)
     w["mrcnn_mask_deconv/kernel"] = deconv_gemm_to_keras(w["mrcnn_mask_deconv/kernel"])   # Keras layout at the boundary
     # keep RPN box deltas small so proposals stay near their anchors and some reach IoU >= 0.5 with the GT
     w["rpn_bbox_pred/kernel"] = w["rpn_bbox_pred/kernel"] * np.float32(0.02)
@@ -352,7 +360,7 @@ def test_cfg3_r101_256_nimg4_training_step(dev):
     from caesar_mrcnn_amd.model import MaskRCNN
     cfg = _full_cfg("resnet101", 256, nimg=4)
     B = 4
-    w = _weights(cfg, 53)
+    w = _weights(cfg, 53, damp=0.25)
     inputs, keys = _train_inputs(cfg, B, 57)
     images, meta, rpn_match, rpn_bbox_t, gt_cls, gt_boxes, gt_masks = inputs
     runs = {}
@@ -369,7 +377,7 @@ def test_cfg3_r101_256_nimg4_training_step(dev):
         del model, eng
         torch.cuda.empty_cache()
     last = runs["dense"][2]
-    assert int(last["counts"][:, 0].sum()) > 0
+    assert (last["counts"][:, 0] > 0).all(), last["counts"]       # every image contributes positive ROIs
     for k in ("rois", "target_class_ids", "target_bbox", "target_mask"):
         np.testing.assert_array_equal(runs["sparse"][2][k], last[k])
     o = orc.OracleMaskRCNN(cfg, w, requires_grad=True)

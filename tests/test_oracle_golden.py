@@ -151,3 +151,68 @@ def test_bilinear_resize_restatement_properties():
     full = U.unmold_mask(m, (10, 20, 66, 76), (100, 100, 3))
     assert full.dtype == bool and full[:10].sum() == 0 and full[10:66, 20:76].sum() > 0
     assert U.resize(np.ones((4, 4), bool), (8, 8)).max() <= 1.0      # bool input is scaled like img_as_float
+
+
+# ---- round 2: the remaining reference-held pins ------------------------------------------------------
+@pytest.mark.parametrize("name,mod", _impls())
+def test_anchors_1024(name, mod):
+    """configs[3] (1024x1024, 261 888 anchors): SHA-256 of the reference's float64 array and of its normalised
+    float32 twin, plus head / tail rows and sums."""
+    import hashlib
+    cfg = _cfg()
+    shapes = (mod.compute_backbone_shapes(cfg.BACKBONE_STRIDES, (1024, 1024, 3)) if name == "oracle"
+              else mod.compute_backbone_shapes(cfg, (1024, 1024, 3)))
+    assert np.array_equal(shapes, G["backbone_shapes_1024"])
+    a = mod.generate_pyramid_anchors(cfg.RPN_ANCHOR_SCALES, cfg.RPN_ANCHOR_RATIOS, shapes, cfg.BACKBONE_STRIDES,
+                                     cfg.RPN_ANCHOR_STRIDE)
+    assert a.shape == (261888, 4) and a.dtype == np.float64
+    assert np.array_equal(a[:64], G["anchors_px_1024_head"]) and np.array_equal(a[-64:], G["anchors_px_1024_tail"])
+    assert np.array_equal(np.array([a.shape[0], a.sum(), np.abs(a).sum()]), G["anchors_px_1024_sum"])
+    sha = lambda x: np.frombuffer(hashlib.sha256(np.ascontiguousarray(x).tobytes()).digest(), np.uint8)
+    assert np.array_equal(sha(a), G["anchors_px_1024_sha256"])
+    assert np.array_equal(sha(mod.norm_boxes(a, (1024, 1024))), G["anchors_norm_1024_sha256"])
+    assert np.array_equal(sha(mod.get_anchors(cfg_1024(), (1024, 1024, 3))), G["anchors_norm_1024_sha256"])
+
+
+def cfg_1024():
+    from caesar_mrcnn_amd.config import run_py_config
+    return run_py_config(imgsize=1024)
+
+
+def test_nms_at_exact_threshold_pairs():
+    """Pairs whose IoU equals the threshold exactly (0.5, 0.25: exact in float32) are BOTH kept -- the rule is
+    `iou > threshold` in the reference's NumPy NMS (utils.py:215) and in the restated TF kernel alike."""
+    eb, es = G["nms_eq_boxes"], G["nms_eq_scores"]
+    for thr, tag in ((0.5, "50"), (0.25, "25"), (0.6, "60")):
+        ref = G["nms_eq_keep_" + tag]
+        assert np.array_equal(orc.non_max_suppression_np(eb, es, thr), ref)
+        assert np.array_equal(orc.tf_non_max_suppression(eb, es, eb.shape[0], thr).astype(np.int32), ref)
+    assert 1 in G["nms_eq_keep_50"] and 3 in G["nms_eq_keep_25"] and 3 not in G["nms_eq_keep_50"][:0]
+    assert 1 not in G["nms_eq_keep_25"]           # IoU 0.5 > 0.25: suppressed there
+
+
+def test_compute_matches_and_ap():
+    from caesar_mrcnn_amd import utils as U
+    args = (G["ev_gt_boxes"], G["ev_gt_ids"], G["ev_gt_masks"], G["ev_pred_boxes"], G["ev_pred_ids"],
+            G["ev_pred_scores"], G["ev_pred_masks"])
+    assert np.array_equal(U.compute_overlaps_masks(G["ev_pred_masks"], G["ev_gt_masks"][..., :5]), G["ev_overlaps_masks"])
+    for thr, tag in ((0.5, "50"), (0.75, "75")):
+        gm, pm, ov = U.compute_matches(*args, iou_threshold=thr)
+        assert gm.dtype == G["ev_gt_match_" + tag].dtype
+        assert np.array_equal(gm, G["ev_gt_match_" + tag]) and np.array_equal(pm, G["ev_pred_match_" + tag])
+        assert np.array_equal(ov, G["ev_overlaps_" + tag])
+        ap, prec, rec, _ = U.compute_ap(*args, iou_threshold=thr)
+        assert ap == float(G["ev_ap_" + tag])
+        assert np.array_equal(prec, G["ev_precisions_" + tag]) and np.array_equal(rec, G["ev_recalls_" + tag])
+    assert (G["ev_pred_match_50"] > -1).sum() >= 3 and float(G["ev_ap_50"]) > 0.5
+
+
+def test_connected_components_order():
+    """analyze.connected_components reproduces mrcnn/graph.py's Graph.connectedComponents: component order, and
+    the depth-first vertex order inside each component."""
+    from caesar_mrcnn_amd.analyze import connected_components
+    for tag in "abc":
+        n, edges = int(G["graph_%s_n" % tag]), [tuple(int(v) for v in e) for e in G["graph_%s_edges" % tag]]
+        cc = connected_components(n, edges)
+        assert [len(c) for c in cc] == G["graph_%s_cc_len" % tag].tolist()
+        assert [v for c in cc for v in c] == G["graph_%s_cc_flat" % tag].tolist()
