@@ -419,6 +419,27 @@ def test_proposal_layer(dev, A, limit, count, thr):
         assert np.all(rois[b, n:].cpu().numpy() == 0)
 
 
+def test_proposal_nms_at_exact_threshold_pairs(dev):
+    """The reference-generated fixture with pairs whose IoU EQUALS the threshold (0.5, 0.25; exact in float32) through
+    the HIP proposal layer: zero deltas decode to the anchors themselves (coordinates are multiples of 1/128, every
+    step exact), so the kernel's keep list must be the reference NumPy NMS's -- both boxes survive at equality."""
+    ops = _ops()
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_numpy_helpers.npz"))
+    eb, es = G["nms_eq_boxes"], G["nms_eq_scores"]
+    n = eb.shape[0]
+    anchors = torch.tensor((eb / np.float32(128)).astype(np.float32), device=dev)
+    probs = torch.tensor(np.stack([1 - es, es], -1)[None].astype(np.float32), device=dev)
+    deltas = torch.zeros((1, n, 4), device=dev)
+    for thr, tag in ((0.5, "50"), (0.25, "25"), (0.6, "60")):
+        rois, top_idx, keep_idx, num_keep, boxes = ops.proposals(probs, deltas, anchors, 6000, n, thr, _cfg().RPN_BBOX_STD_DEV,
+                                                                 debug=True)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(boxes[0].cpu().numpy(), eb / np.float32(128))
+        k = int(num_keep[0])
+        kept = top_idx[0].cpu().numpy()[keep_idx[0, :k].cpu().numpy()]
+        np.testing.assert_array_equal(kept, G["nms_eq_keep_" + tag])
+
+
 def test_proposal_selection_survives_stale_counters(dev):
     """Fault injection for the multi-workgroup top-k (A >= 32 768): the second call runs with the reset of its
     histograms / counters suppressed (MRCNN_PROPOSAL_SKIP_ZERO=1), i.e. with the state a missing reset would leave.
