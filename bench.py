@@ -212,7 +212,7 @@ def measure(args, backbone, nimg, rank, local_rank, world, full):
     batch = synthetic_batch(cfg, nimg, seed=1234 + rank)
     dev_inputs = model._to_device(batch)
     eng = model.engine
-    reducer = GradReducer(eng.grads, world) if world > 1 else None
+    reducer = GradReducer(eng.grads, world, rank=rank, timing=True) if world > 1 else None
     eng.grad_ready = reducer.ready if reducer else None
 
     def step():
@@ -243,7 +243,28 @@ def measure(args, backbone, nimg, rank, local_rank, world, full):
     eng.sparse_mask_bwd = False
     for _ in range(args.warmup):
         step()
+    if reducer:
+        reducer.pop_timing()
     dt, losses = timed(args.steps)
+    comm = None
+    if reducer:
+        # what the gradient exchange costs: time on the exchange stream (HIP events around every range), bytes per range,
+        # and the EXPOSED part = step time with the exchange - step time of the same step without it (all ranks run both)
+        ar_ms, ar_bytes, ranges = reducer.pop_timing()
+        eng.grad_ready = None
+        reducer_saved, reducer = reducer, None
+        step()
+        dt_nocomm, _ = timed(args.steps)
+        reducer = reducer_saved
+        eng.grad_ready = reducer.ready
+        comm = {"transport": {"rccl": "RCCL ncclAllReduce through the C-ABI (mrcnn_allreduce_grad)",
+                              "direct": "grouped point-to-point reduce-scatter + all-gather through the C-ABI",
+                              "torch": "torch.distributed all_reduce"}.get(reducer.mode, reducer.mode),
+                "ms_per_step_on_exchange_stream": round(ar_ms / args.steps, 3),
+                "bytes_per_step": int(ar_bytes / args.steps), "range_bytes": ranges[:len(ranges) // max(args.steps, 1)],
+                "ms_per_step_without_exchange": round(dt_nocomm / args.steps * 1e3, 3),
+                "exposed_ms_per_step": round((dt - dt_nocomm) / args.steps * 1e3, 3),
+                "algorithmic_bus_GBps": round(2.0 * (world - 1) / world * ar_bytes / max(ar_ms, 1e-9) / 1e6, 2)}
     # product default: the mask head runs on the positive quota of each image only (rows the loss can read)
     eng.sparse_mask_bwd = True
     if args.dense_only:
@@ -266,6 +287,8 @@ def measure(args, backbone, nimg, rank, local_rank, world, full):
            "images_per_s": nimg * world * args.steps / dt,
            "images_per_s_sparse": None if args.dense_only else nimg * world * args.steps / dt_sparse,
            "losses": [float(v) for v in losses.cpu().numpy()]}
+    if comm is not None:
+        res["allreduce"] = comm
     if rank != 0:
         return res
 
@@ -446,6 +469,8 @@ def main():
             out["roofline_wgrad"] = r["roofline_wgrad"]
         if "train_loop" in r:
             out["train_loop"] = r["train_loop"]
+        if "allreduce" in r:
+            out["allreduce"] = r["allreduce"]
         if second is not None:
             out["config1_resnet50_nimg2"] = {
                 "workload": "BASELINE.json configs[1]: resnet50+FPN %dx%d, nimg_per_gpu=2, 1 GPU train + detect" % (args.imgsize, args.imgsize),

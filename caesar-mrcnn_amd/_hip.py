@@ -124,6 +124,13 @@ _SIGNATURES = {
     "mrcnn_grad_prepare": (C.c_int, [_P, _P, C.c_float, _P, C.c_int64, _P, _P]),
     "mrcnn_sumsq": (C.c_int, [_P, C.c_int64, _P, _P]),
     "mrcnn_sgd_momentum": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, C.c_int64, _P]),
+    "mrcnn_allreduce_load": (C.c_int, [C.c_char_p]),
+    "mrcnn_allreduce_unique_id": (C.c_int, [_P]),
+    "mrcnn_allreduce_init": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int]),
+    "mrcnn_allreduce_scratch": (C.c_size_t, [C.c_int, C.c_int64, C.c_int]),
+    "mrcnn_allreduce_grad": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, _P, C.c_size_t, _P]),
+    "mrcnn_allreduce_destroy": (C.c_int, [_P]),
+    "mrcnn_allreduce_last_error": (C.c_char_p, []),
     "mrcnn_hip_version": (C.c_char_p, []),
 }
 
@@ -139,17 +146,20 @@ def lib():
     """Load (once) and return the kernel library; never falls back to anything else."""
     global _lib
     if _lib is None:
+        why = ""
         if not os.path.exists(LIB_PATH):
-            # not built yet (fresh checkout on a box with the toolchain): build once, in-tree; still no fallback
+            # not built yet (fresh checkout on a box with the toolchain): build once, in-tree; still no fallback.
+            # build() takes a file lock and links to a temporary name, so the ranks of a torchrun job that all arrive
+            # here together neither compile twice nor load a half-written library.
             try:
                 from . import build as _build
                 _build.build(verbose=False)
-            except Exception:
-                pass
+            except Exception as e:
+                why = " Building it here failed: %s" % (e,)
         if not os.path.exists(LIB_PATH):
             raise HipPathError(
                 "libmrcnn_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
-                "g.build()'`; there is no CPU fallback for the hot path." % LIB_PATH)
+                "g.build()'`; there is no CPU fallback for the hot path.%s" % (LIB_PATH, why))
         # torch first: its wheel carries its own HIP runtime, and the streams / device pointers we are handed belong
         # to that one.  Loaded before torch, this library would pull in the system runtime instead and every launch
         # on a torch stream would fail (seen as status -2 from the first kernel when build() and smoke() share a process).

@@ -31,6 +31,20 @@ def _newest(paths):
 
 
 def build(force=False, verbose=True, extra_flags=()):
+    """Compile + link under an exclusive file lock (several processes may call this at once: every rank of a torchrun
+    job on a fresh checkout); the library is linked to a temporary name and renamed into place, so a concurrent
+    CDLL never sees a partial file."""
+    import fcntl
+    os.makedirs(os.path.join(PKG_DIR, "build"), exist_ok=True)
+    with open(os.path.join(PKG_DIR, "build", ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose, extra_flags)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose, extra_flags):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h"))) + sorted(glob.glob(os.path.join(INCLUDE, "*.h")))
     if not srcs:
@@ -59,12 +73,16 @@ def build(force=False, verbose=True, extra_flags=()):
                 if verbose or rc:
                     sys.stderr.write("[build] %s\n%s" % (os.path.basename(cmd[-3]), out))
                 if rc:
-                    raise RuntimeError("hipcc failed for %s" % cmd[-3])
+                    raise RuntimeError("hipcc failed for %s:\n%s" % (cmd[-3], out[-4000:]))
     if jobs or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < _newest(objs):
-        cmd, rc, out = run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs)
+        tmp = LIB_PATH + ".tmp.%d" % os.getpid()
+        cmd, rc, out = run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs)
         if rc:
             sys.stderr.write(out)
-            raise RuntimeError("link of libmrcnn_hip.so failed")
+            if os.path.exists(tmp):
+                os.remove(tmp)
+            raise RuntimeError("link of libmrcnn_hip.so failed:\n%s" % out[-4000:])
+        os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
 

@@ -11,6 +11,10 @@ from . import utils
 logger = logging.getLogger("mrcnn")
 
 
+class EmptyShareError(RuntimeError):
+    """A rank's share of the dataset can never yield a batch (fewer images than ranks, or none with instances)."""
+
+
 def load_image_gt(dataset, config, image_id, augment=False, augmentation=None, use_mini_mask=False):
     """image, image_meta, class_ids, bbox, mask for one dataset entry (model.py:1277-1377).
     `augmentation` may be an imgaug augmenter (if imgaug is installed) or any callable
@@ -108,6 +112,10 @@ def data_generator(dataset, config, shuffle=True, augment=False, augmentation=No
     backbone_shapes = utils.compute_backbone_shapes(config, config.IMAGE_SHAPE)
     anchors = utils.generate_pyramid_anchors(config.RPN_ANCHOR_SCALES, config.RPN_ANCHOR_RATIOS, backbone_shapes,
                                              config.BACKBONE_STRIDES, config.RPN_ANCHOR_STRIDE)
+    if len(image_ids) < world_size:
+        raise EmptyShareError("data_generator: %d images for %d ranks -- rank %d would never receive one (and the other "
+                         "ranks would hang in the gradient all-reduce)" % (len(image_ids), world_size, rank))
+    barren = 0                                      # consecutive own-stride images without a usable instance
     while True:
         try:
             image_index = (image_index + 1) % len(image_ids)
@@ -115,6 +123,10 @@ def data_generator(dataset, config, shuffle=True, augment=False, augmentation=No
                 rng.shuffle(image_ids)
             if image_index % world_size != rank:
                 continue
+            barren += 1
+            if barren > 2 * len(image_ids):
+                raise EmptyShareError("data_generator: rank %d found no image with instances in two passes over its share of "
+                                 "the %d images" % (rank, len(image_ids)))
             image_id = image_ids[image_index]
             if dataset.image_info[image_id]['source'] in no_augmentation_sources:
                 image, image_meta, gt_class_ids, gt_boxes, gt_masks = load_image_gt(
@@ -125,6 +137,7 @@ def data_generator(dataset, config, shuffle=True, augment=False, augmentation=No
                     use_mini_mask=config.USE_MINI_MASK)
             if not np.any(gt_class_ids > 0):
                 continue
+            barren = 0
             if not device_targets:
                 rpn_match, rpn_bbox = build_rpn_targets(image.shape, anchors, gt_class_ids, gt_boxes, config)
             if b == 0:
@@ -155,7 +168,7 @@ def data_generator(dataset, config, shuffle=True, augment=False, augmentation=No
                 yield [batch_images, batch_image_meta, batch_rpn_match, batch_rpn_bbox, batch_gt_class_ids,
                        batch_gt_boxes, batch_gt_masks], []
                 b = 0
-        except (GeneratorExit, KeyboardInterrupt):
+        except (GeneratorExit, KeyboardInterrupt, EmptyShareError):
             raise
         except Exception:
             logger.exception("Error processing image {}".format(dataset.image_info[image_id]))

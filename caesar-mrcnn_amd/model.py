@@ -68,6 +68,12 @@ class MaskRCNN(object):
             raise Exception("Image size must be dividable by 2 at least 6 times "
                             "to avoid fractions when downscaling and upscaling."
                             "For example, use 256, 320, 384, 448, 512, ... etc. ")
+        if getattr(config, "TRAIN_BN", False) is not False:
+            # the reference passes training=config.TRAIN_BN to every BatchNorm (model.py:57-72): None / True would
+            # normalise with batch statistics and update the moving averages; this engine implements the frozen form
+            # only (run.py never changes the default False) -- refuse instead of silently training something else
+            raise NotImplementedError("TRAIN_BN=%r: only frozen BatchNorm (TRAIN_BN=False, the run.py default) is "
+                                      "implemented" % (config.TRAIN_BN,))
         import torch
         from . import _hip
         from .engine import MaskRCNNEngine
@@ -116,6 +122,19 @@ class MaskRCNN(object):
         if not by_name and len(picked) != len(tensors):
             raise ValueError("weight file does not match the model topology; use by_name=True")
         self.engine.set_weights(picked, strict=False)
+        # by-name loading skips what does not match, silently in Keras; a naming / layout mismatch would leave layers at
+        # their random initialisation without a trace, so say what happened (and keep the lists for callers / tests)
+        wanted = set(known) | {"%s/%s" % (l.bn, s_) for l in self.engine.layout.bn_layers for s_ in stats}
+        self.last_load = {"loaded": sorted(set(picked) & wanted),
+                          "missing_in_file": sorted(n for n in wanted if n not in picked
+                                                    and not (exclude and n.split("/")[0] in exclude)),
+                          "unused_in_file": sorted(n for n in tensors if n not in wanted)}
+        log("load_weights(%s): %d tensors loaded, %d model tensors not in the file, %d file tensors not used" % (
+            os.path.basename(str(filepath)), len(self.last_load["loaded"]), len(self.last_load["missing_in_file"]),
+            len(self.last_load["unused_in_file"])))
+        for key in ("missing_in_file", "unused_in_file"):
+            if self.last_load[key]:
+                log("  %s: %s%s" % (key, ", ".join(self.last_load[key][:6]), " ..." if len(self.last_load[key]) > 6 else ""))
         self.set_log_dir(filepath)
 
     def save_weights(self, filepath):

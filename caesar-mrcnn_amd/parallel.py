@@ -7,8 +7,16 @@ each rank runs the whole step on its IMAGES_PER_GPU images and the flat gradient
 Reduction is overlapped with the backward pass: the engine reports contiguous gradient ranges as soon
 as they are final (heads+FPN first, then res5..res2, then the stem and BatchNorm block) and each range
 is reduced on a side stream while the remaining backward kernels keep the compute stream busy.
-xGMI is point-to-point (7 links/GPU), so few large messages beat many small ones: 7 ranges of 4-100 MB.
+xGMI is point-to-point (7 links/GPU), so few large messages beat many small ones: 7 ranges of 4-100 MB
+by default; ``MRCNN_ALLREDUCE_MAX_MB`` cuts ranges into pieces of at most that size.
+
+Transport.  On GPUs the exchange goes through the C-ABI (include/mrcnn_hip.h: mrcnn_allreduce_init /
+mrcnn_allreduce_grad, RCCL bound at run time); torch.distributed only carries the 128-byte rendezvous id
+and the logging scalars.  ``MRCNN_ALLREDUCE=direct`` selects the reduce-scatter + all-gather written as
+grouped point-to-point transfers (one per xGMI link), ``MRCNN_ALLREDUCE=torch`` (and every run without a
+GPU, i.e. the gloo tests) the plain ``dist.all_reduce`` per range.
 """
+import ctypes as C
 import os
 
 import torch
@@ -31,29 +39,113 @@ def init_distributed(backend=None):
     return rank, local_rank, world
 
 
-class GradReducer(object):
-    """Sums a flat gradient tensor over ranks, range by range, on a side stream."""
+def split_range(start, end, max_floats):
+    """[start, end) in pieces of at most max_floats (multiples of 64 floats, the layout's granule); None = one piece."""
+    if not max_floats or end - start <= max_floats:
+        return [(start, end)]
+    step = max(64, int(max_floats) // 64 * 64)
+    return [(a, min(a + step, end)) for a in range(start, end, step)]
 
-    def __init__(self, flat_grads, world_size):
+
+class RcclComm(object):
+    """The C-ABI communicator (mrcnn_allreduce_*): created collectively by all ranks; the 128-byte id travels over
+    torch.distributed (whatever backend it runs on) or, for a single rank, nowhere."""
+
+    def __init__(self, rank, world, device):
+        from . import _hip
+        self.lib = _hip.lib()
+        self.rank, self.world = rank, world
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        rc = self.lib.mrcnn_allreduce_load(path.encode() if os.path.exists(path) else None)
+        if rc != 0:
+            raise _hip.HipPathError("RCCL could not be loaded: %s" % self.lib.mrcnn_allreduce_last_error().decode())
+        ident = (C.c_ubyte * 128)()
+        if rank == 0:
+            _hip.check(self.lib.mrcnn_allreduce_unique_id(ident), "mrcnn_allreduce_unique_id")
+        if world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0)
+            ident = (C.c_ubyte * 128).from_buffer_copy(box[0])
+        torch.cuda.set_device(device)
+        self.handle = C.c_void_p()
+        rc = self.lib.mrcnn_allreduce_init(C.byref(self.handle), ident, rank, world)
+        if rc != 0:
+            raise _hip.HipPathError("mrcnn_allreduce_init failed (%d): %s" % (rc, self.lib.mrcnn_allreduce_last_error().decode()))
+
+    def reduce(self, flat, start, end, algo, scratch, stream):
+        from . import _hip
+        rc = self.lib.mrcnn_allreduce_grad(self.handle, flat.data_ptr(), start, end, algo,
+                                           scratch.data_ptr() if scratch is not None else None,
+                                           scratch.numel() * 4 if scratch is not None else 0, stream)
+        if rc != 0:
+            raise _hip.HipPathError("mrcnn_allreduce_grad failed (%d): %s" % (rc, self.lib.mrcnn_allreduce_last_error().decode()))
+
+    def close(self):
+        if self.handle:
+            self.lib.mrcnn_allreduce_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+class GradReducer(object):
+    """Sums a flat gradient tensor over ranks, range by range, on a side stream.
+
+    ``timing=True`` brackets every exchange with HIP events on the exchange stream: ``pop_timing()`` then returns the
+    milliseconds the exchanges of the finished steps took there and the bytes they moved (bench.py, N > 1)."""
+
+    def __init__(self, flat_grads, world_size, rank=None, mode=None, timing=False, max_mb=None):
         self.g = flat_grads
         self.world = world_size
         self.cuda = flat_grads.is_cuda
         self.stream = torch.cuda.Stream(device=flat_grads.device) if (self.cuda and world_size > 1) else None
         self.pending = []
+        self.timing = timing
+        self._events, self.bytes_moved, self.range_log = [], 0, []
+        mode = mode or os.environ.get("MRCNN_ALLREDUCE") or ("rccl" if self.cuda else "torch")
+        if dist.is_initialized() and dist.get_backend() == "gloo":
+            mode = "torch"                                  # ranks sharing one GPU (rehearsals) cannot form an RCCL communicator
+        self.mode = mode if world_size > 1 else "none"
+        mb = max_mb if max_mb is not None else os.environ.get("MRCNN_ALLREDUCE_MAX_MB")
+        self.max_floats = int(float(mb) * (1 << 20) / 4) if mb else None
+        self.comm = self.scratch = None
+        if self.mode in ("rccl", "direct"):
+            rank = dist.get_rank() if rank is None else rank
+            self.comm = RcclComm(rank, world_size, flat_grads.device)
+            self.algo = 1 if self.mode == "direct" else 0
+            if self.algo == 1:
+                longest = self.max_floats or flat_grads.numel()
+                nbytes = self.comm.lib.mrcnn_allreduce_scratch(world_size, min(longest, flat_grads.numel()), 1)
+                self.scratch = torch.empty(max(nbytes // 4, 64), dtype=torch.float32, device=flat_grads.device)
 
     def ready(self, start, end):
         """Called by the engine when grads[start:end] are final."""
         if self.world <= 1 or end <= start:
             return
-        view = self.g[start:end]
+        pieces = split_range(start, end, self.max_floats)
         if self.stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(self.g.device))
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
-                self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+                if self.timing:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(self.stream)
+                for a, b in pieces:
+                    self._one(a, b)
+                if self.timing:
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(self.stream)
+                    self._events.append((e0, e1))
         else:
-            self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, async_op=True))
+            for a, b in pieces:
+                self._one(a, b)
+        self.bytes_moved += (end - start) * 4
+        self.range_log.append((end - start) * 4)
+
+    def _one(self, a, b):
+        if self.comm is not None:
+            self.comm.reduce(self.g, a, b, self.algo, self.scratch, self.stream.cuda_stream)
+        else:
+            self.pending.append(dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self):
         """Make the compute stream wait for every outstanding reduction."""
@@ -62,6 +154,20 @@ class GradReducer(object):
         self.pending = []
         if self.stream is not None:
             torch.cuda.current_stream(self.g.device).wait_stream(self.stream)
+
+    def pop_timing(self):
+        """(ms on the exchange stream, bytes reduced, per-range byte sizes of the last step) since the last call;
+        synchronises."""
+        torch.cuda.synchronize(self.g.device)
+        ms = sum(e0.elapsed_time(e1) for e0, e1 in self._events)
+        out = (ms, self.bytes_moved, list(self.range_log))
+        self._events, self.bytes_moved, self.range_log = [], 0, []
+        return out
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
 
 def allreduce_mean_scalars(t, world_size):

@@ -344,6 +344,33 @@ int mrcnn_sgd_momentum(float* params, float* momentum_buf, const float* grads, c
                        float clipnorm, float lr, float momentum, const float* gran_coef, int64_t n,
                        void* stream);
 
+/* ---- data-parallel gradient exchange over RCCL / xGMI ---------------------------------------------------------------
+ * Replaces the in-graph tower aggregation of mrcnn/parallel_model.py:54-104 (weights shared between towers, gradients
+ * summed implicitly by TF, scalar losses averaged :97-99): one process per GPU, each rank sums contiguous ranges
+ * [start, end) of its flat float32 gradient buffer with all peers, in place, on `stream`; the division by the world size
+ * happens in mrcnn_grad_prepare (grad_scale = 1 / world).  RCCL is bound at run time:
+ *   mrcnn_allreduce_load(path)   dlopen + dlsym; path = the librccl the process already uses (PyTorch's), or NULL for
+ *                                the default search.  MRCNN_ERR_UNSUPPORTED when no RCCL can be loaded.
+ *   mrcnn_allreduce_unique_id    rank 0 creates the 128-byte rendezvous id; the caller hands it to every rank (any
+ *                                side channel: a torch.distributed broadcast, a file, MPI).
+ *   mrcnn_allreduce_init         ncclCommInitRank on the calling thread's current HIP device; collective over all ranks.
+ *   mrcnn_allreduce_grad         algo MRCNN_ALLREDUCE_RCCL: ncclAllReduce(sum);  MRCNN_ALLREDUCE_DIRECT: reduce-scatter +
+ *                                all-gather as grouped point-to-point transfers, one per xGMI link, chunks summed in rank
+ *                                order by the owner (bitwise identical on every rank); needs mrcnn_allreduce_scratch()
+ *                                bytes of device scratch.  Enqueues only; never synchronises.
+ * Calls on one communicator must be issued in the same order on every rank (RCCL's rule).                          */
+#define MRCNN_UNIQUE_ID_BYTES 128
+#define MRCNN_ALLREDUCE_RCCL 0
+#define MRCNN_ALLREDUCE_DIRECT 1
+int mrcnn_allreduce_load(const char* librccl_path);
+int mrcnn_allreduce_unique_id(void* id_128_bytes);
+int mrcnn_allreduce_init(void** comm, const void* id_128_bytes, int rank, int world);
+size_t mrcnn_allreduce_scratch(int world, int64_t max_range_floats, int algo);
+int mrcnn_allreduce_grad(void* comm, float* grads, int64_t start, int64_t end, int algo, float* scratch,
+                         size_t scratch_bytes, void* stream);
+int mrcnn_allreduce_destroy(void* comm);
+const char* mrcnn_allreduce_last_error(void);
+
 const char* mrcnn_hip_version(void);
 
 #ifdef __cplusplus

@@ -70,3 +70,31 @@ def test_two_rank_step_matches_manual_average(dev, tmp_path):
     ref = model.engine.params.cpu().numpy()
     scale = np.abs(ref).max()
     assert np.abs(ref - p0).max() <= 1e-5 * scale
+
+
+def test_rccl_cabi_single_rank(dev):
+    """The C-ABI RCCL binding (mrcnn_allreduce_load / _unique_id / _init / _grad / _destroy) end to end on the one GPU of
+    this pool: a communicator of one rank, where the sum over ranks is the identity -- checks the run-time binding (the
+    librccl PyTorch already loaded), the rendezvous id, the enqueue on a side stream and both algorithms' argument
+    handling.  More than one rank needs more than one GPU (RCCL refuses two ranks on one device): the multi-rank
+    arithmetic of the data-parallel step is covered over gloo above, the transport itself only on a real node."""
+    from caesar_mrcnn_amd.parallel import GradReducer, RcclComm
+    comm = RcclComm(0, 1, dev)
+    g = torch.arange(70000, dtype=torch.float32, device=dev)
+    ref = g.clone()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        comm.reduce(g, 0, 70000, 0, None, side.cuda_stream)
+        comm.reduce(g, 128, 4096, 0, None, side.cuda_stream)
+        comm.reduce(g, 0, 70000, 1, None, side.cuda_stream)        # direct form: nothing to exchange with one rank
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref)
+    assert comm.lib.mrcnn_allreduce_scratch(8, 1 << 20, 1) == 7 * (1 << 17) * 4
+    assert comm.lib.mrcnn_allreduce_scratch(8, 1 << 20, 0) == 0
+    comm.close()
+    red = GradReducer(g, 1)                                         # world 1: no communicator, ready() is a no-op
+    red.ready(0, 100)
+    red.finish()
+    assert red.mode == "none" and red.comm is None

@@ -258,11 +258,29 @@ for lo, hi in ((600, 1000), (200, 600), (0, 200)):      # ranges arrive in backw
     red.ready(lo, hi)
 red.finish()
 assert torch.equal(g, torch.arange(1000, dtype=torch.float32) * 3), g[:5]
+assert red.mode == "torch"
+# ranges cut into <= 256-float messages (MRCNN_ALLREDUCE_MAX_MB): same sums, more, smaller exchanges
+g2 = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+red2 = GradReducer(g2, world, max_mb=256 * 4 / 2 ** 20)
+for lo, hi in ((600, 1000), (200, 600), (0, 200)):
+    red2.ready(lo, hi)
+assert len(red2.pending) == 2 + 2 + 1
+red2.finish()
+assert torch.equal(g2, torch.arange(1000, dtype=torch.float32) * 3)
+assert red2.range_log == [1600, 1600, 800] and red2.bytes_moved == 4000
 l = allreduce_mean_scalars(torch.full((5,), float(rank)), world)
 assert torch.allclose(l, torch.full((5,), 0.5))
 dist.barrier(); dist.destroy_process_group()
 print("rank", rank, "ok")
 """
+
+
+def test_split_range():
+    from caesar_mrcnn_amd.parallel import split_range
+    assert split_range(0, 1000, None) == [(0, 1000)]
+    assert split_range(64, 1000, 5000) == [(64, 1000)]
+    assert split_range(0, 1000, 300) == [(0, 256), (256, 512), (512, 768), (768, 1000)]     # pieces are granule multiples
+    assert split_range(128, 256, 10) == [(128, 192), (192, 256)]
 
 
 def test_grad_reducer_gloo_world2(tmp_path):
