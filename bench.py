@@ -158,16 +158,16 @@ def _train_loop_leg(args, res, model, cfg, nimg, world, rank):
     gen = Prefetcher([data_generator(ds, cfg, shuffle=True, batch_size=nimg, seed=99 + 1000 * k, device_targets=True)
                       for k in range(nw)], depth=2 * nw + 2)
     eng = model.engine
-    eng.sparse_mask_bwd = False                       # the headline's work per step (every ROI row through the mask head)
     steps = max(args.steps, 10)
-    try:
+
+    def run(sparse):
+        eng.sparse_mask_bwd = sparse
         for _ in range(3):
             inputs, _ = next(gen)
             model.train_on_batch(inputs)
         torch.cuda.synchronize()
         t0 = time.time()
-        wait = 0.0
-        h2d = 0
+        wait, h2d = 0.0, 0
         for _ in range(steps):
             t1 = time.time()
             inputs, _ = next(gen)
@@ -178,15 +178,20 @@ def _train_loop_leg(args, res, model, cfg, nimg, world, rank):
             model.train_on_batch(inputs)
         torch.cuda.synchronize()
         dt = time.time() - t0
+        return {"images_per_s": round(nimg * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3),
+                "ms_per_step_waiting_for_loader": round(wait / steps * 1e3, 3), "h2d_bytes_per_step": int(h2d / steps)}
+
+    try:
+        dense = run(False)                            # the headline's work per step (every ROI row through the mask head)
+        sparse = run(True)                            # product default (positive-quota rows only): the feed shows here first
     finally:
         gen.close()
-    res["train_loop"] = {
-        "images_per_s": round(nimg * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-        "loader_threads": nw, "ms_per_step_waiting_for_loader": round(wait / steps * 1e3, 3),
-        "h2d_bytes_per_step": int(h2d / steps),
-        "what": "MaskRCNN.train()'s own iteration: Prefetcher threads over data_generator on 32 synthetic FITS tiles "
-                "(read_fits + zscale + uint8 RGB + resize + extract_bboxes), per-step H2D of images and used GT-mask planes "
-                "(uint8), RPN targets built on the device, dense mask head; feed-inclusive, never `value`"}
+        eng.sparse_mask_bwd = True
+    res["train_loop"] = dict(dense, steps=steps, loader_threads=nw, exact_zero_skip=sparse,
+        what="MaskRCNN.train()'s own iteration: Prefetcher threads over data_generator on 32 synthetic FITS tiles "
+             "(read_fits + zscale + uint8 RGB + resize + extract_bboxes), per-step H2D of images and used GT-mask planes "
+             "(uint8), RPN targets built on the device; dense mask head like `value`, and the product-default step under "
+             "exact_zero_skip; feed-inclusive, never `value`")
 
 
 TRAFFIC_PER_LAUNCH = {1024: None, 2048: 1.810e9}   # mask-head conv, PMC passes: profiles/r01_pmc_conv_traffic.md

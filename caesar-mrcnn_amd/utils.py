@@ -186,11 +186,12 @@ def resize_image(image, min_dim=None, max_dim=None, min_scale=None, mode="square
 def resize_mask(mask, scale, padding, crop=None):
     """Nearest-neighbour zoom of [H,W,N] masks by `scale` + the image's padding/crop
     (mrcnn/utils.py:564-583; scipy.ndimage.zoom(order=0))."""
-    import scipy.ndimage
-    import warnings
-    with warnings.catch_warnings():
-        warnings.simplefilter("ignore")
-        mask = scipy.ndimage.zoom(mask, zoom=[scale, scale, 1], order=0)
+    if scale != 1:                  # zoom by 1 with order 0 is the identity: the 256-pixel tiles of run.py skip the call
+        import scipy.ndimage
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            mask = scipy.ndimage.zoom(mask, zoom=[scale, scale, 1], order=0)
     if crop is not None:
         y, x, h, w = crop
         return mask[y:y + h, x:x + w]
