@@ -131,6 +131,7 @@ _SIGNATURES = {
     "mrcnn_allreduce_grad": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, _P, C.c_size_t, _P]),
     "mrcnn_allreduce_destroy": (C.c_int, [_P]),
     "mrcnn_allreduce_last_error": (C.c_char_p, []),
+    "mrcnn_tuning_set": (C.c_int, [C.c_char_p, C.c_longlong]),
     "mrcnn_hip_version": (C.c_char_p, []),
 }
 

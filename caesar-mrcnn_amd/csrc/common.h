@@ -10,6 +10,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define WAVE 64
 
+// Process-wide tuning values (mrcnn_tuning_set): host-side, read at launch time.
+//   wgrad_lds_pad: extra dynamic LDS bytes requested by the large LDS-DMA weight-gradient kernel.  Its 32 KiB of static LDS
+//   let five workgroups fill a CU's 160 KiB; padded to 40 KiB only four fit, which leaves one workgroup slot per CU to
+//   the small latency-bound kernels of another stream (the engine sets it around the weight gradients it runs beside the
+//   backbone's backward pass, see engine.py "deferred mask-head weight gradients").
+extern int g_mrcnn_wgrad_lds_pad;
+
 static inline int mrcnn_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MRCNN_OK : MRCNN_ERR_LAUNCH;

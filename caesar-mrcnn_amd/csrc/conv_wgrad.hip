@@ -586,11 +586,11 @@ extern "C" int mrcnn_conv2d_wgrad(const mrcnn_conv_desc* d, const float* x, cons
                 hipLaunchKernelGGL(pixel_table_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, (PixelEntry*)a.table, d->N,
                                    d->H, d->W, d->Cin, d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->OH, d->OW, (int)M, rows,
                                    (unsigned)shift, 4);
-                hipLaunchKernelGGL((conv_wgrad_blds_kernel<WGRAD_BP, true>), dim3((unsigned)blocks), dim3(256), 0, s, a, (unsigned)shift,
-                                   (unsigned)(xbytes + shift));
+                hipLaunchKernelGGL((conv_wgrad_blds_kernel<WGRAD_BP, true>), dim3((unsigned)blocks), dim3(256),
+                                   (size_t)g_mrcnn_wgrad_lds_pad, s, a, (unsigned)shift, (unsigned)(xbytes + shift));
             } else {
-                hipLaunchKernelGGL((conv_wgrad_blds_kernel<WGRAD_BP, false>), dim3((unsigned)blocks), dim3(256), 0, s, a, (unsigned)shift,
-                                   (unsigned)(xbytes + shift));
+                hipLaunchKernelGGL((conv_wgrad_blds_kernel<WGRAD_BP, false>), dim3((unsigned)blocks), dim3(256),
+                                   (size_t)g_mrcnn_wgrad_lds_pad, s, a, (unsigned)shift, (unsigned)(xbytes + shift));
             }
         }
         else

@@ -3,6 +3,7 @@
 // adjoint of nearest 2x upsampling, row softmax.  Reference ops: mrcnn/model.py:57-72, 117-130, 187,
 // 2005-2022, 946, 1028.
 #include "common.h"
+#include <string.h>
 
 // ---------------------------------------------------------------------------------------------
 __global__ void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -492,6 +493,18 @@ extern "C" int mrcnn_fill_zero(void* dst, size_t bytes, void* stream) {
         return mrcnn_launch_status();
     }
     return hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream) == hipSuccess ? MRCNN_OK : MRCNN_ERR_LAUNCH;
+}
+
+int g_mrcnn_wgrad_lds_pad = 0;
+
+extern "C" int mrcnn_tuning_set(const char* key, long long value) {
+    if (!key) return MRCNN_ERR_ARG;
+    if (!strcmp(key, "wgrad_lds_pad")) {
+        if (value < 0 || value > 32768) return MRCNN_ERR_ARG;
+        g_mrcnn_wgrad_lds_pad = (int)value;
+        return MRCNN_OK;
+    }
+    return MRCNN_ERR_UNSUPPORTED;
 }
 
 extern "C" const char* mrcnn_hip_version(void) { return "mrcnn_hip 0.1 (gfx950)"; }

@@ -196,6 +196,14 @@ class MaskRCNNEngine(object):
         self.fused_dgrad_epilogue = True  # data-gradient convs of the mask head apply the lower layer's epilogue backward
         self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self.aux_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        # The mask head's weight gradients feed nothing in the backward chain.  Launched where their operands appear they run
+        # beside the mask head's data gradients -- two matrix-bound streams, no gain -- and the backbone's backward pass
+        # (some 330 small, latency-bound launches) then runs almost alone on the chip.  Deferred, they are issued on the
+        # auxiliary stream when the backbone's backward pass starts: the matrix-bound work fills the CUs the small kernels
+        # leave idle.  "wgrad_lds_pad" keeps one workgroup slot per CU free for those small kernels meanwhile.
+        self.defer_mask_wgrad = os.environ.get("MRCNN_DEFER_MASK_WGRAD", "1") != "0"
+        self.defer_lds_pad = int(os.environ.get("MRCNN_DEFER_LDS_PAD", "8192"))
+        self._deferred = []
         self.gather_roialign_bwd = os.environ.get("MRCNN_GATHER_ROIALIGN_BWD", "1") != "0"   # class-head ROIAlign adjoint in gather form
         self.multi_launch = os.environ.get("MRCNN_MULTI_LAUNCH", "1") != "0"     # independent small convolutions share launches
 
@@ -307,6 +315,50 @@ class MaskRCNNEngine(object):
     def join_wgrad(self):
         if self.wgrad_stream is not None:
             torch.cuda.current_stream(self.dev).wait_stream(self.wgrad_stream)
+
+    # ---- deferred mask-head weight gradients ----------------------------------------------------------
+    def _mask_wgrad(self, kind, *args):
+        """A weight gradient of the mask head: now (on the weight-gradient stream) or, with ``defer_mask_wgrad``, beside
+        the backbone's backward pass (``_flush_deferred``).  kind "f32": ConvOp.wgrad_item tuple; "h16": the arguments of
+        wgrad_h16_async."""
+        if self.defer_mask_wgrad and self.aux_stream is not None:
+            self._deferred.append((kind, args))
+        elif kind == "f32":
+            self.wgrad_async(*args)
+        else:
+            self.wgrad_h16_async(*args)
+
+    def _flush_deferred(self):
+        """Issue the deferred weight gradients on the auxiliary stream, behind everything the main stream has done so far."""
+        if not self._deferred:
+            return
+        aux, main = self.aux_stream, torch.cuda.current_stream(self.dev)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        if self.defer_lds_pad:
+            ops.tuning_set("wgrad_lds_pad", self.defer_lds_pad)
+        try:
+            with torch.cuda.stream(aux):
+                aux.wait_event(ev)
+                for kind, a in self._deferred:
+                    if kind == "f32":
+                        x, dz, wshape, stride, padding, dw, acc = a
+                        ops.conv2d_wgrad(x, dz, wshape, stride, padding, dw=dw, accumulate=acc)
+                    else:
+                        x, dz, wshape, dw, mult = a
+                        ops.conv2d_wgrad_h16(x, dz, wshape, 1, "same", dw=dw, multiplier=mult)
+                    dz.record_stream(aux)
+                    x.record_stream(aux)
+        finally:
+            if self.defer_lds_pad:
+                ops.tuning_set("wgrad_lds_pad", 0)
+        self._deferred = []
+        self._aux_pending = True
+
+    def join_aux(self):
+        if getattr(self, "_aux_pending", False):
+            torch.cuda.current_stream(self.dev).wait_stream(self.aux_stream)
+            self._aux_pending = False
 
     # ---- weights in / out (Keras layouts at this boundary) --------------------------------------
     def refresh_wt(self):
@@ -679,10 +731,15 @@ class MaskRCNNEngine(object):
             self._mask_head_bwd(d_mmask, ctx_mask, rois_m, dP, area)
             self._class_head_bwd(d_logits, d_mbbox, ctx_cls, rois, dP, area)
             dP6 = self._rpn_bwd(d_rpn_logits, d_rpn_bbox, rpn_tape, dP)
-        if self.grad_ready:                      # ~2/3 of the gradient bytes (FC1 alone is 51 MB) are final here,
+        deferred = bool(self._deferred)
+        self._flush_deferred()
+        if self.grad_ready and not deferred:     # ~2/3 of the gradient bytes (FC1 alone is 51 MB) are final here,
             self.join_wgrad()
             self.grad_ready(*self.grad_ranges["heads"])     # with the whole FPN/backbone backward left to hide them
         self._trunk_bwd(dP, dP6, tape)
+        self.join_aux()
+        if self.grad_ready and deferred:         # the mask head's kernels became final beside the backbone's backward pass
+            self.grad_ready(*self.grad_ranges["heads"])
         if keep_outputs:
             self.last = {"rpn_class_logits": rpn_logits, "rpn_class": rpn_probs, "rpn_bbox": rpn_bbox,
                          "rpn_rois": rpn_rois, "rois": rois, "target_class_ids": tcls, "target_bbox": tbbox,
@@ -715,7 +772,7 @@ class MaskRCNNEngine(object):
             # output stage and deconvolution on the 16-bit tensors: dzg comes out scaled, in 16 bits
             dzg = ops.mask_out_bwd_h16(g, cm[2], up, mop.w.view(mop.wshape[2], mop.wshape[3]),
                                        mop.dw.view(mop.wshape[2], mop.wshape[3]), mop.db, dc.db, S)
-            self.wgrad_h16_async(x_in, dzg, dc.wshape, dc.dw, 1.0 / S)
+            self._mask_wgrad("h16", x_in, dzg, dc.wshape, dc.dw, 1.0 / S)
             d16 = ops.conv2d_h16(dzg, self._h16[dc.name][1], (1, 1, dc.wshape[3], dc.wshape[2]), None, None, None, 1, "valid",
                                  ACT_NONE)
         elif self.fused_mask_out_bwd and C_ <= 16 and up.shape[-1] % 64 == 0 and up.shape[-1] <= 1024:
@@ -732,7 +789,7 @@ class MaskRCNNEngine(object):
             ops.epilogue_bwd(d_up, up, None, None, None, None, None, dzu, None, None, dc.db, ACT_RELU)
             dzg = ops.pixel_unshuffle2(dzu)                             # [M,14,14,1024]
         if d16 is None:
-            self.wgrad_async(x_in, dzg, dc.wshape, 1, "valid", dc.dw, False)
+            self._mask_wgrad("f32", x_in, dzg, dc.wshape, 1, "valid", dc.dw, False)
             if not self.wt_valid:
                 ops.weight_flip_transpose(dc.w, dc.wt)
         if self.head_dtype is None:
@@ -741,7 +798,7 @@ class MaskRCNNEngine(object):
             chain = [(self.op("mrcnn_mask_conv%d" % i), c) for i, c in ((4, c4), (3, c3), (2, c2), (1, c1))]
             dz = self._dgrad_ep(dzg, dc.wt, "valid", chain[0][0], chain[0][1])
             for k, (op, c) in enumerate(chain):
-                op.wgrad(dz, c)
+                self._mask_wgrad("f32", *op.wgrad_item(dz, c))
                 if k + 1 < len(chain):
                     kh, kw = op.wshape[0], op.wshape[1]
                     if not self.wt_valid:
@@ -758,7 +815,7 @@ class MaskRCNNEngine(object):
                 kh, kw, cin, cout = op.wshape
                 xin, z, y, _ = c
                 dz = ops.epilogue_bwd_h16(d16, y, z, op.scale, op.mean, op.rstd, op.dgamma, op.dbeta, op.db, ACT_RELU, 1.0 / S)
-                self.wgrad_h16_async(xin, dz, op.wshape, op.dw, 1.0 / S)
+                self._mask_wgrad("h16", xin, dz, op.wshape, op.dw, 1.0 / S)
                 d16 = ops.conv2d_h16(dz, self._h16[op.name][1], (kh, kw, cout, cin), None, None, None, 1,
                                      ((kh - 1) // 2, (kw - 1) // 2), ACT_NONE)
             d = ops.cast_from_h16(d16, 1.0 / S)

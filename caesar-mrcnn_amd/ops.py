@@ -595,6 +595,10 @@ def pixel_unshuffle2(src, out=None):
     return out
 
 
+def tuning_set(key, value):
+    check(_hip.lib().mrcnn_tuning_set(key.encode(), int(value)), "mrcnn_tuning_set(%s)" % key)
+
+
 def copy2d(dst_ptr, dst_pitch, src_ptr, src_pitch, row_bytes, rows):
     check(_hip.lib().mrcnn_copy2d(dst_ptr, dst_pitch, src_ptr, src_pitch, row_bytes, rows, current_stream()),
           "mrcnn_copy2d")

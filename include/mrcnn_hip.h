@@ -371,6 +371,11 @@ int mrcnn_allreduce_grad(void* comm, float* grads, int64_t start, int64_t end, i
 int mrcnn_allreduce_destroy(void* comm);
 const char* mrcnn_allreduce_last_error(void);
 
+/* Process-wide tuning values, read by the host side of later launches.  Keys: "wgrad_lds_pad" (0..32768 bytes of extra
+ * LDS per workgroup of the large weight-gradient kernel: 8192 caps it at four workgroups per CU so that kernels of another
+ * stream find a free slot on every CU).  MRCNN_ERR_UNSUPPORTED for an unknown key.                                  */
+int mrcnn_tuning_set(const char* key, long long value);
+
 const char* mrcnn_hip_version(void);
 
 #ifdef __cplusplus

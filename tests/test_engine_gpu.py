@@ -490,6 +490,33 @@ def test_fused_mask_output_backward_equals_unfused(dev):
     assert np.abs(grads[0] - grads[1]).max() <= 2e-5 * scale
 
 
+@pytest.mark.parametrize("head_dtype", [None, "float16"])
+def test_deferred_mask_wgrad_equals_inline(dev, head_dtype):
+    """engine.defer_mask_wgrad only moves the mask head's weight-gradient launches (to the auxiliary stream, beside the
+    backbone's backward pass): same kernels on the same operands, so losses and the whole gradient buffer agree up to the
+    float atomics of the other kernels.  ResNet-50 256x256 so that the large LDS-DMA weight-gradient kernel (and its
+    occupancy cap) is the one that runs."""
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _full_cfg("resnet50", 256)
+    w = _weights(cfg, 47)
+    inputs, keys = _train_inputs(cfg, 2, 49)
+    res = []
+    for defer in (True, False):
+        model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+        eng = model.engine
+        eng.defer_mask_wgrad = defer
+        eng.sparse_mask_bwd = False
+        if head_dtype:
+            eng.head_dtype = getattr(torch, head_dtype)
+        for _ in range(2):                                   # twice: the second step reuses the arena and every side stream
+            losses = model.train_on_batch(inputs, rand_keys=keys, apply=False)
+        torch.cuda.synchronize()
+        res.append((losses.cpu().numpy(), eng.grads.cpu().numpy().copy()))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-6)
+    scale = np.abs(res[1][1]).max()
+    assert np.abs(res[0][1] - res[1][1]).max() <= 2e-5 * scale and scale > 0
+
+
 def test_device_rpn_targets_in_training_step(dev):
     """A step fed with rpn_match / rpn_bbox = None (targets built on the GPU, only the used GT-mask planes
     uploaded) equals the step fed with the oracle's host-built targets for the same draw keys."""
