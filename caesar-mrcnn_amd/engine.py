@@ -196,12 +196,13 @@ class MaskRCNNEngine(object):
         self.fused_dgrad_epilogue = True  # data-gradient convs of the mask head apply the lower layer's epilogue backward
         self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self.aux_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
-        # The mask head's weight gradients feed nothing in the backward chain.  Launched where their operands appear they run
-        # beside the mask head's data gradients -- two matrix-bound streams, no gain -- and the backbone's backward pass
-        # (some 330 small, latency-bound launches) then runs almost alone on the chip.  Deferred, they are issued on the
-        # auxiliary stream when the backbone's backward pass starts: the matrix-bound work fills the CUs the small kernels
-        # leave idle.  "wgrad_lds_pad" keeps one workgroup slot per CU free for those small kernels meanwhile.
-        self.defer_mask_wgrad = os.environ.get("MRCNN_DEFER_MASK_WGRAD", "1") != "0"
+        # A/B switch, default OFF (measured, DESIGN.md "rejected"): the mask head's weight gradients feed nothing in the
+        # backward chain, so they can be held back and issued (auxiliary stream) when the backbone's backward pass starts,
+        # to fill the chip beside its ~330 small launches; "wgrad_lds_pad" then keeps one workgroup slot per CU free for
+        # those.  Result on ResNet-101, 4 images, dense: 60.56 -> 60.26 ms (pad 0), 60.81 (pad 8192): the small kernels are
+        # paced by the matrix pipe of their SIMD (serial K chains of 64-cycle fp32 MFMAs), which the large kernel keeps
+        # 88 % busy -- beside it they run 4x slower (18 -> 73 us) and the large kernels 1.45x slower: zero sum.
+        self.defer_mask_wgrad = os.environ.get("MRCNN_DEFER_MASK_WGRAD", "0") != "0"
         self.defer_lds_pad = int(os.environ.get("MRCNN_DEFER_LDS_PAD", "8192"))
         self._deferred = []
         self.gather_roialign_bwd = os.environ.get("MRCNN_GATHER_ROIALIGN_BWD", "1") != "0"   # class-head ROIAlign adjoint in gather form

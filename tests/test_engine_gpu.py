@@ -492,7 +492,7 @@ def test_fused_mask_output_backward_equals_unfused(dev):
 
 @pytest.mark.parametrize("head_dtype", [None, "float16"])
 def test_deferred_mask_wgrad_equals_inline(dev, head_dtype):
-    """engine.defer_mask_wgrad only moves the mask head's weight-gradient launches (to the auxiliary stream, beside the
+    """engine.defer_mask_wgrad (an A/B switch, off by default) only moves the mask head's weight-gradient launches (to the auxiliary stream, beside the
     backbone's backward pass): same kernels on the same operands, so losses and the whole gradient buffer agree up to the
     float atomics of the other kernels.  ResNet-50 256x256 so that the large LDS-DMA weight-gradient kernel (and its
     occupancy cap) is the one that runs."""
