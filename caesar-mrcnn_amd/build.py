@@ -82,6 +82,15 @@ def _build_locked(force, verbose, extra_flags):
             if os.path.exists(tmp):
                 os.remove(tmp)
             raise RuntimeError("link of libmrcnn_hip.so failed:\n%s" % out[-4000:])
+        # hipcc can silently drop the host stub of a kernel template (seen with a dependent array bound captured by a
+        # lambda): the link succeeds, the library then fails to load.  Catch it here, with the name.
+        nm = shutil.which("nm")
+        if nm:
+            und = subprocess.run([nm, "-D", "--undefined-only", tmp], capture_output=True, text=True).stdout
+            missing = [l.split()[-1] for l in und.splitlines() if "__device_stub__" in l]
+            if missing:
+                os.remove(tmp)
+                raise RuntimeError("kernel host stubs missing after link (compiler dropped them): %s" % ", ".join(missing[:4]))
         os.replace(tmp, LIB_PATH)
     return LIB_PATH
 

@@ -12,6 +12,7 @@
 //                         [Cin][KH*KW*Cout] the data gradient uses, from the float32 HWIO master copy).
 //   cast kernels          float32 <-> 16-bit, elementwise.
 #include "common.h"
+#include <string.h>
 #include <type_traits>
 #include <utility>
 
@@ -45,20 +46,38 @@ __device__ __forceinline__ void h16_static_for(F&& f, std::integer_sequence<int,
     (f(std::integral_constant<int, I>{}), ...);
 }
 
-// NBUF = 2: double buffering, every wave waits for all its loads at each barrier (relies on 3 workgroups per CU to hide
-// the DMA latency).  NBUF = 4: a ring of four tile pairs with the loads issued THREE K-steps ahead and counted waits
-// (s_waitcnt vmcnt(12 / 6 / 0): the two younger stages stay in flight across the barrier) -- one workgroup per CU
-// (96 KiB LDS), latency hidden by prefetch distance instead of occupancy.
-template <typename T, int NBUF>
-__global__ __launch_bounds__(256, NBUF <= 3 ? 2 : 1) void conv_fwd_h16_kernel(const ConvH16Args p) {
+// s_waitcnt vmcnt(N) for a compile-time N (the immediate has to be in the instruction text)
+template <int N> __device__ __forceinline__ void h16_wait_vmcnt() {
+    static_assert(N == 0 || N == 4 || N == 6 || N == 8 || N == 12, "add the count");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+
+// Tile = (WAVES_M x 128) x (WAVES_N x 64), one wave per 128 x 64 (4 x 2 MFMA tiles of 32 x 32 x 16), K-step 32.
+//   <T, 2, 2, 2>  256 x 128, 4 waves, double buffering; every wave waits for all its loads at each barrier and the DMA
+//                 latency is hidden by 3 workgroups per CU (48 KiB LDS each).  24 KiB fetched per 2.1 MFLOP: at the
+//                 matrix rate that is 47 B/clk/CU out of L2 -- the kernel is operand-starved (PMC: 32 % MFMA-busy).
+//   <T, 4, 2, 4>  256 x 256, 8 waves (two per SIMD), ONE workgroup per CU: a ring of four 32 KiB stages with the loads
+//                 issued three K-steps ahead and counted waits (s_waitcnt vmcnt(8 / 4 / 0): the two younger stages
+//                 stay in flight across the raw s_barrier).  32 KiB per 4.2 MFLOP halves the L2 traffic per flop, and
+//                 with one 256-row tile per CU the nine shifted tap reads of a channel chunk (K is walked chunk-outer,
+//                 tap-inner) find their rows in the CU's own vector cache instead of evicting each other.
+template <typename T, int NBUF, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, NBUF <= 3 ? 2 : (WAVES_M * WAVES_N) / 4) void conv_fwd_h16_kernel(const ConvH16Args p) {
     typedef typename H16Traits<T>::v8 v8;
-    constexpr int BM = 256, BN = 128, TM = 4, TN = 2;
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int BM = WAVES_M * 128, BN = WAVES_N * 64, TM = 4, TN = 2;
     constexpr int ROWB = 64;                                    // bytes per LDS row (32 x 16-bit)
-    constexpr int AB = BM * ROWB, BB = BN * ROWB;               // 16 KiB + 8 KiB per buffer
+    constexpr int AB = BM * ROWB, BB = BN * ROWB;               // bytes per stage
+    constexpr int APW = BM / 16 / NW, BPW = BN / 16 / NW;       // 1 KiB DMA pieces (16 rows) per wave and stage
+    constexpr int DPS = APW + BPW;                              // DMA instructions per wave and stage
     __shared__ __attribute__((aligned(16))) char lds[NBUF * (AB + BB)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int ntiles = p.Cout / BN;
     const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x % ntiles;
     const int m0 = mtile * BM, n0 = ntile * BN;
@@ -68,12 +87,12 @@ __global__ __launch_bounds__(256, NBUF <= 3 ? 2 : 1) void conv_fwd_h16_kernel(co
         __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - p.x_shift), 0, p.x_records, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.w_records, 0x00020000);
 
-    // A: 16 pieces of 16 rows (this wave: pieces wave + 4 jj); lane (r, c) fetches logical 16-byte chunk c ^ ((r>>2)&3)
-    unsigned a_voff[4];
-    unsigned long long a_mask[4];
+    // A: BM / 16 pieces of 16 rows (this wave: pieces wave + NW jj); lane (r, c) fetches logical 16-byte chunk c ^ ((r>>2)&3)
+    unsigned a_voff[4];                                         // [APW] in use (fixed bounds: a dependent bound here made
+    unsigned long long a_mask[4];                               //  hipcc drop the kernel's host stub, see b_voff)
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int r = (wave + jj * 4) * 16 + (lane >> 2);
+    for (int jj = 0; jj < APW; ++jj) {
+        const int r = (wave + jj * NW) * 16 + (lane >> 2);
         const int cl = (lane & 3) ^ ((r >> 2) & 3);
         const int m = m0 + r;
         const bool ok = m < p.M;
@@ -91,11 +110,12 @@ __global__ __launch_bounds__(256, NBUF <= 3 ? 2 : 1) void conv_fwd_h16_kernel(co
             }
         a_mask[jj] = mk;
     }
-    // B = W^T [Cout][Ktot]: 8 pieces of 16 output channels
-    unsigned b_voff[2];
+    // B = W^T [Cout][Ktot]: BN / 16 pieces of 16 output channels
+    unsigned b_voff[2];                                         // [BPW] in use
+    static_assert(APW <= 4 && BPW <= 2, "piece bookkeeping arrays");
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int r = (wave + jj * 4) * 16 + (lane >> 2);
+    for (int jj = 0; jj < BPW; ++jj) {
+        const int r = (wave + jj * NW) * 16 + (lane >> 2);
         const int cl = (lane & 3) ^ ((r >> 2) & 3);
         b_voff[jj] = (unsigned)((((long long)(n0 + r)) * p.Ktot + cl * 8) * 2);
     }
@@ -107,13 +127,13 @@ __global__ __launch_bounds__(256, NBUF <= 3 ? 2 : 1) void conv_fwd_h16_kernel(co
         const unsigned soff_b = (unsigned)((tap * p.Cin + ci0) * 2);
         const unsigned long long bit = 1ull << tap;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
+        for (int jj = 0; jj < APW; ++jj) {
             const unsigned vo = (a_mask[jj] & bit) ? a_voff[jj] : H16_OOB_OFFSET;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (h16_lds_ptr)(ab + (wave + jj * 4) * 1024), 16, vo, soff_a, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (h16_lds_ptr)(ab + (wave + jj * NW) * 1024), 16, vo, soff_a, 0, 0);
         }
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (h16_lds_ptr)(bb + (wave + jj * 4) * 1024), 16, b_voff[jj], soff_b, 0, 0);
+        for (int jj = 0; jj < BPW; ++jj)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (h16_lds_ptr)(bb + (wave + jj * NW) * 1024), 16, b_voff[jj], soff_b, 0, 0);
         ++tap;                                                  // channel-chunk outer, filter-tap inner
         if (++kw == p.KW) { kw = 0; if (++kh == p.KH) { kh = 0; tap = 0; ci0 += 32; } }
     };
@@ -168,7 +188,7 @@ __global__ __launch_bounds__(256, NBUF <= 3 ? 2 : 1) void conv_fwd_h16_kernel(co
             }
         }
     } else {
-        constexpr int D = NBUF - 1;                             // prefetch distance in K-steps; 6 DMA instructions per stage and wave
+        constexpr int D = NBUF - 1;                             // prefetch distance in K-steps; DPS DMA instructions per stage and wave
         for (int s0 = 0; s0 < D && s0 < nk; ++s0) stage(lds + s0 * (AB + BB));
         for (int ks0 = 0; ks0 < nk; ks0 += NBUF) {
             h16_static_for([&](auto sc) {
@@ -176,9 +196,9 @@ __global__ __launch_bounds__(256, NBUF <= 3 ? 2 : 1) void conv_fwd_h16_kernel(co
                 const int ks = ks0 + S;
                 if (ks < nk) {
                     const int younger = nk - 1 - ks;            // stages issued after ks that may still be in flight (<= D - 1)
-                    if (D >= 3 && younger >= 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                    else if (younger >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (D >= 3 && younger >= 2) h16_wait_vmcnt<2 * DPS>();
+                    else if (younger >= 1) h16_wait_vmcnt<DPS>();
+                    else h16_wait_vmcnt<0>();
                     __builtin_amdgcn_s_barrier();               // stage ks has landed for every wave; everyone is done with stage ks - 1
                     if (ks + D < nk) stage(lds + ((S + D) % NBUF) * (AB + BB));
                     compute(std::integral_constant<int, S>{});
@@ -189,7 +209,7 @@ __global__ __launch_bounds__(256, NBUF <= 3 ? 2 : 1) void conv_fwd_h16_kernel(co
 
     // ---- epilogue: bias, frozen-BN affine, activation in float32; one rounding to 16 bits --------------
     // rows outermost: one output address per row (the transposed conv needs two divisions for it), then the wave's two
-    // column tiles -- keeps the number of live registers small (256 x 128 accumulators are already 128 of them)
+    // column tiles -- keeps the number of live registers small (128 x 64 accumulators per wave are already 128 of them)
     T* out = (T*)p.out;
     T* zo = (T*)p.z;
     const bool deconv = p.out_mode == MRCNN_OUT_DECONV2;        // column n = (a*2+b)*cmod + c -> pixel (2oh+a, 2ow+b), channel c
@@ -782,17 +802,36 @@ extern "C" int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const v
     a.M = (int)M; a.Ktot = d->KH * d->KW * d->Cin;
     a.x_shift = (unsigned)shift_b; a.x_records = (unsigned)(xbytes + shift_b); a.w_records = (unsigned)wbytes;
     a.out_mode = d->out_mode; a.cmod = d->cmod; a.ons = d->out_n_stride; a.ohs = d->out_h_stride; a.ows = d->out_w_stride;
+    // Tile choice (read per call so that tests and A/B timings can switch: MRCNN_H16_TILE = big | small | ring):
+    //   big    256 x 256, 8 waves, 4-stage ring, one workgroup per CU -- Cout % 256 == 0 and at least one full round of tiles
+    //   small  256 x 128, 4 waves, double buffered, 3 workgroups per CU (the round-1 kernel; everything else)
+    //   ring   256 x 128 with a 3-slot ring (round-1 experiment)
+    const char* tile = getenv("MRCNN_H16_TILE");
+    const long long big_tiles = ((M + 255) / 256) * (d->Cout / 256);
+    // default: small.  Isolated, big is 3-5 % faster on the mask-head shape (770-810 vs 745-795 TFLOP/s); in the training
+    // step its 128 KiB of LDS cannot share a CU with the weight-gradient stream's 48 KiB workgroups.  Both stop at ~30 %
+    // of the matrix peak: per K-step a wave spends about as long issuing its LDS-DMA pieces and waiting for operand reads
+    // as the matrix pipe needs for its 16 MFMAs, and the two waves of a SIMD do it in lockstep.  De-phasing them in HIP
+    // source (second wave group computes before it prefetches) made hipcc spill the 128 accumulator registers both ways
+    // tried (branch-duplicated bodies: 175 TFLOP/s; two-trip selector loop: 256 VGPRs + 260 B scratch).
+    bool big = false;
+    if (tile && !strcmp(tile, "big")) big = d->Cout % 256 == 0;
+    const bool ring = (tile && !strcmp(tile, "ring")) || getenv("MRCNN_H16_RING") != nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    if (big) {
+        const unsigned blocks = (unsigned)big_tiles;
+        if (dtype == MRCNN_DTYPE_F16) hipLaunchKernelGGL((conv_fwd_h16_kernel<_Float16, 4, 2, 4>), dim3(blocks), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((conv_fwd_h16_kernel<__bf16, 4, 2, 4>), dim3(blocks), dim3(512), 0, s, a);
+        return mrcnn_launch_status();
+    }
     const unsigned blocks = (unsigned)(((M + 255) / 256) * (d->Cout / 128));
-    static const bool ring = getenv("MRCNN_H16_RING") != nullptr;  // A/B switch: 3-slot ring (faster in isolation, slower in the step)
     if (ring) {
-        if (dtype == MRCNN_DTYPE_F16)
-            hipLaunchKernelGGL((conv_fwd_h16_kernel<_Float16, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-        else
-            hipLaunchKernelGGL((conv_fwd_h16_kernel<__bf16, 3>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        if (dtype == MRCNN_DTYPE_F16) hipLaunchKernelGGL((conv_fwd_h16_kernel<_Float16, 3, 2, 2>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_fwd_h16_kernel<__bf16, 3, 2, 2>), dim3(blocks), dim3(256), 0, s, a);
     } else if (dtype == MRCNN_DTYPE_F16)
-        hipLaunchKernelGGL((conv_fwd_h16_kernel<_Float16, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv_fwd_h16_kernel<_Float16, 2, 2, 2>), dim3(blocks), dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL((conv_fwd_h16_kernel<__bf16, 2>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL((conv_fwd_h16_kernel<__bf16, 2, 2, 2>), dim3(blocks), dim3(256), 0, s, a);
     return mrcnn_launch_status();
 }
 
