@@ -115,6 +115,7 @@ _SIGNATURES = {
     "mrcnn_cast_to_h16": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "mrcnn_epilogue_bwd_h16": (C.c_int, [C.c_int] + [_P] * 10 + [C.c_int64, C.c_int, C.c_int, C.c_float, _P]),
     "mrcnn_cast_from_h16": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_float, _P]),
+    "mrcnn_axpy_from_h16": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "mrcnn_rpn_targets_workspace": (C.c_size_t, [C.POINTER(RpnTargetDesc)]),
     "mrcnn_rpn_targets": (C.c_int, [C.POINTER(RpnTargetDesc)] + [_P] * 7 + [C.c_size_t, _P]),
     "mrcnn_detection_workspace": (C.c_size_t, [C.POINTER(DetectionDesc)]),

@@ -417,10 +417,15 @@ __global__ void weights_to_h16_kernel(const float* __restrict__ w, T* wt_f, T* w
 
 template <typename T>
 __global__ void cast_to_h16_kernel(const float* __restrict__ src, T* dst, long long n, float mul) {
+    typedef T t4 __attribute__((ext_vector_type(4)));
     const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
     if (i + 3 < n) {
         const f32x4 v = *(const f32x4*)(src + i);
-        dst[i] = (T)(v[0] * mul); dst[i + 1] = (T)(v[1] * mul); dst[i + 2] = (T)(v[2] * mul); dst[i + 3] = (T)(v[3] * mul);
+        t4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = (T)(v[k] * mul);
+        if ((reinterpret_cast<uintptr_t>(dst + i) & 7) == 0) *(t4*)(dst + i) = o;
+        else { dst[i] = o[0]; dst[i + 1] = o[1]; dst[i + 2] = o[2]; dst[i + 3] = o[3]; }
     } else {
         for (long long j = i; j < n; ++j) dst[j] = (T)(src[j] * mul);
     }
@@ -503,10 +508,28 @@ __global__ __launch_bounds__(256) void epilogue_bwd_h16_kernel(const T* __restri
     }
 }
 
-template <typename T>
-__global__ void cast_from_h16_kernel(const T* __restrict__ src, float* dst, long long n, float mul) {
-    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    for (long long j = i; j < i + 4 && j < n; ++j) dst[j] = (float)src[j] * mul;
+// 8 elements per thread when n % 8 == 0 and both pointers are 16-byte aligned (every tensor of the engine); ACC: dst += src * mul
+template <typename T, bool ACC>
+__global__ void cast_from_h16_kernel(const T* __restrict__ src, float* dst, long long n, float mul, int vec) {
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const long long i = t * 8;
+        if (i >= n) return;
+        const t8 v = *(const t8*)(src + i);
+        f32x4 lo, hi;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { lo[k] = (float)v[k] * mul; hi[k] = (float)v[4 + k] * mul; }
+        if (ACC) {
+            const f32x4 a = *(const f32x4*)(dst + i), b = *(const f32x4*)(dst + i + 4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { lo[k] += a[k]; hi[k] += b[k]; }
+        }
+        *(f32x4*)(dst + i) = lo;
+        *(f32x4*)(dst + i + 4) = hi;
+        return;
+    }
+    for (long long j = t * 8; j < t * 8 + 8 && j < n; ++j) dst[j] = (ACC ? dst[j] : 0.f) + (float)src[j] * mul;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -938,15 +961,25 @@ extern "C" int mrcnn_cast_to_h16(const float* src, void* dst, int64_t n, int dty
     return mrcnn_launch_status();
 }
 
-extern "C" int mrcnn_cast_from_h16(const void* src, float* dst, int64_t n, int dtype, float multiplier, void* stream) {
+template <bool ACC>
+static int launch_cast_from_h16(const void* src, float* dst, int64_t n, int dtype, float multiplier, void* stream) {
     if (!src || !dst || n < 0 || !h16_dtype_ok(dtype)) return MRCNN_ERR_ARG;
     if (n == 0) return 0;
-    const unsigned blocks = (unsigned)cdiv64(cdiv64(n, 4), 256);
+    const int vec = (n % 8 == 0) && ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const unsigned blocks = (unsigned)cdiv64(cdiv64(n, 8), 256);
     if (dtype == MRCNN_DTYPE_F16)
-        hipLaunchKernelGGL(cast_from_h16_kernel<_Float16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src, dst,
-                           (long long)n, multiplier);
+        hipLaunchKernelGGL((cast_from_h16_kernel<_Float16, ACC>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)src,
+                           dst, (long long)n, multiplier, vec);
     else
-        hipLaunchKernelGGL(cast_from_h16_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src, dst,
-                           (long long)n, multiplier);
+        hipLaunchKernelGGL((cast_from_h16_kernel<__bf16, ACC>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)src, dst,
+                           (long long)n, multiplier, vec);
     return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_cast_from_h16(const void* src, float* dst, int64_t n, int dtype, float multiplier, void* stream) {
+    return launch_cast_from_h16<false>(src, dst, n, dtype, multiplier, stream);
+}
+
+extern "C" int mrcnn_axpy_from_h16(const void* src, float* dst, int64_t n, int dtype, float multiplier, void* stream) {
+    return launch_cast_from_h16<true>(src, dst, n, dtype, multiplier, stream);
 }

@@ -18,6 +18,12 @@ from . import ops
 from ._hip import ACT_NONE, ACT_RELU, ACT_SIGMOID, RES_NONE, RES_SAME, RES_UP2
 from .params import ParamLayout, deconv_gemm_to_keras, deconv_keras_to_gemm, granule_coefficients, init_weights
 
+# configs[4], stage 3: besides the mask head, these layers run on the 16-bit matrix cores when head_dtype is set (and
+# their shapes fit the 16-bit kernels): the FPN smoothing convolutions, the shared RPN convolution over all five levels,
+# and the two FC layers of the class head (K = 12 544: weight-bandwidth halves) -- 82 of the 161 GFLOP per image of the
+# 512 x 512 trunk.  float32 at their boundaries (casts), float32 master weights, accumulation and gradients.
+H16_WIDE_LAYERS = ("fpn_p2", "fpn_p3", "fpn_p4", "fpn_p5", "rpn_conv_shared", "mrcnn_class_conv1", "mrcnn_class_conv2")
+
 LOSS_NAMES = ("rpn_class_loss", "rpn_bbox_loss", "mrcnn_class_loss", "mrcnn_bbox_loss", "mrcnn_mask_loss")
 
 
@@ -183,12 +189,14 @@ class MaskRCNNEngine(object):
         self.grad_ranges = {"heads": (hd, L.gamma_offset), "tail": (fp, hd), 5: (s5, fp), 4: (s4, s5), 3: (s3, s4),
                             2: (s2, s3), "head": (0, s2), "bn": (L.gamma_offset, L.total)}
         self.grad_ready = None          # callable(start, end) or None
+        self.forced_rpn_rois = None     # test hook: [B, POST_NMS_ROIS_TRAINING, 4] used instead of the ProposalLayer's output
         self.sparse_mask_bwd = True     # skip the exactly-zero rows of the mask-head backward
         # BASELINE configs[4], stage 1: torch.float16 / torch.bfloat16 runs the four 3x3 convolutions of the mask head
         # (forward, data and weight gradient) on the 16-bit matrix cores; master weights, accumulation and every
         # gradient buffer stay float32.  None (default) = float32 everywhere.  loss_scale guards float16 gradients.
         self.head_dtype = None
         self.loss_scale = 4096.0
+        self.h16_wide = os.environ.get("MRCNN_H16_WIDE", "1") != "0"   # False: only the mask head in 16 bits (round-1 stages 1-2)
         self._h16 = {}
         self._h16_store = {}            # dtype -> {layer: (W^T image, data-gradient image)}, stable addresses
         self._h16_valid = False
@@ -250,16 +258,16 @@ class MaskRCNNEngine(object):
             dz.record_stream(ws)
             x.record_stream(ws)
 
-    def wgrad_h16_async(self, x, dz, wshape, dw, multiplier):
+    def wgrad_h16_async(self, x, dz, wshape, dw, multiplier, padding="same", accumulate=False):
         ws = self.wgrad_stream
         if ws is None:
-            ops.conv2d_wgrad_h16(x, dz, wshape, 1, "same", dw=dw, multiplier=multiplier)
+            ops.conv2d_wgrad_h16(x, dz, wshape, 1, padding, dw=dw, accumulate=accumulate, multiplier=multiplier)
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(ws):
             ws.wait_event(ev)
-            ops.conv2d_wgrad_h16(x, dz, wshape, 1, "same", dw=dw, multiplier=multiplier)
+            ops.conv2d_wgrad_h16(x, dz, wshape, 1, padding, dw=dw, accumulate=accumulate, multiplier=multiplier)
         dz.record_stream(ws)
         x.record_stream(ws)
 
@@ -271,10 +279,61 @@ class MaskRCNNEngine(object):
         # their addresses, so a weight update must never move them
         imgs = self._h16_store.setdefault(self.head_dtype, {})
         names = ["mrcnn_mask_conv%d" % i for i in range(1, 5)] + ["mrcnn_mask_deconv"]   # deconv: GEMM matrix [Cin, 4*Cd]
+        if self.h16_wide:
+            names += [n for n in H16_WIDE_LAYERS if self._h16_shape_ok(self.op(n))]
         for name in names:
-            imgs[name] = ops.weights_to_h16(self.op(name).w, self.head_dtype, out=imgs.get(name))
+            op = self.op(name)
+            if op.padding == "valid" and op.wshape[0] > 1:
+                # "FC as VALID conv" (mrcnn_class_conv1): forward image W^T as usual; its data gradient is the GEMM
+                # dx[M, K] = dz[M, Cout] . W^T, whose operand image [K][Cout] is the HWIO kernel itself, in 16 bits
+                kh, kw, cin, cout = op.wshape
+                old = imgs.get(name)
+                wf, _ = ops.weights_to_h16(op.w, self.head_dtype, want_dgrad=False, out=None if old is None else (old[0], None))
+                wn = old[1] if old is not None else torch.empty((kh * kw * cin, cout), dtype=self.head_dtype, device=self.dev)
+                ops.cast_to_h16(op.w.view(kh * kw * cin, cout), self.head_dtype, out=wn)   # never from the step arena
+                imgs[name] = (wf, wn)
+            else:
+                imgs[name] = ops.weights_to_h16(op.w, self.head_dtype, out=imgs.get(name))
         self._h16 = dict(imgs, dtype=self.head_dtype)
         self._h16_valid = True
+
+    @staticmethod
+    def _h16_shape_ok(op):
+        """Shapes the 16-bit kernels take: forward Cin % 32 == 0, Cout % 128 == 0; weight gradient Cin % 256 == 0."""
+        kh, kw, cin, cout = op.wshape
+        return op.stride == 1 and cin % 256 == 0 and cout % 128 == 0 and kh * kw <= 64
+
+    def _h16_layer(self, name):
+        """True when layer `name` runs on the 16-bit matrix cores in the current mode."""
+        return self.head_dtype is not None and self.h16_wide and name in H16_WIDE_LAYERS and self._h16_shape_ok(self.op(name))
+
+    def _h16_fwd(self, op, x16, act, train):
+        """conv + bias + frozen BN + activation of layer `op` on a 16-bit input: 16-bit result; ctx for _h16_bwd."""
+        d = ops.conv_desc(tuple(x16.shape), op.wshape, op.stride, op.padding, act)
+        z = ops.empty((d.N, d.OH, d.OW, d.Cout), x16.dtype, x16.device) if (train and op.bn) else None
+        y = ops.conv2d_h16(x16, self._h16[op.name][0], op.wshape, op.b, op.scale, op.shift, op.stride, op.padding, act, z_out=z)
+        return y, ((x16, z, y, act) if train else None)
+
+    def _h16_bwd(self, op, d16, ctx, S, accumulate_w=False, need_dx=True):
+        """Backward of _h16_fwd.  d16: gradient w.r.t. the activated output, 16 bit, times the loss scale S.  Bias / BN
+        sums and the weight gradient land unscaled in the float32 gradient buffer; returns dx (16 bit, times S)."""
+        x16, z, y, act = ctx
+        dz = ops.epilogue_bwd_h16(d16, y if act != ACT_NONE else None, z, op.scale, op.mean, op.rstd, op.dgamma, op.dbeta, op.db,
+                                  act, 1.0 / S)
+        self.wgrad_h16_async(x16, dz, op.wshape, op.dw, 1.0 / S, op.padding, accumulate_w)
+        if not need_dx:
+            return None
+        kh, kw, cin, cout = op.wshape
+        if op.padding == "valid" and kh > 1:                     # FC as VALID conv: one GEMM over the flattened window
+            M = dz.shape[0]
+            dx = ops.conv2d_h16(dz.view(M, 1, 1, cout), self._h16[op.name][1], (1, 1, cout, kh * kw * cin), None, None, None, 1,
+                                "valid", ACT_NONE)
+            return dx.view(M, kh, kw, cin)
+        return ops.conv2d_h16(dz, self._h16[op.name][1], (kh, kw, cout, cin), None, None, None, 1,
+                              ((kh - 1) // 2, (kw - 1) // 2) if op.padding == "same" else "valid", ACT_NONE)
+
+    def _S(self):
+        return float(self.loss_scale) if self.head_dtype == torch.float16 else 1.0
 
     # ---- independent small convolutions in one launch (mrcnn_conv2d_fwd_multi) ------------------------
     def _forward_multi(self, layers, xs, act=ACT_NONE, train=False):
@@ -463,6 +522,18 @@ class MaskRCNNEngine(object):
         P3s, tape["fpn_c3p3"] = self.op("fpn_c3p3").forward(C3, res=P4s, res_mode=RES_UP2, train=train)
         P2s, tape["fpn_c2p2"] = self.op("fpn_c2p2").forward(C2, res=P3s, res_mode=RES_UP2, train=train)
         names = ("fpn_p2", "fpn_p3", "fpn_p4", "fpn_p5")
+        self._p16 = None
+        if all(self._h16_layer(n) for n in names):
+            self._ensure_h16()
+            outs, p16 = [], []
+            for n, x in zip(names, (P2s, P3s, P4s, P5s)):
+                y16, tape[n] = self._h16_fwd(self.op(n), ops.cast_to_h16(x, self.head_dtype), ACT_NONE, train)
+                p16.append(y16)
+                outs.append(ops.cast_from_h16(y16))             # float32 copies for ROIAlign and P6
+            P2, P3, P4, P5 = outs
+            P6 = ops.subsample2(P5)
+            self._p16 = p16 + [ops.cast_to_h16(P6, self.head_dtype)]
+            return [P2, P3, P4, P5, P6], tape
         res = self._forward_multi([self.op(n) for n in names], [P2s, P3s, P4s, P5s], train=train)
         (P2, P3, P4, P5) = [r[0] for r in res]
         for n, r in zip(names, res):
@@ -480,9 +551,16 @@ class MaskRCNNEngine(object):
         bbox = ops.empty((B, A, 4), torch.float32, self.dev)
         shared, cls, box = self.op("rpn_conv_shared"), self.op("rpn_class_raw"), self.op("rpn_bbox_pred")
         tape, off = [], 0
+        h16 = self._h16_layer("rpn_conv_shared") and self.multi_launch and len(pyramid) <= 5
+        if h16:
+            self._ensure_h16()
+            p16 = self._p16 if self._p16 is not None else [ops.cast_to_h16(p, self.head_dtype) for p in pyramid]
+            s16 = [self._h16_fwd(shared, x16, ACT_RELU, train) for x16 in p16]
+            ss = [ops.cast_from_h16(y) for y, _ in s16]          # the two small heads (6 / 12 columns) stay float32
         if self.multi_launch and len(pyramid) <= 5:
             # the levels are independent and P3..P6 are a handful of workgroups each: one launch per layer for all levels
-            ss = ops.conv2d_multi([dict(x=p, w=shared.w, bias=shared.b, act=ACT_RELU) for p in pyramid])
+            if not h16:
+                ss = ops.conv2d_multi([dict(x=p, w=shared.w, bias=shared.b, act=ACT_RELU) for p in pyramid])
             assert ss is not None                       # one weight tensor: the levels always share a launch shape
             offs = []
             for p in pyramid:
@@ -492,8 +570,10 @@ class MaskRCNNEngine(object):
                                    out_strides=(A * 2, s.shape[2] * 2 * na, 2 * na)) for s, o in zip(ss, offs)])
             ops.conv2d_multi([dict(x=s, w=box.w, bias=box.b, padding="valid", out_ptr=bbox.data_ptr() + o * 4 * 4,
                                    out_strides=(A * 4, s.shape[2] * 4 * na, 4 * na)) for s, o in zip(ss, offs)])
-            for p, s, o in zip(pyramid, ss, offs):
-                tape.append(((p, None, s, ACT_RELU) if train else None, (s, None, None, ACT_NONE), o, p.shape[1], p.shape[2]))
+            for lvl, (p, s, o) in enumerate(zip(pyramid, ss, offs)):
+                cs = (s16[lvl][1] if h16 else (p, None, s, ACT_RELU)) if train else None
+                tape.append((cs, (s, None, None, ACT_NONE), o, p.shape[1], p.shape[2]))
+            self._p16 = None
             return logits, ops.softmax_rows(logits), bbox, tape
         for p in pyramid:
             s, cs = shared.forward(p, ACT_RELU, train=train)
@@ -511,8 +591,14 @@ class MaskRCNNEngine(object):
         B, R = rois.shape[0], rois.shape[1]
         pooled = ops.roialign(rois, fms, cfg.POOL_SIZE, image_area)
         x = pooled.view(B * R, cfg.POOL_SIZE, cfg.POOL_SIZE, -1)
-        h1, c1 = self.op("mrcnn_class_conv1").forward(x, ACT_RELU, train=train)
-        h2, c2 = self.op("mrcnn_class_conv2").forward(h1, ACT_RELU, train=train)
+        if self._h16_layer("mrcnn_class_conv1") and self._h16_layer("mrcnn_class_conv2"):
+            self._ensure_h16()
+            h1, c1 = self._h16_fwd(self.op("mrcnn_class_conv1"), ops.cast_to_h16(x, self.head_dtype), ACT_RELU, train)
+            h2_16, c2 = self._h16_fwd(self.op("mrcnn_class_conv2"), h1, ACT_RELU, train)
+            h2 = ops.cast_from_h16(h2_16)                        # the 4- / 16-column output layers stay float32
+        else:
+            h1, c1 = self.op("mrcnn_class_conv1").forward(x, ACT_RELU, train=train)
+            h2, c2 = self.op("mrcnn_class_conv2").forward(h1, ACT_RELU, train=train)
         lg, c3 = self.op("mrcnn_class_logits").forward(h2, train=train)
         bb, c4 = self.op("mrcnn_bbox_fc").forward(h2, train=train)
         logits = lg.view(B, R, cfg.NUM_CLASSES)
@@ -641,15 +727,20 @@ class MaskRCNNEngine(object):
         if self.wgrad_stream is not None:
             ev0 = torch.cuda.Event()
             ev0.record(torch.cuda.current_stream(self.dev))
+            h16_ev = None
             with torch.cuda.stream(self.wgrad_stream):
                 self.wgrad_stream.wait_event(ev0)
+                if self.head_dtype is not None:
+                    self._ensure_h16()                 # 16-bit weight images: first needed by the FPN (wide mode) / after the trunk
+                    h16_ev = torch.cuda.Event()
+                    h16_ev.record(self.wgrad_stream)
                 ops.fill_zero(self.grads)
                 if not self.wt_valid:
                     self.refresh_wt()
-                if self.head_dtype is not None:
-                    self._ensure_h16()                 # 16-bit weight images of the mask head: first needed after the trunk
             prep_ev = torch.cuda.Event()
             prep_ev.record(self.wgrad_stream)
+            if h16_ev is not None and self.h16_wide:
+                torch.cuda.current_stream(self.dev).wait_event(h16_ev)
         else:
             ops.fill_zero(self.grads)
             if not self.wt_valid:
@@ -659,6 +750,8 @@ class MaskRCNNEngine(object):
         anchors = self.anchors((H, W, images.shape[3]))
         rpn_rois = ops.proposals(rpn_probs, rpn_bbox, anchors, cfg.PRE_NMS_LIMIT, cfg.POST_NMS_ROIS_TRAINING,
                                  cfg.RPN_NMS_THRESHOLD, np.asarray(cfg.RPN_BBOX_STD_DEV, np.float32))
+        if self.forced_rpn_rois is not None:     # tests: compare two precisions of the differentiable part on one ROI set
+            rpn_rois = self.forced_rpn_rois
         rois, tcls, tbbox, tmask, assign, counts = ops.detection_targets(
             rpn_rois, gt_class_ids, gt_boxes_norm, gt_masks, rand_keys, cfg.TRAIN_ROIS_PER_IMAGE,
             cfg.ROI_POSITIVE_RATIO, cfg.BBOX_STD_DEV, cfg.MASK_SHAPE, cfg.USE_MINI_MASK)
@@ -853,12 +946,17 @@ class MaskRCNNEngine(object):
         bo.wgrad(dz, c4)
         bo.dgrad(dz, c4, out=d_h2, accumulate=True)
         op2, op1 = self.op("mrcnn_class_conv2"), self.op("mrcnn_class_conv1")
-        dz, _ = op2.epilogue_bwd(d_h2, c2)
-        op2.wgrad(dz, c2)
-        d_h1 = op2.dgrad(dz, c2)
-        dz, _ = op1.epilogue_bwd(d_h1, c1)
-        op1.wgrad(dz, c1)
-        d_pool = op1.dgrad(dz, c1)
+        if c2[0].dtype != torch.float32:                        # the two FC layers ran in 16 bits
+            S = self._S()
+            d_h1 = self._h16_bwd(op2, ops.cast_to_h16(d_h2, self.head_dtype, multiplier=S), c2, S)
+            d_pool = ops.cast_from_h16(self._h16_bwd(op1, d_h1, c1, S), 1.0 / S)
+        else:
+            dz, _ = op2.epilogue_bwd(d_h2, c2)
+            op2.wgrad(dz, c2)
+            d_h1 = op2.dgrad(dz, c2)
+            dz, _ = op1.epilogue_bwd(d_h1, c1)
+            op1.wgrad(dz, c1)
+            d_pool = op1.dgrad(dz, c1)
         B, R = rois.shape[0], rois.shape[1]
         ops.roialign_bwd(rois, d_pool.view(B, R, cfg.POOL_SIZE, cfg.POOL_SIZE, -1), dP, cfg.POOL_SIZE, area,
                          dense=self.gather_roialign_bwd)
@@ -886,6 +984,15 @@ class MaskRCNNEngine(object):
                 heads.append(chead)
             d_s = self._dgrad_multi([cls] * n, dzl, heads)
             self._dgrad_multi([box] * n, dzb, heads, outs=d_s, accumulate=True)
+            if self._h16_layer("rpn_conv_shared") and rpn_tape[0][0][0].dtype != torch.float32:
+                S = self._S()
+                for lvl, (cs, chead, off, H, W) in enumerate(rpn_tape):
+                    dx16 = self._h16_bwd(shared, ops.cast_to_h16(d_s[lvl], self.head_dtype, multiplier=S), cs, S, accumulate_w=lvl > 0)
+                    if lvl < 4:
+                        ops.axpy_from_h16(dx16, dP[lvl], 1.0 / S)       # P2..P5 also feed the ROI heads: add to their gradients
+                    else:
+                        dP6 = ops.cast_from_h16(dx16, 1.0 / S)
+                return dP6
             dzs, ctxs = [], []
             for lvl, (cs, chead, off, H, W) in enumerate(rpn_tape):
                 dz, _ = shared.epilogue_bwd(d_s[lvl], cs)
@@ -917,12 +1024,18 @@ class MaskRCNNEngine(object):
         dP2, dP3, dP4, dP5 = dP
         ops.subsample2_bwd_acc(dP6, dP5)
         layers, dzs, cs = [], [], []
-        for name, g in (("fpn_p5", dP5), ("fpn_p4", dP4), ("fpn_p3", dP3), ("fpn_p2", dP2)):
-            op, c = self.op(name), tape[name]
-            dz, _ = op.epilogue_bwd(g, c)
-            layers.append(op); dzs.append(dz); cs.append(c)
-        self.wgrad_group([op.wgrad_item(dz, c) for op, dz, c in zip(layers, dzs, cs)])
-        d5s, d4s, d3s, d2s = self._dgrad_multi(layers, dzs, cs)        # four independent 3x3 data gradients: one launch
+        if tape["fpn_p5"][0].dtype != torch.float32:                 # smoothing convolutions ran in 16 bits
+            S = self._S()
+            d16 = [self._h16_bwd(self.op(name), ops.cast_to_h16(g, self.head_dtype, multiplier=S), tape[name], S)
+                   for name, g in (("fpn_p5", dP5), ("fpn_p4", dP4), ("fpn_p3", dP3), ("fpn_p2", dP2))]
+            d5s, d4s, d3s, d2s = [ops.cast_from_h16(t, 1.0 / S) for t in d16]
+        else:
+            for name, g in (("fpn_p5", dP5), ("fpn_p4", dP4), ("fpn_p3", dP3), ("fpn_p2", dP2)):
+                op, c = self.op(name), tape[name]
+                dz, _ = op.epilogue_bwd(g, c)
+                layers.append(op); dzs.append(dz); cs.append(c)
+            self.wgrad_group([op.wgrad_item(dz, c) for op, dz, c in zip(layers, dzs, cs)])
+            d5s, d4s, d3s, d2s = self._dgrad_multi(layers, dzs, cs)    # four independent 3x3 data gradients: one launch
         ops.upsample2_bwd(d2s, d3s, True)
         ops.upsample2_bwd(d3s, d4s, True)
         ops.upsample2_bwd(d4s, d5s, True)

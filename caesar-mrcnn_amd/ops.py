@@ -736,3 +736,12 @@ def cast_from_h16(src, multiplier=1.0, out=None):
     check(_hip.lib().mrcnn_cast_from_h16(ptr(src), ptr(out), src.numel(), _H16[src.dtype], float(multiplier),
                                          current_stream()), "mrcnn_cast_from_h16")
     return out
+
+
+def axpy_from_h16(src, dst, multiplier=1.0):
+    """dst (float32) += multiplier * src (16 bit), elementwise."""
+    _need_cuda(src, dst)
+    assert dst.dtype == torch.float32 and dst.numel() == src.numel()
+    check(_hip.lib().mrcnn_axpy_from_h16(ptr(src), ptr(dst), src.numel(), _H16[src.dtype], float(multiplier), current_stream()),
+          "mrcnn_axpy_from_h16")
+    return dst

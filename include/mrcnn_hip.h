@@ -282,6 +282,9 @@ int mrcnn_mask_out_bwd_h16(int dtype, const float* d_mask_out, const float* mask
                            int C, float loss_scale, void* stream);
 int mrcnn_cast_to_h16(const float* src, void* dst, int64_t n, int dtype, float multiplier, void* stream);
 int mrcnn_cast_from_h16(const void* src, float* dst, int64_t n, int dtype, float multiplier, void* stream);
+/* dst[i] += multiplier * src[i]: a 16-bit data gradient (scaled by the loss scale) added to a float32 accumulator, e.g.
+ * the RPN's contribution to the pyramid gradients the ROI heads have already written (fan-out of P2..P5, model.py:2040). */
+int mrcnn_axpy_from_h16(const void* src, float* dst, int64_t n, int dtype, float multiplier, void* stream);
 
 /* build_rpn_targets (mrcnn/model.py:1536-1644), the per-image RPN target builder of the CPU input
  * pipeline, for one batch on the device.  anchors [A,4] float64 pixels (utils.generate_pyramid_anchors);

@@ -133,12 +133,15 @@ def test_casts(dev):
         assert torch.equal(ops.cast_from_h16(h, 0.5), h.float() * 0.5)
 
 
+@pytest.mark.parametrize("wide", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_mixed_precision_mask_head_training_step(dev, dtype):
-    """engine.head_dtype: the four mask-head convolutions on the 16-bit matrix cores (forward, data and weight
-    gradient), everything else float32.  Against the all-float32 engine on the same batch: losses to 1e-2, every
-    gradient tensor to 4e-2 of its float32 maximum (f16: 11-bit operands; bf16: 8-bit operands), and the
-    gradients of the layers that never see 16-bit data through the mask branch only via the pyramid sum."""
+def test_mixed_precision_training_step(dev, dtype, wide):
+    """engine.head_dtype: the mask head (wide=False: stages 1-2) and, with engine.h16_wide, also the FPN smoothing
+    convolutions, the shared RPN convolution and the two class-head FC layers (stage 3) on the 16-bit matrix cores --
+    forward, data and weight gradient -- everything else float32.  Against the all-float32 engine on the same batch
+    and the SAME proposals (the float32 run's ProposalLayer output is forced into the 16-bit run: RPN scores that
+    differ in the 4th digit re-order the NMS and would change the sampled ROIs, i.e. compare two different problems):
+    losses to 1e-2 (f16) / 4e-2 (bf16), every gradient tensor to 4x that of its float32 maximum."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import test_engine_gpu as T
     from caesar_mrcnn_amd.model import MaskRCNN
@@ -146,12 +149,19 @@ def test_mixed_precision_mask_head_training_step(dev, dtype):
     w = T._weights(cfg, 31)
     inputs, keys = T._train_inputs(cfg, 2, 33)
     res = {}
+    forced = None
     for mode in (None, dtype):
         model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
-        model.engine.head_dtype = mode
-        losses = model.train_on_batch(inputs, rand_keys=keys, apply=False)
+        eng = model.engine
+        eng.head_dtype, eng.h16_wide = mode, wide
+        eng.forced_rpn_rois = forced
+        losses = model.train_on_batch(inputs, rand_keys=keys, apply=False, keep_outputs=True)
         torch.cuda.synchronize()
-        res[mode] = (losses.cpu().numpy(), model.engine.get_weights(grads=True))
+        if mode is None:
+            forced = eng.last["rpn_rois"].clone()
+        else:
+            assert eng._h16_layer("rpn_conv_shared") == wide and eng._h16_layer("mrcnn_class_conv1") == wide
+        res[mode] = (losses.cpu().numpy(), eng.get_weights(grads=True))
     tol = 1e-2 if dtype == torch.float16 else 4e-2
     np.testing.assert_allclose(res[dtype][0], res[None][0], rtol=tol)
     bad = []
@@ -161,8 +171,9 @@ def test_mixed_precision_mask_head_training_step(dev, dtype):
         if err > 4 * tol:
             bad.append((name, err))
     assert not bad, bad[:6]
-    g = res[dtype][1]["mrcnn_mask_conv2/kernel"]
-    assert np.abs(g).max() > 0 and np.isfinite(g).all()
+    for name in ("mrcnn_mask_conv2/kernel", "rpn_conv_shared/kernel", "fpn_p3/kernel", "mrcnn_class_conv1/kernel"):
+        g = res[dtype][1][name]
+        assert np.abs(g).max() > 0 and np.isfinite(g).all(), name
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
