@@ -106,6 +106,8 @@ _SIGNATURES = {
     "mrcnn_proposal_fwd": (C.c_int, [C.POINTER(ProposalDesc)] + [_P] * 8 + [C.c_size_t, _P]),
     "mrcnn_detection_targets": (C.c_int, [C.POINTER(DetTargetDesc)] + [_P] * 12),
     "mrcnn_conv2d_fwd_h16": (C.c_int, [C.POINTER(ConvDesc), C.c_int] + [_P] * 8),
+    "mrcnn_conv2d_fwd_h16_res": (C.c_int, [C.POINTER(ConvDesc), C.c_int] + [_P] * 9),
+    "mrcnn_conv2d_fwd_h16_supported": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
     "mrcnn_conv2d_dgrad_ep": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, C.POINTER(BwdEpilogue), _P, C.c_size_t, _P]),
     "mrcnn_conv2d_wgrad_h16_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "mrcnn_conv2d_wgrad_h16": (C.c_int, [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_float, _P]),

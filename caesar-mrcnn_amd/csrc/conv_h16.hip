@@ -37,6 +37,8 @@ struct ConvH16Args {
     int N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW, act, M, Ktot;
     unsigned x_shift, x_records, w_records;
     int out_mode, cmod; long long ons, ohs, ows;     // MRCNN_OUT_DECONV2: pixel-shuffle store of the 2x2 transposed conv
+    const void* res;                                 // small-tile kernel: 16-bit tensor added before the activation (strides of out)
+    int dense;                                       // out is plain NHWC [M][Cout]
 };
 
 #define H16_OOB_OFFSET 0xFFFFFFF0u
@@ -251,6 +253,148 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, NBUF <= 3 ? 2 : (WAVES_M * 
                 out[addr] = (T)y;
             }
         }
+    }
+}
+
+// Small-tile variant for the layers of the trunk (feature maps of 1 024 .. 16 384 pixels, Cin / Cout multiples of 64):
+// 64 x 64 output tile, 4 waves of 32 x 32 (one MFMA tile each), K-step 64, a ring of four 16 KiB stages filled by LDS-DMA
+// three steps ahead (counted vmcnt, raw barrier), two workgroups per CU.  No split-K and no second launch: a layer with
+// M = 4 096, N = 256 is 256 workgroups whose K loop is 16-36 short steps -- what bounds these layers is the length of the
+// dependent chain per workgroup, not the matrix rate.  LDS rows are 128 bytes (64 k); logical 16-byte chunk c of row r
+// lives at chunk c ^ ((r >> 1) & 7) (rows r, r + 1 share a chunk but sit in different bank halves): applied on the DMA's
+// source side and in the operand reads, conflict-free for the ds_read_b128 lane groups.
+// Epilogue: bias, frozen-BN affine, optional 16-bit residual (a bottleneck block's shortcut, or the accumulating input of
+// a data gradient), activation; output strides as in mrcnn_conv_desc (a stride-2 data gradient scatters into a zeroed
+// tensor).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void conv_fwd_h16s_kernel(const ConvH16Args p) {
+    typedef typename H16Traits<T>::v8 v8;
+    constexpr int BM = 64, BN = 64, NBUF = 4, D = 3;
+    constexpr int ROWB = 128;                                   // bytes per LDS row (64 x 16-bit)
+    constexpr int AB = BM * ROWB, BB = BN * ROWB;               // 8 KiB + 8 KiB per stage
+    __shared__ __attribute__((aligned(16))) char lds[NBUF * (AB + BB)];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.Cout / BN;
+    const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x % ntiles;
+    const int m0 = mtile * BM, n0 = ntile * BN;
+    const int ohw = p.OH * p.OW;
+
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - p.x_shift), 0, p.x_records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.w_records, 0x00020000);
+
+    // a 1 KiB DMA piece = 8 rows of 128 bytes: lane -> row (lane >> 3), physical chunk (lane & 7).  8 pieces per operand,
+    // this wave stages pieces wave and wave + 4 of each.
+    unsigned a_voff[2], b_voff[2];
+    unsigned long long a_mask[2];
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int r = (wave + jj * 4) * 8 + (lane >> 3);
+        const int cl = (lane & 7) ^ ((r >> 1) & 7);
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / ohw, rem = mm - n * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
+        a_voff[jj] = (unsigned)(((long long)n * p.H * p.W * p.Cin + ((long long)ih0 * p.W + iw0) * p.Cin + cl * 8) * 2 + p.x_shift);
+        unsigned long long mk = 0ull;
+        if (ok)
+            for (int t = 0; t < p.KH * p.KW; ++t) {
+                const int th = t / p.KW, tw = t - th * p.KW;
+                if ((unsigned)(ih0 + th) < (unsigned)p.H && (unsigned)(iw0 + tw) < (unsigned)p.W) mk |= 1ull << t;
+            }
+        a_mask[jj] = mk;
+        b_voff[jj] = (unsigned)((((long long)(n0 + r)) * p.Ktot + cl * 8) * 2);
+    }
+
+    int kh = 0, kw = 0, ci0 = 0, tap = 0;
+    auto stage = [&](char* ab) {
+        char* bb = ab + AB;
+        const unsigned soff_a = (unsigned)(((kh * p.W + kw) * p.Cin + ci0) * 2);
+        const unsigned soff_b = (unsigned)((tap * p.Cin + ci0) * 2);
+        const unsigned long long bit = 1ull << tap;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const unsigned vo = (a_mask[jj] & bit) ? a_voff[jj] : H16_OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (h16_lds_ptr)(ab + (wave + jj * 4) * 1024), 16, vo, soff_a, 0, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (h16_lds_ptr)(bb + (wave + jj * 4) * 1024), 16, b_voff[jj], soff_b, 0, 0);
+        ++tap;                                                  // channel-chunk outer, filter-tap inner
+        if (++kw == p.KW) { kw = 0; if (++kh == p.KH) { kh = 0; tap = 0; ci0 += 64; } }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int li = lane & 31, lh = lane >> 5;
+    // operand k-group kk (16 k values) of a 32-row tile: lane (li, lh) reads logical chunk 2*kk + lh of its row
+    const int arow = wm * 32 + li, brow = wn * 32 + li;
+    int a_rd[4], b_rd[4];                                       // byte offsets inside a stage
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        a_rd[kk] = arow * ROWB + (((2 * kk + lh) ^ ((arow >> 1) & 7)) << 4);
+        b_rd[kk] = AB + brow * ROWB + (((2 * kk + lh) ^ ((brow >> 1) & 7)) << 4);
+    }
+    auto compute = [&](auto curc) {
+        const char* buf = lds + decltype(curc)::value * (AB + BB);
+        v8 av[4], bv[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { av[kk] = *(const v8*)(buf + a_rd[kk]); bv[kk] = *(const v8*)(buf + b_rd[kk]); }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = H16Traits<T>::mfma(av[kk], bv[kk], acc);
+    };
+
+    const int nk = p.Ktot / 64;
+    for (int s0 = 0; s0 < D && s0 < nk; ++s0) stage(lds + s0 * (AB + BB));
+    for (int ks0 = 0; ks0 < nk; ks0 += NBUF) {
+        h16_static_for([&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            const int ks = ks0 + S;
+            if (ks < nk) {
+                const int younger = nk - 1 - ks;                // stages issued after ks that may still be in flight (<= D - 1)
+                if (younger >= 2) h16_wait_vmcnt<8>();          // 4 DMA instructions per stage and wave
+                else if (younger >= 1) h16_wait_vmcnt<4>();
+                else h16_wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();                   // stage ks has landed for every wave; everyone is done with stage ks - 1
+                if (ks + D < nk) stage(lds + ((S + D) % NBUF) * (AB + BB));
+                compute(std::integral_constant<int, S>{});
+            }
+        }, std::make_integer_sequence<int, NBUF>{});
+    }
+
+    // ---- epilogue ----------------------------------------------------------------------------------------------
+    T* out = (T*)p.out;
+    T* zo = (T*)p.z;
+    const T* res = (const T*)p.res;
+    const int n = n0 + wn * 32 + li;
+    const float cbias = p.bias ? p.bias[n] : 0.f;
+    const float csc = p.scale ? p.scale[n] : 1.f, csh = p.scale ? p.shift[n] : 0.f;
+    const int mb = m0 + wm * 32 + 4 * lh;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = mb + (r & 3) + 8 * (r >> 2);
+        if (m >= p.M) continue;
+        long long addr;
+        if (p.dense) {
+            addr = (long long)m * p.Cout + n;
+        } else {
+            const int ni = m / ohw, rem = m - ni * ohw;
+            const int oh = rem / p.OW, ow = rem - oh * p.OW;
+            addr = (long long)ni * p.ons + (long long)oh * p.ohs + (long long)ow * p.ows + n;
+        }
+        const float zv = acc[r] + cbias;
+        if (zo) zo[addr] = (T)zv;
+        float y = csc * zv + csh;
+        if (res) y += (float)res[addr];
+        if (p.act == MRCNN_ACT_RELU) y = fmaxf(y, 0.f);
+        else if (p.act == MRCNN_ACT_SIGMOID) y = 1.f / (1.f + expf(-y));
+        out[addr] = (T)y;
     }
 }
 
@@ -799,13 +943,38 @@ extern "C" int mrcnn_conv2d_wgrad_h16(const mrcnn_conv_desc* d, int dtype, const
 }
 
 
-extern "C" int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const void* x, const void* w_t, const float* bias,
-                                    const float* scale, const float* shift, void* out, void* z_out, void* stream) {
+// Which 16-bit forward kernel a shape takes: 2 = small tile (64 x 64), 1 = large tile (256 x 128 / 256 x 256), 0 = none.
+static int h16_fwd_kernel_for(const mrcnn_conv_desc* d, const void* res) {
+    if (!d || d->Cin % 32 || d->KH * d->KW > 64) return 0;
+    const long long M = (long long)d->N * d->OH * d->OW;
+    const bool dense = d->out_mode == MRCNN_OUT_NHWC && d->out_w_stride == d->Cout && d->out_h_stride == (int64_t)d->OW * d->Cout &&
+                       d->out_n_stride == (int64_t)d->OH * d->OW * d->Cout;
+    const bool large_ok = d->Cout % 128 == 0 && !res && (dense || d->out_mode == MRCNN_OUT_DECONV2);
+    const bool small_ok = d->Cin % 64 == 0 && d->Cout % 64 == 0 && d->out_mode == MRCNN_OUT_NHWC && d->cmod == d->Cout;
+    const char* force = getenv("MRCNN_H16_SMALL");                   // A/B: 0 = never, 1 = whenever possible
+    if (force && force[0] == '0') return large_ok ? 1 : 0;
+    if (force && force[0] == '1') return small_ok ? 2 : (large_ok ? 1 : 0);
+    // the large tiles need a few hundred workgroups to fill the chip; below that the short dependent chains of the small
+    // tiles win (and they are the only ones with a residual port and strided output)
+    const long long large_wgs = ((M + 255) / 256) * (d->Cout / 128);
+    if (large_ok && (large_wgs >= 384 || !small_ok)) return 1;
+    return small_ok ? 2 : 0;
+}
+
+extern "C" int mrcnn_conv2d_fwd_h16_supported(const mrcnn_conv_desc* d, int has_res) {
+    return h16_fwd_kernel_for(d, has_res ? (const void*)d : nullptr) != 0;
+}
+
+extern "C" int mrcnn_conv2d_fwd_h16_res(const mrcnn_conv_desc* d, int dtype, const void* x, const void* w_t, const float* bias,
+                                        const float* scale, const float* shift, const void* res, void* out, void* z_out,
+                                        void* stream) {
     if (!d || !x || !w_t || !out || !h16_dtype_ok(dtype)) return MRCNN_ERR_ARG;
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->stride <= 0 ||
         d->OH <= 0 || d->OW <= 0 || d->KH * d->KW > 64)
         return MRCNN_ERR_ARG;
-    if (d->Cin % 32 || d->Cout % 128 || d->res_mode != MRCNN_RES_NONE) return MRCNN_ERR_ARG;   // the shapes of the ROI heads
+    if (d->res_mode == MRCNN_RES_UP2 || (d->res_mode == MRCNN_RES_SAME) != (res != nullptr)) return MRCNN_ERR_ARG;
+    const int which = h16_fwd_kernel_for(d, res);
+    if (!which) return MRCNN_ERR_ARG;
     if (d->out_mode == MRCNN_OUT_DECONV2) {
         if (d->Cout != 4 * d->cmod || d->cmod % 128 || z_out) return MRCNN_ERR_ARG;
     } else if (d->out_mode != MRCNN_OUT_NHWC || d->cmod != d->Cout) {
@@ -819,15 +988,24 @@ extern "C" int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const v
     const long long wbytes = (long long)d->KH * d->KW * d->Cin * d->Cout * 2;
     if (M >= (1LL << 31) || xbytes + shift_b >= 0x7FFFFFF0LL || wbytes >= 0x7FFFFFF0LL) return MRCNN_ERR_ARG;
     ConvH16Args a;
-    a.x = x; a.wt = w_t; a.bias = bias; a.scale = scale; a.shift = shift; a.out = out; a.z = z_out;
+    a.x = x; a.wt = w_t; a.bias = bias; a.scale = scale; a.shift = shift; a.out = out; a.z = z_out; a.res = res;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW;
     a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.OH = d->OH; a.OW = d->OW; a.act = d->act;
     a.M = (int)M; a.Ktot = d->KH * d->KW * d->Cin;
     a.x_shift = (unsigned)shift_b; a.x_records = (unsigned)(xbytes + shift_b); a.w_records = (unsigned)wbytes;
     a.out_mode = d->out_mode; a.cmod = d->cmod; a.ons = d->out_n_stride; a.ohs = d->out_h_stride; a.ows = d->out_w_stride;
-    // Tile choice (read per call so that tests and A/B timings can switch: MRCNN_H16_TILE = big | small | ring):
-    //   big    256 x 256, 8 waves, 4-stage ring, one workgroup per CU -- Cout % 256 == 0 and at least one full round of tiles
-    //   small  256 x 128, 4 waves, double buffered, 3 workgroups per CU (the round-1 kernel; everything else)
+    a.dense = d->out_mode == MRCNN_OUT_NHWC && d->out_w_stride == d->Cout && d->out_h_stride == (int64_t)d->OW * d->Cout &&
+              d->out_n_stride == (int64_t)d->OH * d->OW * d->Cout;
+    hipStream_t s = (hipStream_t)stream;
+    if (which == 2) {
+        const unsigned blocks = (unsigned)(((M + 63) / 64) * (d->Cout / 64));
+        if (dtype == MRCNN_DTYPE_F16) hipLaunchKernelGGL(conv_fwd_h16s_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(conv_fwd_h16s_kernel<__bf16>, dim3(blocks), dim3(256), 0, s, a);
+        return mrcnn_launch_status();
+    }
+    // Large tiles (read per call so that tests and A/B timings can switch: MRCNN_H16_TILE = big | small | ring):
+    //   big    256 x 256, 8 waves, 4-stage ring, one workgroup per CU -- Cout % 256 == 0
+    //   small  256 x 128, 4 waves, double buffered, 3 workgroups per CU (the round-1 kernel; the default)
     //   ring   256 x 128 with a 3-slot ring (round-1 experiment)
     const char* tile = getenv("MRCNN_H16_TILE");
     const long long big_tiles = ((M + 255) / 256) * (d->Cout / 256);
@@ -840,7 +1018,6 @@ extern "C" int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const v
     bool big = false;
     if (tile && !strcmp(tile, "big")) big = d->Cout % 256 == 0;
     const bool ring = (tile && !strcmp(tile, "ring")) || getenv("MRCNN_H16_RING") != nullptr;
-    hipStream_t s = (hipStream_t)stream;
     if (big) {
         const unsigned blocks = (unsigned)big_tiles;
         if (dtype == MRCNN_DTYPE_F16) hipLaunchKernelGGL((conv_fwd_h16_kernel<_Float16, 4, 2, 4>), dim3(blocks), dim3(512), 0, s, a);
@@ -856,6 +1033,11 @@ extern "C" int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const v
     else
         hipLaunchKernelGGL((conv_fwd_h16_kernel<__bf16, 2, 2, 2>), dim3(blocks), dim3(256), 0, s, a);
     return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const void* x, const void* w_t, const float* bias,
+                                    const float* scale, const float* shift, void* out, void* z_out, void* stream) {
+    return mrcnn_conv2d_fwd_h16_res(d, dtype, x, w_t, bias, scale, shift, nullptr, out, z_out, stream);
 }
 
 extern "C" int mrcnn_mask_out_fwd_h16(int dtype, const void* up, const float* w_mask, const float* b_mask, float* mask_out,

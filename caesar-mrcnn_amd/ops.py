@@ -643,16 +643,26 @@ def weights_to_h16(w, dtype=torch.float16, want_dgrad=True, out=None):
 
 
 def conv2d_h16(x, w_t, kshape, bias=None, scale=None, shift=None, stride=1, padding="same", act=ACT_NONE, z_out=None,
-               out=None):
-    """16-bit convolution: x [N,H,W,Cin] half/bfloat16, w_t = W^T [Cout, KH*KW*Cin]; kshape = (KH, KW, Cin, Cout)."""
-    _need_cuda(x, w_t, bias, scale, shift, z_out, out)
-    assert x.dtype in _H16 and w_t.dtype == x.dtype
-    d = conv_desc(tuple(x.shape), tuple(kshape), stride, padding, act, RES_NONE)
+               out=None, res=None, out_strides=None):
+    """16-bit convolution: x [N,H,W,Cin] half/bfloat16, w_t = W^T [Cout, KH*KW*Cin]; kshape = (KH, KW, Cin, Cout).
+    res: 16-bit tensor of out's shape added before the activation; out_strides (n, h, w element strides): strided store
+    into `out` (small-tile kernel)."""
+    _need_cuda(x, w_t, bias, scale, shift, z_out, out, res)
+    assert x.dtype in _H16 and w_t.dtype == x.dtype and (res is None or res.dtype == x.dtype)
+    d = conv_desc(tuple(x.shape), tuple(kshape), stride, padding, act, RES_SAME if res is not None else RES_NONE)
+    if out_strides is not None:
+        assert out is not None
+        d.out_n_stride, d.out_h_stride, d.out_w_stride = out_strides
     if out is None:
         out = empty((d.N, d.OH, d.OW, d.Cout), x.dtype, x.device)
-    check(_hip.lib().mrcnn_conv2d_fwd_h16(C.byref(d), _H16[x.dtype], ptr(x), ptr(w_t), ptr(bias), ptr(scale), ptr(shift),
-                                          ptr(out), ptr(z_out), current_stream()), "mrcnn_conv2d_fwd_h16")
+    check(_hip.lib().mrcnn_conv2d_fwd_h16_res(C.byref(d), _H16[x.dtype], ptr(x), ptr(w_t), ptr(bias), ptr(scale), ptr(shift),
+                                              ptr(res), ptr(out), ptr(z_out), current_stream()), "mrcnn_conv2d_fwd_h16")
     return out
+
+
+def conv2d_h16_supported(x_shape, kshape, stride=1, padding="same", res=False):
+    d = conv_desc(tuple(x_shape), tuple(kshape), stride, padding)
+    return bool(_hip.lib().mrcnn_conv2d_fwd_h16_supported(C.byref(d), 1 if res else 0))
 
 
 def deconv2x2_h16(x, w_t, bias, Cd, act=ACT_RELU):

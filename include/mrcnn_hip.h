@@ -258,6 +258,15 @@ int mrcnn_detection_targets(const mrcnn_dettarget_desc* d, const float* proposal
 #define MRCNN_DTYPE_BF16 1
 int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const void* x, const void* w_t, const float* bias,
                          const float* scale, const float* shift, void* out, void* z_out, void* stream);
+/* The same with a 16-bit residual `res` (shape and strides of out; d->res_mode must be MRCNN_RES_SAME exactly when res is
+ * given) added before the activation -- the shortcut of a bottleneck block (mrcnn/model.py:99-131), or the accumulating
+ * input of a data gradient -- and with arbitrary output strides (a stride-2 1x1 data gradient scatters into a zeroed
+ * tensor).  Shapes: as above, or the small-tile kernel for the trunk's layers: Cin % 64 == 0, Cout % 64 == 0, plain NHWC
+ * (strided allowed), the only one with the residual port.  mrcnn_conv2d_fwd_h16_supported() tells whether a descriptor
+ * (with / without residual) has a 16-bit kernel.                                                                     */
+int mrcnn_conv2d_fwd_h16_res(const mrcnn_conv_desc* d, int dtype, const void* x, const void* w_t, const float* bias,
+                             const float* scale, const float* shift, const void* res, void* out, void* z_out, void* stream);
+int mrcnn_conv2d_fwd_h16_supported(const mrcnn_conv_desc* d, int has_res);
 int mrcnn_weights_to_h16(const float* w_hwio, void* wt_fwd, void* wt_dgrad, int KH, int KW, int Cin, int Cout,
                          int dtype, void* stream);
 /* Weight gradient with 16-bit operands x [N,H,W,Cin], dy [N,OH,OW,Cout]: dw (float32, HWIO) = multiplier * sum

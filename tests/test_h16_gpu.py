@@ -247,3 +247,69 @@ def test_graph_replay_follows_weight_updates_h16(dev):
     e3 = eng.infer(x, win)["mrcnn_mask"].cpu().numpy().copy()
     g3 = eng.infer_graphed(x, win)["mrcnn_mask"].cpu().numpy()
     assert np.array_equal(e3, g3) and not np.array_equal(e3, e2["mrcnn_mask"])
+
+
+SMALL_CASES = [
+    # N, H, W, Cin, Cout, k, stride, padding, act, bn, res
+    (4, 32, 32, 1024, 256, 1, 1, "valid", 1, True, False),     # res4 2a at 512 x 512: 16 K-steps of 64
+    (4, 32, 32, 256, 256, 3, 1, "same", 1, True, False),       # res4 2b: 36 K-steps, padded taps
+    (4, 32, 32, 256, 1024, 1, 1, "valid", 1, True, True),      # res4 2c: shortcut added before the ReLU
+    (2, 16, 16, 64, 64, 3, 1, "same", 1, True, False),         # res2-sized: Cin = Cout = 64, one chunk per tap
+    (2, 16, 16, 512, 256, 1, 2, "valid", 1, True, False),      # stride-2 1x1 (first block of a stage)
+    (3, 13, 11, 128, 192, 3, 1, "same", 0, False, True),       # ragged M (429 = 6 x 64 + 45), 3 column tiles, residual, no BN
+    (1, 5, 5, 64, 64, 1, 1, "valid", 2, False, False),         # one K-step (fewer than ring slots), sigmoid
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", SMALL_CASES)
+def test_conv_fwd_h16_small_tile(dev, case, dtype):
+    """conv_fwd_h16s_kernel (64 x 64 tiles, 4-stage LDS-DMA ring; the trunk's layers) against the float32 oracle on the
+    same 16-bit-rounded operands: forward with bias / frozen BN / 16-bit residual / activation, pre-BN output, and the
+    data gradient of a stride-2 1x1 convolution as a strided (scattering) store."""
+    ops = _ops()
+    N, H, W, Cin, Cout, k, stride, padding, act, bn, use_res = case
+    rng = np.random.default_rng(sum(v if isinstance(v, int) else 3 for v in case))
+    x = torch.tensor(rng.standard_normal((N, H, W, Cin)).astype(np.float32)).to(dtype)
+    w = torch.tensor((rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)).to(dtype)
+    b = torch.tensor(rng.standard_normal(Cout).astype(np.float32) * 0.1)
+    z_ref = orc.conv2d_nhwc(x.float(), w.float(), b, stride, padding)
+    y_ref = z_ref
+    scale = shift = None
+    if bn:
+        scale = torch.tensor(rng.uniform(0.5, 1.5, Cout).astype(np.float32))
+        shift = torch.tensor(rng.uniform(-0.2, 0.2, Cout).astype(np.float32))
+        y_ref = z_ref * scale + shift
+    res = None
+    if use_res:
+        res = torch.tensor(rng.standard_normal(tuple(z_ref.shape)).astype(np.float32)).to(dtype)
+        y_ref = y_ref + res.float()
+    if act == 1:
+        y_ref = torch.relu(y_ref)
+    elif act == 2:
+        y_ref = torch.sigmoid(y_ref)
+    os.environ["MRCNN_H16_SMALL"] = "1"
+    try:
+        assert ops.conv2d_h16_supported(tuple(x.shape), (k, k, Cin, Cout), stride, padding, res=use_res)
+        wf, wd = ops.weights_to_h16(w.float().to(dev), dtype)
+        z = torch.empty(tuple(z_ref.shape), dtype=dtype, device=dev)
+        y = ops.conv2d_h16(x.to(dev), wf, (k, k, Cin, Cout), b.to(dev), None if scale is None else scale.to(dev),
+                           None if shift is None else shift.to(dev), stride, padding, act, z_out=z,
+                           res=None if res is None else res.to(dev))
+        torch.cuda.synchronize()
+        for got, ref, name in ((y, y_ref, "out"), (z, z_ref, "z")):
+            err = float((got.float().cpu() - ref).abs().max()) / float(ref.abs().max())
+            assert err <= TOL[dtype], "%s: max error %.3g of max |ref| (allowed %.3g)" % (name, err, TOL[dtype])
+        if k == 1 and stride == 2:
+            # data gradient of the stride-2 1x1 convolution: the 1x1 product scattered to the even pixels of a zeroed tensor
+            dz = torch.tensor(rng.standard_normal(tuple(z_ref.shape)).astype(np.float32)).to(dtype)
+            xg = x.float().clone().requires_grad_(True)
+            orc.conv2d_nhwc(xg, w.float(), None, stride, padding).backward(dz.float())
+            dx = torch.zeros((N, H, W, Cin), dtype=dtype, device=dev)
+            ops.conv2d_h16(dz.to(dev), wd, (1, 1, Cout, Cin), None, None, None, 1, "valid", 0, out=dx,
+                           out_strides=(H * W * Cin, 2 * W * Cin, 2 * Cin))
+            torch.cuda.synchronize()
+            err = float((dx.float().cpu() - xg.grad).abs().max()) / float(xg.grad.abs().max())
+            assert err <= TOL[dtype], "strided dgrad: %.3g" % err
+    finally:
+        del os.environ["MRCNN_H16_SMALL"]
