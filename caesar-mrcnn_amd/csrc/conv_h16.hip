@@ -588,7 +588,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_h16_kernel(const T* __restri
                                                                const T* __restrict__ z, const float* __restrict__ scale,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                T* dz_out, float* dgamma, float* dbeta, float* dbias, long long M,
-                                                               int C, int act, long long rows_per_block, int lg, float gmul) {
+                                                               int C, int act, long long rows_per_block, int lg, float gmul, T* dy_out) {
     __shared__ float sacc[3 * 8 * 256];   // [3][8L]
     const int L = 1 << lg, R = 256 >> lg;
     for (int c = threadIdx.x; c < 24 * L; c += 256) sacc[c] = 0.f;
@@ -623,18 +623,20 @@ __global__ __launch_bounds__(256) void epilogue_bwd_h16_kernel(const T* __restri
             const long long r = rb + (long long)u * R;
             if (r >= r1) break;
             const long long e = r * C + c;
-            t8 dzv;
+            t8 dzv, dyv;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
                 float g = (float)gg[u][k];
                 if (act == MRCNN_ACT_RELU) g = (float)oo[u][k] > 0.f ? g : 0.f;
                 const float dz = g * sc[k];
                 dzv[k] = (T)dz;
+                dyv[k] = (T)g;
                 if (dgamma) a_dg[k] += g * ((float)zz[u][k] - mu[k]) * rs[k];
                 a_db[k] += g;
                 a_bias[k] += dz;
             }
             *(t8*)(dz_out + e) = dzv;
+            if (dy_out) *(t8*)(dy_out + e) = dyv;
         }
     }
 #pragma unroll
@@ -1103,14 +1105,14 @@ extern "C" int mrcnn_weights_to_h16(const float* w, void* wt_fwd, void* wt_dgrad
     return mrcnn_launch_status();
 }
 
-extern "C" int mrcnn_epilogue_bwd_h16(int dtype, const void* dout, const void* out, const void* z, const float* scale,
-                                      const float* mean, const float* rstd, void* dz_out, float* dgamma, float* dbeta,
-                                      float* dbias, int64_t M, int C, int act, float grad_multiplier, void* stream) {
+extern "C" int mrcnn_epilogue_bwd_h16_dy(int dtype, const void* dout, const void* out, const void* z, const float* scale,
+                                         const float* mean, const float* rstd, void* dz_out, void* dy_out, float* dgamma, float* dbeta,
+                                         float* dbias, int64_t M, int C, int act, float grad_multiplier, void* stream) {
     if (!dout || !dz_out || M <= 0 || C < 16 || C > 4096 || (C & (C - 1)) || !h16_dtype_ok(dtype)) return MRCNN_ERR_ARG;
     if ((act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) || (act == MRCNN_ACT_RELU && !out)) return MRCNN_ERR_ARG;
     if (dgamma && (!z || !mean || !rstd)) return MRCNN_ERR_ARG;
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    if (!al(dout) || !al(out) || !al(z) || !al(dz_out)) return MRCNN_ERR_ARG;
+    if (!al(dout) || !al(out) || !al(z) || !al(dz_out) || !al(dy_out)) return MRCNN_ERR_ARG;
     const int c8n = C >> 3;                                   // C is a power of two >= 16
     int lg = 0;
     while ((2 << lg) <= (c8n < 16 ? c8n : 16)) ++lg;           // 16 lanes x 8 channels per row at most
@@ -1121,12 +1123,19 @@ extern "C" int mrcnn_epilogue_bwd_h16(int dtype, const void* dout, const void* o
     if (dtype == MRCNN_DTYPE_F16)
         hipLaunchKernelGGL(epilogue_bwd_h16_kernel<_Float16>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const _Float16*)dout, (const _Float16*)out, (const _Float16*)z, scale, mean, rstd, (_Float16*)dz_out,
-                           dgamma, dbeta, dbias, (long long)M, C, act, rows_per_block, lg, grad_multiplier);
+                           dgamma, dbeta, dbias, (long long)M, C, act, rows_per_block, lg, grad_multiplier, (_Float16*)dy_out);
     else
         hipLaunchKernelGGL(epilogue_bwd_h16_kernel<__bf16>, grid, dim3(256), 0, (hipStream_t)stream,
                            (const __bf16*)dout, (const __bf16*)out, (const __bf16*)z, scale, mean, rstd, (__bf16*)dz_out, dgamma,
-                           dbeta, dbias, (long long)M, C, act, rows_per_block, lg, grad_multiplier);
+                           dbeta, dbias, (long long)M, C, act, rows_per_block, lg, grad_multiplier, (__bf16*)dy_out);
     return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_epilogue_bwd_h16(int dtype, const void* dout, const void* out, const void* z, const float* scale,
+                                      const float* mean, const float* rstd, void* dz_out, float* dgamma, float* dbeta,
+                                      float* dbias, int64_t M, int C, int act, float grad_multiplier, void* stream) {
+    return mrcnn_epilogue_bwd_h16_dy(dtype, dout, out, z, scale, mean, rstd, dz_out, nullptr, dgamma, dbeta, dbias, M, C, act,
+                                     grad_multiplier, stream);
 }
 
 extern "C" int mrcnn_cast_to_h16(const float* src, void* dst, int64_t n, int dtype, float multiplier, void* stream) {

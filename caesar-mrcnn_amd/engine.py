@@ -197,6 +197,7 @@ class MaskRCNNEngine(object):
         self.head_dtype = None
         self.loss_scale = 4096.0
         self.h16_wide = os.environ.get("MRCNN_H16_WIDE", "1") != "0"   # False: only the mask head in 16 bits (round-1 stages 1-2)
+        self.h16_blocks = os.environ.get("MRCNN_H16_BLOCKS", "1") != "0"   # identity blocks of res4 / res5 in 16 bits (stage 4)
         self._h16 = {}
         self._h16_store = {}            # dtype -> {layer: (W^T image, data-gradient image)}, stable addresses
         self._h16_valid = False
@@ -281,6 +282,10 @@ class MaskRCNNEngine(object):
         names = ["mrcnn_mask_conv%d" % i for i in range(1, 5)] + ["mrcnn_mask_deconv"]   # deconv: GEMM matrix [Cin, 4*Cd]
         if self.h16_wide:
             names += [n for n in H16_WIDE_LAYERS if self._h16_shape_ok(self.op(n))]
+            for stage in self.stages:
+                for blk in stage:
+                    if self._h16_block(blk):
+                        names += [blk.c2a.name, blk.c2b.name, blk.c2c.name]
         for name in names:
             op = self.op(name)
             if op.padding == "valid" and op.wshape[0] > 1:
@@ -307,22 +312,30 @@ class MaskRCNNEngine(object):
         """True when layer `name` runs on the 16-bit matrix cores in the current mode."""
         return self.head_dtype is not None and self.h16_wide and name in H16_WIDE_LAYERS and self._h16_shape_ok(self.op(name))
 
-    def _h16_fwd(self, op, x16, act, train):
-        """conv + bias + frozen BN + activation of layer `op` on a 16-bit input: 16-bit result; ctx for _h16_bwd."""
+    def _h16_fwd(self, op, x16, act, train, res=None):
+        """conv + bias + frozen BN (+ 16-bit residual) + activation of layer `op` on a 16-bit input: 16-bit result; ctx for
+        _h16_bwd."""
         d = ops.conv_desc(tuple(x16.shape), op.wshape, op.stride, op.padding, act)
         z = ops.empty((d.N, d.OH, d.OW, d.Cout), x16.dtype, x16.device) if (train and op.bn) else None
-        y = ops.conv2d_h16(x16, self._h16[op.name][0], op.wshape, op.b, op.scale, op.shift, op.stride, op.padding, act, z_out=z)
+        y = ops.conv2d_h16(x16, self._h16[op.name][0], op.wshape, op.b, op.scale, op.shift, op.stride, op.padding, act, z_out=z,
+                           res=res)
         return y, ((x16, z, y, act) if train else None)
 
-    def _h16_bwd(self, op, d16, ctx, S, accumulate_w=False, need_dx=True):
+    def _h16_bwd(self, op, d16, ctx, S, accumulate_w=False, need_dx=True, want_dy=False, dx_res=None):
         """Backward of _h16_fwd.  d16: gradient w.r.t. the activated output, 16 bit, times the loss scale S.  Bias / BN
-        sums and the weight gradient land unscaled in the float32 gradient buffer; returns dx (16 bit, times S)."""
+        sums and the weight gradient land unscaled in the float32 gradient buffer; returns dx (16 bit, times S; plus
+        dx_res when given), or (dx, dy) with want_dy: dy = d16 * act' is what a shortcut into this layer's Add receives."""
         x16, z, y, act = ctx
-        dz = ops.epilogue_bwd_h16(d16, y if act != ACT_NONE else None, z, op.scale, op.mean, op.rstd, op.dgamma, op.dbeta, op.db,
-                                  act, 1.0 / S)
+        got = ops.epilogue_bwd_h16(d16, y if act != ACT_NONE else None, z, op.scale, op.mean, op.rstd, op.dgamma, op.dbeta, op.db,
+                                   act, 1.0 / S, want_dy=want_dy)
+        dz, dy = got if want_dy else (got, None)
         self.wgrad_h16_async(x16, dz, op.wshape, op.dw, 1.0 / S, op.padding, accumulate_w)
         if not need_dx:
-            return None
+            return (None, dy) if want_dy else None
+        dx = self._h16_dgrad(op, dz, dx_res)
+        return (dx, dy) if want_dy else dx
+
+    def _h16_dgrad(self, op, dz, dx_res=None):
         kh, kw, cin, cout = op.wshape
         if op.padding == "valid" and kh > 1:                     # FC as VALID conv: one GEMM over the flattened window
             M = dz.shape[0]
@@ -330,7 +343,27 @@ class MaskRCNNEngine(object):
                                 "valid", ACT_NONE)
             return dx.view(M, kh, kw, cin)
         return ops.conv2d_h16(dz, self._h16[op.name][1], (kh, kw, cout, cin), None, None, None, 1,
-                              ((kh - 1) // 2, (kw - 1) // 2) if op.padding == "same" else "valid", ACT_NONE)
+                              ((kh - 1) // 2, (kw - 1) // 2) if op.padding == "same" else "valid", ACT_NONE, res=dx_res)
+
+    # ---- identity bottleneck blocks in 16 bits (configs[4], stage 4) ------------------------------------------
+    def _h16_block(self, blk):
+        """An identity block (mrcnn/model.py:99-131) whose three convolutions fit the 16-bit kernels -- res4 b.. and
+        res5 b, c (widths 256 / 1024 and 512 / 2048): 72 of ResNet-101's 104 convolutions."""
+        return (self.head_dtype is not None and self.h16_wide and self.h16_blocks and blk.c1 is None and
+                all(self._h16_shape_ok(o) for o in (blk.c2a, blk.c2b, blk.c2c)))
+
+    def _block_fwd_h16(self, blk, x16, train):
+        a, ca = self._h16_fwd(blk.c2a, x16, ACT_RELU, train)
+        b, cb = self._h16_fwd(blk.c2b, a, ACT_RELU, train)
+        y, cc = self._h16_fwd(blk.c2c, b, ACT_RELU, train, res=x16)
+        return y, ("h16", ca, cb, cc)
+
+    def _block_bwd_h16(self, blk, d16, ctxs, S):
+        """d16: gradient w.r.t. the block output (16 bit, times S) -> gradient w.r.t. the block input."""
+        _, ca, cb, cc = ctxs
+        d_b, dy = self._h16_bwd(blk.c2c, d16, cc, S, want_dy=True)
+        d_a = self._h16_bwd(blk.c2b, d_b, cb, S)
+        return self._h16_bwd(blk.c2a, d_a, ca, S, dx_res=dy)       # identity shortcut: dx = dgrad_2a + dy
 
     def _S(self):
         return float(self.loss_scale) if self.head_dtype == torch.float16 else 1.0
@@ -504,8 +537,20 @@ class MaskRCNNEngine(object):
         else:
             x = ops.maxpool3x3s2(x)
         feats = []
+        x16 = None                                  # the running activation in 16 bits, between 16-bit blocks
         for stage in self.stages:
             for blk in stage:
+                if self._h16_block(blk):
+                    if x16 is None:
+                        self._ensure_h16()
+                        x16 = ops.cast_to_h16(x, self.head_dtype)
+                    x16, ctx = self._block_fwd_h16(blk, x16, train)
+                    x = None
+                    if train:
+                        tape[id(blk)] = ctx
+                    continue
+                if x is None:
+                    x, x16 = ops.cast_from_h16(x16), None
                 a, ca = blk.c2a.forward(x, ACT_RELU, train=train)
                 b, cb = blk.c2b.forward(a, ACT_RELU, train=train)
                 if blk.c1 is not None:
@@ -515,6 +560,8 @@ class MaskRCNNEngine(object):
                 x, cc = blk.c2c.forward(b, ACT_RELU, res=sc, res_mode=RES_SAME, train=train)
                 if train:
                     tape[id(blk)] = (ca, cb, cc, c1c)
+            if x is None:                           # stage output: float32 for the FPN lateral and the next stage's first block
+                x, x16 = ops.cast_from_h16(x16), None
             feats.append(x)
         C2, C3, C4, C5 = feats
         P5s, tape["fpn_c5p5"] = self.op("fpn_c5p5").forward(C5, train=train)
@@ -1050,10 +1097,20 @@ class MaskRCNNEngine(object):
             self.join_wgrad()
             self.grad_ready(*self.grad_ranges["tail"])
         d_out = dC[3]                                   # gradient w.r.t. C5
+        d16 = None                                      # the running gradient in 16 bits (times S), between 16-bit blocks
+        S = self._S()
         for si in (3, 2, 1, 0):
             stage = self.stages[si]
             for bi in range(len(stage) - 1, -1, -1):
                 blk = stage[bi]
+                if tape[id(blk)][0] == "h16":
+                    if d16 is None:
+                        d16 = ops.cast_to_h16(d_out, self.head_dtype, multiplier=S)
+                    d16 = self._block_bwd_h16(blk, d16, tape[id(blk)], S)
+                    d_out = None
+                    continue
+                if d_out is None:
+                    d_out, d16 = ops.cast_from_h16(d16, 1.0 / S), None
                 # the first block of stage s+1 consumes C_s, whose FPN gradient is already in dC[si-1]
                 acc_buf = dC[si - 1] if (bi == 0 and si > 0) else None
                 # the block before this one in the forward order: its output epilogue backward (ReLU mask, BN of its 2c
@@ -1064,6 +1121,8 @@ class MaskRCNNEngine(object):
                 elif si > 0:
                     prev = self.stages[si - 1][-1]
                     below = (prev, tape[id(prev)][2])
+                if below is not None and tape[id(below[0])][0] == "h16":
+                    below = None                        # the block below runs in 16 bits: it differentiates its own output stage
                 d_out = self._block_bwd(blk, d_out, tape[id(blk)], acc_buf, below)
             if self.grad_ready:
                 self.join_wgrad()

@@ -718,16 +718,18 @@ def conv2d_wgrad_h16(x, dy, w_shape, stride=1, padding="same", dw=None, accumula
 
 
 def epilogue_bwd_h16(dout, out=None, z=None, scale=None, mean=None, rstd=None, dgamma=None, dbeta=None, dbias=None,
-                     act=ACT_NONE, grad_multiplier=1.0):
-    """16-bit twin of epilogue_bwd: returns dz (same dtype as dout); channel sums go to the float32 gradients."""
+                     act=ACT_NONE, grad_multiplier=1.0, want_dy=False):
+    """16-bit twin of epilogue_bwd: returns dz (same dtype as dout), or (dz, dy) with want_dy (dy = dout * act': the
+    gradient a shortcut receives); channel sums go to the float32 gradients."""
     _need_cuda(dout, out, z, scale, mean, rstd, dgamma, dbeta, dbias)
     C_ = dout.shape[-1]
     M = dout.numel() // C_
     dz = empty(dout.shape, dout.dtype, dout.device)
-    check(_hip.lib().mrcnn_epilogue_bwd_h16(_H16[dout.dtype], ptr(dout), ptr(out), ptr(z), ptr(scale), ptr(mean), ptr(rstd),
-                                            ptr(dz), ptr(dgamma), ptr(dbeta), ptr(dbias), M, C_, act, float(grad_multiplier),
-                                            current_stream()), "mrcnn_epilogue_bwd_h16")
-    return dz
+    dy = empty(dout.shape, dout.dtype, dout.device) if want_dy else None
+    check(_hip.lib().mrcnn_epilogue_bwd_h16_dy(_H16[dout.dtype], ptr(dout), ptr(out), ptr(z), ptr(scale), ptr(mean), ptr(rstd),
+                                               ptr(dz), ptr(dy), ptr(dgamma), ptr(dbeta), ptr(dbias), M, C_, act,
+                                               float(grad_multiplier), current_stream()), "mrcnn_epilogue_bwd_h16")
+    return (dz, dy) if want_dy else dz
 
 
 def cast_to_h16(src, dtype=torch.float16, out=None, multiplier=1.0):

@@ -280,6 +280,11 @@ int mrcnn_conv2d_wgrad_h16(const mrcnn_conv_desc* d, int dtype, const void* x, c
 int mrcnn_epilogue_bwd_h16(int dtype, const void* dout, const void* out, const void* z, const float* scale,
                            const float* mean, const float* rstd, void* dz_out, float* dgamma, float* dbeta,
                            float* dbias, int64_t M, int C, int act, float grad_multiplier, void* stream);
+/* The same with a second output dy_out = dout * act'(out) (before the BatchNorm scale): what the shortcut of a bottleneck
+ * block receives when the block's last convolution is differentiated (mrcnn/model.py:128-130, Add + Activation).      */
+int mrcnn_epilogue_bwd_h16_dy(int dtype, const void* dout, const void* out, const void* z, const float* scale,
+                              const float* mean, const float* rstd, void* dz_out, void* dy_out, float* dgamma, float* dbeta,
+                              float* dbias, int64_t M, int C, int act, float grad_multiplier, void* stream);
 /* Output stage of the mask head on a 16-bit deconvolution output `up` [M,H,W,Cd] (mrcnn_conv2d_fwd_h16 with out_mode
  * MRCNN_OUT_DECONV2 writes it): mask_out [M,H,W,C] float32 = sigmoid(up . w_mask + b_mask); and the one-pass backward
  * of mrcnn_mask_out_bwd with dzg written in 16 bits times loss_scale (the sums dw_mask / db_mask / db_deconv stay

@@ -133,20 +133,23 @@ def test_casts(dev):
         assert torch.equal(ops.cast_from_h16(h, 0.5), h.float() * 0.5)
 
 
-@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("backbone,wide", [("custom", False), ("custom", True), ("resnet50", True)])
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
-def test_mixed_precision_training_step(dev, dtype, wide):
+def test_mixed_precision_training_step(dev, dtype, backbone, wide):
     """engine.head_dtype: the mask head (wide=False: stages 1-2) and, with engine.h16_wide, also the FPN smoothing
     convolutions, the shared RPN convolution and the two class-head FC layers (stage 3) on the 16-bit matrix cores --
     forward, data and weight gradient -- everything else float32.  Against the all-float32 engine on the same batch
     and the SAME proposals (the float32 run's ProposalLayer output is forced into the 16-bit run: RPN scores that
     differ in the 4th digit re-order the NMS and would change the sampled ROIs, i.e. compare two different problems):
-    losses to 1e-2 (f16) / 4e-2 (bf16), every gradient tensor to 4x that of its float32 maximum."""
+    losses to 1e-2 (f16) / 4e-2 (bf16), every gradient tensor to 4x that of its float32 maximum.
+    backbone resnet50 adds stage 4: the identity bottleneck blocks of res4 / res5 (16-bit activations from block to
+    block, residual adds and ReLU in the convolution's epilogue, 16-bit data gradients with the shortcut's gradient added
+    in the last one)."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import test_engine_gpu as T
     from caesar_mrcnn_amd.model import MaskRCNN
-    cfg = T._small_cfg("custom", 128)
-    w = T._weights(cfg, 31)
+    cfg = T._small_cfg(backbone, 128)
+    w = T._weights(cfg, 31, damp=0.5 if backbone != "custom" else None)
     inputs, keys = T._train_inputs(cfg, 2, 33)
     res = {}
     forced = None
@@ -161,6 +164,9 @@ def test_mixed_precision_training_step(dev, dtype, wide):
             forced = eng.last["rpn_rois"].clone()
         else:
             assert eng._h16_layer("rpn_conv_shared") == wide and eng._h16_layer("mrcnn_class_conv1") == wide
+            if backbone == "resnet50":
+                n16 = sum(eng._h16_block(b) for st in eng.stages for b in st)
+                assert n16 == 5 + 2, n16                    # res4 b-f, res5 b-c
         res[mode] = (losses.cpu().numpy(), eng.get_weights(grads=True))
     tol = 1e-2 if dtype == torch.float16 else 4e-2
     np.testing.assert_allclose(res[dtype][0], res[None][0], rtol=tol)
@@ -171,7 +177,10 @@ def test_mixed_precision_training_step(dev, dtype, wide):
         if err > 4 * tol:
             bad.append((name, err))
     assert not bad, bad[:6]
-    for name in ("mrcnn_mask_conv2/kernel", "rpn_conv_shared/kernel", "fpn_p3/kernel", "mrcnn_class_conv1/kernel"):
+    names = ["mrcnn_mask_conv2/kernel", "rpn_conv_shared/kernel", "fpn_p3/kernel", "mrcnn_class_conv1/kernel"]
+    if backbone == "resnet50":
+        names += ["res4c_branch2b/kernel", "res5b_branch2a/kernel", "bn4d_branch2c/gamma"]
+    for name in names:
         g = res[dtype][1][name]
         assert np.abs(g).max() > 0 and np.isfinite(g).all(), name
 
