@@ -408,6 +408,78 @@ def _roofline_leg(res, ops, torch, dev, nimg, cfg):
     del xm, om, dym
 
 
+def measure_config4(args, rank, local_rank, world):
+    """BASELINE.json configs[4]: ResNet-101 with 16-bit weight images / activations on the 16-bit matrix cores, 512 x 512
+    tiles, 4 images per GPU.  Mixed precision as built so far: mask head, FPN smoothing, shared RPN
+    convolution, class-head FC layers and the identity bottleneck blocks of res4 / res5 in 16 bits (forward, data and
+    weight gradient); stem, res2, res3, the first block of each stage, laterals and the small output layers float32;
+    float32 master weights, accumulation, gradients; loss scale 4096 for float16.  Own object, never the headline."""
+    import contextlib
+    import torch
+    import torch.distributed as dist
+    from caesar_mrcnn_amd import ops
+    from caesar_mrcnn_amd.config import run_py_config
+    from caesar_mrcnn_amd.model import MaskRCNN
+    dev = torch.device("cuda", int(os.environ.get("MRCNN_FORCE_DEVICE", local_rank)))
+    size, nimg = 512, 4
+    cfg = run_py_config(num_classes=4, imgsize=size, backbone="resnet101", images_per_gpu=nimg, gpu_count=world)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = MaskRCNN("training", cfg, "/tmp/mrcnn_bench_logs", device=dev, seed=0)
+        model.compile(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM)
+    dev_inputs = model._to_device(synthetic_batch(cfg, nimg, seed=4321 + rank))
+    eng = model.engine
+
+    def timed(nsteps):
+        for _ in range(3):
+            eng.forward_backward(*dev_inputs)
+            eng.apply_gradients(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM, 1)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(nsteps):
+            losses = eng.forward_backward(*dev_inputs)
+            eng.apply_gradients(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM, 1)
+        torch.cuda.synchronize()
+        return (time.time() - t0) / nsteps, losses
+
+    out = {"workload": "BASELINE.json configs[4]: resnet101+FPN 512x512, nimg_per_gpu=4, train step, 16-bit weights/activations "
+                       "on the 16-bit MFMA where built (mask head, FPN smoothing, shared RPN conv, class FCs, identity blocks of "
+                       "res4/res5), float32 elsewhere; float32 master weights and gradients, loss scale 4096 (f16)",
+           "unit": "images/s"}
+    steps = max(5, args.steps // 2)
+    for tag, sparse, dt in (("f32", False, None), ("f16", False, torch.float16), ("bf16", False, torch.bfloat16),
+                            ("f16_exact_zero_skip", True, torch.float16)):
+        eng.sparse_mask_bwd, eng.head_dtype = sparse, dt
+        t, losses = timed(steps)
+        out["value_" + tag] = round(nimg / t, 3)
+        out["ms_per_step_" + tag] = round(t * 1e3, 3)
+        out["losses_" + tag] = [round(float(v), 5) for v in losses.cpu().numpy()]
+    eng.sparse_mask_bwd, eng.head_dtype = True, None
+    # roofline of the dominant 16-bit kernel (mask-head 3x3 convolution, forward / data gradient), live HIP events
+    M_rois = nimg * cfg.TRAIN_ROIS_PER_IMAGE
+    flops = 2.0 * (M_rois * 196) * 256 * 2304
+    for dt, tag in ((torch.float16, "f16"), (torch.bfloat16, "bf16")):
+        xm = torch.randn((M_rois, 14, 14, 256), device=dev).to(dt)
+        wf, _ = ops.weights_to_h16(torch.randn((3, 3, 256, 256), device=dev) * 0.02, dt)
+        bm = torch.zeros(256, device=dev); sc = torch.ones(256, device=dev)
+        om = torch.empty((M_rois, 14, 14, 256), device=dev, dtype=dt)
+        for _ in range(3):
+            ops.conv2d_h16(xm, wf, (3, 3, 256, 256), bm, sc, bm, 1, "same", 1, out=om)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.conv2d_h16(xm, wf, (3, 3, 256, 256), bm, sc, bm, 1, "same", 1, out=om)
+        e1.record()
+        torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / 20
+        ach = flops / (k_ms * 1e-3) / 1e12
+        out["roofline_" + tag] = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                  "frac": round(ach / 2500.0, 4), "traffic": None,
+                                  "kernel": "conv_fwd_h16_kernel<%s>, 256x128 tile (mask-head 3x3 conv, M=%d N=256 K=2304, %.1f "
+                                            "GFLOP/launch, %.3f ms/launch)" % (tag, M_rois * 196, flops / 1e9, k_ms)}
+        del xm, om
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -420,6 +492,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] (ResNet-50, 2 img/GPU) leg")
     ap.add_argument("--detect-iters", type=int, default=10)
     ap.add_argument("--dense-only", action="store_true", help="skip the exact-zero-skip timing loop (profiling)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the configs[4] leg (ResNet-101 512x512, 16-bit)")
     args = ap.parse_args()
 
     import torch
@@ -431,6 +504,7 @@ def main():
         sys.stderr.write("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE\n" % (args.gpus, world))
     torch.cuda.set_device(torch.device("cuda", int(os.environ.get("MRCNN_FORCE_DEVICE", local_rank))))
 
+    r_model_refs = []
     r = measure(args, args.backbone, args.nimg, rank, local_rank, world, full=True)
     second = None
     if world == 1 and not args.no_secondary and (args.backbone, args.nimg) != ("resnet50", 2):
@@ -439,6 +513,15 @@ def main():
             second = measure(args, "resnet50", 2, rank, local_rank, world, full=False)
         except Exception as e:
             sys.stderr.write("configs[1] leg failed: %r\n" % (e,))
+
+    cfg4 = None
+    if world == 1 and not args.no_config4 and not args.dense_only:
+        del r_model_refs[:]
+        torch.cuda.empty_cache()
+        try:
+            cfg4 = measure_config4(args, rank, local_rank, world)
+        except Exception as e:
+            cfg4 = {"error": repr(e)}
 
     def rnd(v, n=3):
         return None if v is None else round(v, n)
@@ -482,6 +565,8 @@ def main():
                 "value": round(second["images_per_s"], 3), "unit": "images/s", "ms_per_step": round(second["ms_per_step"], 3),
                 "value_exact_zero_skip": None if args.dense_only else round(second["images_per_s_sparse"], 3),
                 "detect_ms_per_image": rnd(second["detect_ms"])}
+        if cfg4 is not None:
+            out["config4_resnet101_512_f16"] = cfg4
         if "cpu_baseline" in r:
             out["cpu_baseline"] = r["cpu_baseline"]
         if "detect_error" in r:
