@@ -59,6 +59,9 @@ class Config(object):
     # extension (not in the reference): build rpn_match / rpn_bbox on the GPU (csrc/rpn_targets.hip) instead of in
     # the NumPy generator; False restores the host path and its np.random.choice stream (model.py:1536-1644)
     DEVICE_RPN_TARGETS = True
+    # extension: single-rank training steps (forward, backward, optimiser) replayed from one HIP graph
+    # (engine.step_graphed); data-parallel runs keep eager launches (the gradient hooks are not capturable)
+    TRAIN_HIP_GRAPH = True
     # extension: None (float32 everywhere, the reference's precision) | "float16" | "bfloat16": run the 3x3
     # convolutions of the mask head on the 16-bit matrix cores (csrc/conv_h16.hip; float32 master weights,
     # accumulation and gradients; HEAD_LOSS_SCALE guards float16 gradients)

@@ -230,6 +230,10 @@ __global__ __launch_bounds__(256) void heads_loss_grad_kernel(const LossArgs p) 
     }
 }
 
+__global__ void loss_zero_kernel(float* p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0.f;
+}
+
 extern "C" size_t mrcnn_losses_workspace(const mrcnn_loss_desc* d) {
     if (!d || d->B <= 0 || d->A <= 0) return 0;
     return 256 + S_NUM * sizeof(float) + (size_t)d->B * d->A * sizeof(int32_t);
@@ -263,7 +267,9 @@ extern "C" int mrcnn_losses_fwd_bwd(const mrcnn_loss_desc* d, const int32_t* rpn
     a.max_rpn_pos = d->max_rpn_pos; a.dice = d->mask_loss_dice;
     a.w0 = d->w[0]; a.w1 = d->w[1]; a.w2 = d->w[2]; a.w3 = d->w[3]; a.w4 = d->w[4];
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(a.scal, 0, S_NUM * sizeof(float), s) != hipSuccess) return MRCNN_ERR_LAUNCH;
+    // a kernel, not hipMemsetAsync: this call sits inside captured training steps, and a captured memset node writes a
+    // garbage value from the second replay on (ROCm 7.2; tools/graph_memset_probe.py)
+    hipLaunchKernelGGL(loss_zero_kernel, dim3(1), dim3(64), 0, s, a.scal, S_NUM);
     hipLaunchKernelGGL(rpn_loss_reduce_kernel, dim3(d->B), dim3(1024), 0, s, a);
     hipLaunchKernelGGL(heads_loss_reduce_kernel, dim3((unsigned)(d->B * d->T)), dim3(256), 0, s, a);
     const int64_t na = (int64_t)d->B * d->A;

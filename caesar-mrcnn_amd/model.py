@@ -238,6 +238,8 @@ class MaskRCNN(object):
         eng = self.engine
         dev_inputs = self._to_device(inputs, rand_keys)
         eng.grad_ready = reducer.ready if reducer is not None else None
+        if apply and reducer is None and world_size == 1 and not keep_outputs and getattr(self.config, "TRAIN_HIP_GRAPH", False):
+            return eng.step_graphed(dev_inputs, self._lr, self._momentum)      # the whole step replayed from one HIP graph
         losses = eng.forward_backward(*dev_inputs, keep_outputs=keep_outputs)
         if reducer is not None:
             reducer.finish()

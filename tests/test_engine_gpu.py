@@ -595,6 +595,46 @@ def test_graph_replay_with_multiworkgroup_topk_512(dev):
     assert np.abs(eager["rpn_rois"]).sum() > 0
 
 
+@pytest.mark.parametrize("head_dtype", [None, "float16"])
+def test_graphed_training_steps_equal_eager(dev, head_dtype):
+    """engine.step_graphed (forward + backward + optimiser of a step replayed from one HIP graph, three forked streams
+    inside) against the same steps issued eagerly: four steps on two alternating batches, same losses every step and the
+    same parameters at the end up to the float atomics (the two warm-up steps taken before the capture are rolled back:
+    they must not count as optimiser steps).  ResNet-50 so that split-K, multi-problem and LDS-DMA kernels, the 16-bit
+    blocks (float16 case) and every side stream are inside the graph."""
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _small_cfg("resnet50", 128)
+    w = _weights(cfg, 71, damp=0.5)
+    batches = [_train_inputs(cfg, 2, 73), _train_inputs(cfg, 2, 75)]
+    out = {}
+    for graphed in (False, True):
+        model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+        eng = model.engine
+        if head_dtype:
+            eng.head_dtype = getattr(torch, head_dtype)
+        model.compile(0.002, 0.9)
+        losses = []
+        for s in range(4):
+            inputs, keys = batches[s % 2]
+            di = model._to_device(inputs, keys)
+            if graphed:
+                ls = eng.step_graphed(di, 0.002, 0.9)
+            else:
+                ls = eng.forward_backward(*di)
+                eng.apply_gradients(0.002, 0.9, 1)
+            losses.append(ls.cpu().numpy().copy())
+        torch.cuda.synchronize()
+        out[graphed] = (np.stack(losses), eng.params.cpu().numpy().copy(), eng.momentum.cpu().numpy().copy())
+        if graphed:
+            assert len(eng._train_graphs) == 1
+    tol = 2e-3 if head_dtype else 2e-4            # four optimiser steps apart: atomics-order noise, amplified by 16-bit rounding
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=tol, atol=1e-5)
+    for k in (1, 2):
+        scale = np.abs(out[False][k]).max()
+        assert np.abs(out[True][k] - out[False][k]).max() <= tol * scale, k
+    assert np.abs(out[False][2]).max() > 0
+
+
 def test_training_step_with_an_image_without_ground_truth(dev):
     """Edge case: one tile of the batch holds no object (all-zero GT rows; the reference's generator skips such images,
     model.py:1786, but DetectionTargetLayer defines the result: with no GT box every proposal is a negative and the
