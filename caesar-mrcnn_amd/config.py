@@ -60,8 +60,12 @@ class Config(object):
     # the NumPy generator; False restores the host path and its np.random.choice stream (model.py:1536-1644)
     DEVICE_RPN_TARGETS = True
     # extension: single-rank training steps (forward, backward, optimiser) replayed from one HIP graph
-    # (engine.step_graphed); data-parallel runs keep eager launches (the gradient hooks are not capturable)
-    TRAIN_HIP_GRAPH = True
+    # (engine.step_graphed); data-parallel runs keep eager launches (the gradient hooks are not capturable).
+    # Off by default: measured 2-3 ms SLOWER per step than eager launches in every mode (ResNet-101, 4 images:
+    # float32 dense 60.2 -> 62.5 ms, 16-bit sparse 14.1 -> 16.7 ms; 512x512 f16 27.9 -> 31.6) -- the replay runs the
+    # three forked streams of the step with less overlap than the eager queues do, which costs more than the host
+    # time it saves
+    TRAIN_HIP_GRAPH = False
     # extension: None (float32 everywhere, the reference's precision) | "float16" | "bfloat16": run the 3x3
     # convolutions of the mask head on the 16-bit matrix cores (csrc/conv_h16.hip; float32 master weights,
     # accumulation and gradients; HEAD_LOSS_SCALE guards float16 gradients)

@@ -627,7 +627,11 @@ def test_graphed_training_steps_equal_eager(dev, head_dtype):
         out[graphed] = (np.stack(losses), eng.params.cpu().numpy().copy(), eng.momentum.cpu().numpy().copy())
         if graphed:
             assert len(eng._train_graphs) == 1
-    tol = 2e-3 if head_dtype else 2e-4            # four optimiser steps apart: atomics-order noise, amplified by 16-bit rounding
+    # the first two steps see (almost) identical weights: tight; afterwards the atomics-order noise of the updates has been
+    # through the network again -- with 16-bit rounding it can re-order an NMS decision, which moves the class / box losses
+    # of that step by a fraction of a per cent (same in two eager runs)
+    np.testing.assert_allclose(out[True][0][:2], out[False][0][:2], rtol=2e-4, atol=1e-5)
+    tol = 2e-2 if head_dtype else 2e-4
     np.testing.assert_allclose(out[True][0], out[False][0], rtol=tol, atol=1e-5)
     for k in (1, 2):
         scale = np.abs(out[False][k]).max()

@@ -22,10 +22,17 @@ for sparse in (False, True):
         if only and tag != only:
             continue
         eng.sparse_mask_bwd, eng.head_dtype = sparse, hd
+        graphed = os.environ.get("MRCNN_TRAIN_GRAPH", "0") != "0"
+
+        def step():
+            if graphed:
+                eng.step_graphed(inp, cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM)
+            else:
+                eng.forward_backward(*inp); eng.apply_gradients(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM, 1)
         for _ in range(3):
-            eng.forward_backward(*inp); eng.apply_gradients(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM, 1)
+            step()
         torch.cuda.synchronize(); t0 = time.time()
         for _ in range(10):
-            eng.forward_backward(*inp); eng.apply_gradients(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM, 1)
+            step()
         torch.cuda.synchronize(); dt = (time.time() - t0) / 10
-        print("sparse=%-5s head=%-14s %.2f ms/step  %.1f img/s" % (sparse, hd, dt * 1e3, nimg / dt))
+        print("sparse=%-5s head=%-14s %s %.2f ms/step  %.1f img/s" % (sparse, hd, "graph" if graphed else "eager", dt * 1e3, nimg / dt))
