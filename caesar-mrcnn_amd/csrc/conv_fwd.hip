@@ -843,6 +843,218 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_bwd_kernel(const Con
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Single-launch kernel for the small layers of the trunk (the feature maps of C3..C5 / P3..P6: a few thousand pixels).
+// Those layers used to be cut into K slices run by separate workgroups, with a second launch summing the slabs: two
+// launches, a float32 slab round trip through HBM, and per workgroup a dependent chain of 64-cycle fp32 MFMAs.  Here a
+// workgroup owns one 32 x 32 output tile and its FOUR WAVES take one quarter of K each -- 1 024 wave-sized tasks for
+// M = 1 024, N = 256, one per SIMD of the chip -- every wave streaming its own operands global -> LDS by DMA (two
+// private 8 KiB stages, the next K-step in flight behind a counted vmcnt: no barrier inside the K loop, the waves never
+// wait for one another; 64 KiB per workgroup, two workgroups per CU).  The four partial tiles meet in LDS, are summed in wave order (fixed order: bitwise reproducible) and
+// every thread finishes four adjacent columns of one row: bias, frozen-BN affine, residual, activation, float4 stores --
+// or, for a data gradient, the backward epilogue of the layer below (conv_splitk_epilogue_bwd_kernel's arithmetic).
+// LDS rows are 128 bytes (32 floats) for both operands; A rows use the chunk swizzle c ^ ((r >> 1) & 7) on the DMA's
+// source side and in the ds_read_b128 operand reads; B rows ([k][32 columns]) are read with ds_read_b32 (lane = column).
+#define SK_STAGE_BYTES 8192
+#define SK_NSTAGE 2
+__global__ __launch_bounds__(256, 2) void conv_fwd_sk_kernel(const ConvArgs p, const unsigned x_shift, const unsigned x_records) {
+    __shared__ __attribute__((aligned(16))) char lds[4 * SK_NSTAGE * SK_STAGE_BYTES];     // 64 KiB: 4 waves x 2 stages x (A 4 KiB + B 4 KiB)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ntiles = p.Cout >> 5;
+    const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x - mtile * ntiles;
+    const int m0 = mtile * 32, n0 = ntile * 32;
+    const int ohw = p.OH * p.OW;
+    char* my = lds + wave * (SK_NSTAGE * SK_STAGE_BYTES);
+
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - x_shift), 0, x_records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + n0), 0, (unsigned)(((long long)p.Ktot * p.Cout - n0) * 4), 0x00020000);
+
+    // A: 4 pieces of 8 rows x 128 B; lane -> row 8 j + (lane >> 3), physical chunk lane & 7
+    unsigned a_voff[4];
+    unsigned long long a_mask[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = j * 8 + (lane >> 3);
+        const int cl = (lane & 7) ^ ((r >> 1) & 7);
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / ohw, rem = mm - n * ohw;
+        const int oh = rem / p.OW, ow = rem - oh * p.OW;
+        const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
+        a_voff[j] = (unsigned)((((long long)n * p.H * p.W + (long long)ih0 * p.W + iw0) * p.Cin + cl * 4) * 4 + x_shift);
+        unsigned long long mk = 0ull;
+        if (ok)
+            for (int t = 0; t < p.KH * p.KW; ++t) {
+                const int th = t / p.KW, tw = t - th * p.KW;
+                if ((unsigned)(ih0 + th) < (unsigned)p.H && (unsigned)(iw0 + tw) < (unsigned)p.W) mk |= 1ull << t;
+            }
+        a_mask[j] = mk;
+    }
+    // B: 4 pieces of 8 k-rows x 128 B (32 columns): lane -> k-row 8 j + (lane >> 3), chunk lane & 7 (no swizzle: b32 reads)
+    const unsigned b_voff = (unsigned)(((lane >> 3) * p.Cout + (lane & 7) * 4) * 4);
+
+    // this wave's K-steps (of 32): [ks0, ks1)
+    const int nk = p.Ktot >> 5;
+    const int ks0 = (nk * wave) >> 2, ks1 = (nk * (wave + 1)) >> 2;
+    const int cpt = p.Cin >> 5;                                  // K-steps per filter tap
+    int tap = ks0 / cpt, cc = ks0 - tap * cpt;
+    int kh = tap / p.KW, kw = tap - kh * p.KW;
+    auto stage = [&](char* buf, int ks) {
+        const unsigned soff_a = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 4);
+        const unsigned long long bit = 1ull << tap;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned vo = (a_mask[j] & bit) ? a_voff[j] : CONV_OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (conv_lds_ptr)(buf + j * 1024), 16, vo, soff_a, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (conv_lds_ptr)(buf + 4096 + j * 1024), 16, b_voff,
+                                                     (unsigned)(((ks * 32 + j * 8) * p.Cout) * 4), 0, 0);
+        if (++cc == cpt) { cc = 0; ++tap; if (++kw == p.KW) { kw = 0; ++kh; } }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int li = lane & 31, lh = lane >> 5;
+    int a_rd[4];
+#pragma unroll
+    for (int t4 = 0; t4 < 4; ++t4) a_rd[t4] = li * 128 + (((lh * 4 + t4) ^ ((li >> 1) & 7)) << 4);
+    const int b_rd = 4096 + lh * 16 * 128 + li * 4;
+    auto compute = [&](const char* buf) {
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const f32x4 av = *(const f32x4*)(buf + a_rd[t4]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float bv = *(const float*)(buf + b_rd + (t4 * 4 + e) * 128);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[e], bv, acc, 0, 0, 0);
+            }
+        }
+    };
+    const int n_my = ks1 - ks0;
+    if (n_my > 0) stage(my, ks0);
+    int slot = 0;
+    for (int i = 0; i < n_my; ++i) {
+        if (i + 1 < n_my) {
+            stage(my + (slot ^ 1) * SK_STAGE_BYTES, ks0 + i + 1); // its previous content (step i - 1) has been consumed
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // 8 DMA instructions per stage: step i + 1 stays in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        compute(my + slot * SK_STAGE_BYTES);
+        slot ^= 1;
+    }
+
+    // ---- the four partial tiles meet in LDS: [wave][row 32][col 32] ---------------------------------------------
+    __syncthreads();                                             // every wave is done with its stages
+    float* part = (float*)lds;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[wave * 1024 + (4 * lh + (r & 3) + 8 * (r >> 2)) * 32 + li] = acc[r];
+    __syncthreads();
+    const int row = tid >> 3, c4 = (tid & 7) * 4;
+    f32x4 v = *(const f32x4*)&part[row * 32 + c4];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) {
+        const f32x4 q = *(const f32x4*)&part[w * 1024 + row * 32 + c4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += q[e];
+    }
+    const int m = m0 + row, n = n0 + c4;
+    const long long addr = (long long)m * p.Cout + n;
+    if (p.fb_act < 0) {
+        if (m >= p.M) return;
+        f32x4 zv, y;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+        const f32x4 bias = p.bias ? *(const f32x4*)(p.bias + n) : zero4;
+        const f32x4 sc = p.scale ? *(const f32x4*)(p.scale + n) : one4, sh = p.scale ? *(const f32x4*)(p.shift + n) : zero4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) zv[e] = v[e] + bias[e];
+        if (p.z) *(f32x4*)(p.z + addr) = zv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = sc[e] * zv[e] + sh[e];
+        if (p.res_mode != MRCNN_RES_NONE) {
+            const f32x4 r4 = *(const f32x4*)(p.res + addr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] += r4[e];
+        }
+        if (p.act == MRCNN_ACT_RELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = fmaxf(y[e], 0.f);
+        } else if (p.act == MRCNN_ACT_SIGMOID) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = 1.f / (1.f + expf(-y[e]));
+        }
+        *(f32x4*)(p.out + addr) = y;
+        return;
+    }
+    // ---- data gradient: y = v (+ res) is d(loss)/d(out_below); apply that layer's epilogue backward ---------------
+    float* sums = part + 4 * 1024;                               // [3][32] column sums of this workgroup (behind the partial tiles)
+    if (tid < 96) sums[tid] = 0.f;
+    __syncthreads();
+    if (m < p.M) {
+        f32x4 g = v;
+        if (p.res_mode != MRCNN_RES_NONE) {
+            const f32x4 r4 = *(const f32x4*)(p.res + addr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] += r4[e];
+        }
+        if (p.fb_act == MRCNN_ACT_RELU) {
+            const f32x4 o4 = *(const f32x4*)(p.fb_out + addr);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = o4[e] > 0.f ? g[e] : 0.f;
+        }
+        const f32x4 one4 = {1.f, 1.f, 1.f, 1.f};
+        const f32x4 sc = p.fb_scale ? *(const f32x4*)(p.fb_scale + n) : one4;
+        f32x4 dz;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dz[e] = g[e] * sc[e];
+        *(f32x4*)(p.out + addr) = dz;
+        if (p.fb_dy) *(f32x4*)(p.fb_dy + addr) = g;
+        if (p.fb_dgamma) {
+            const f32x4 z4 = *(const f32x4*)(p.fb_z + addr), mu = *(const f32x4*)(p.fb_mean + n), rs = *(const f32x4*)(p.fb_rstd + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(&sums[32 + c4 + e], g[e] * (z4[e] - mu[e]) * rs[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { atomicAdd(&sums[c4 + e], g[e]); atomicAdd(&sums[64 + c4 + e], dz[e]); }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        if (p.fb_dbeta) atomicAdd(p.fb_dbeta + n0 + tid, sums[tid]);
+        if (p.fb_dgamma) atomicAdd(p.fb_dgamma + n0 + tid, sums[32 + tid]);
+        if (p.fb_dbias) atomicAdd(p.fb_dbias + n0 + tid, sums[64 + tid]);
+    }
+}
+
+static long long sk_max_tiles() { static const long long v = getenv("MRCNN_SK_MAX_TILES") ? atoll(getenv("MRCNN_SK_MAX_TILES")) : 512; return v; }
+// applicability window, measured (ResNet-101, layer loops and whole steps): 192 .. 512 tiles of 32 x 32 and >= 16 K-steps.
+// Fewer tiles (batch-1 detect: 64) leave three quarters of the SIMDs without a wave -- the old split over 16 K slices
+// spreads wider; more tiles than two per CU run in several rounds (M = 4 096: 39 vs 33 us); short K has nothing to split.
+// In the window: res4 2a 17.3 -> 10.6 us, 2b 26.0 -> 22.2 us per layer; sparse step 29.1 -> 28.5 ms.
+static long long sk_min_tiles() { static const long long v = getenv("MRCNN_SK_MIN_TILES") ? atoll(getenv("MRCNN_SK_MIN_TILES")) : 192; return v; }
+static int sk_min_steps() { static const int v = getenv("MRCNN_SK_MIN_STEPS") ? atoi(getenv("MRCNN_SK_MIN_STEPS")) : 16; return v; }
+
+// Shapes the single-launch kernel takes: a "fast" layer (Cin % 32 == 0), Cout % 32 == 0, dense NHWC output and residual,
+// 16-byte aligned operands, at most 64 taps, buffer-addressable tensors -- and small enough that the large-tile kernels
+// would not fill the chip (the caller decides that part).
+static bool conv_sk_ok(const mrcnn_conv_desc* d, const ConvArgs& a) {
+    static const bool on = !(getenv("MRCNN_SK_KERNEL") && getenv("MRCNN_SK_KERNEL")[0] == '0');
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    if (!on || !a.fastA || !a.dense || d->Cout % 32 || d->out_mode != MRCNN_OUT_NHWC || d->res_mode == MRCNN_RES_UP2) return false;
+    if (d->KH * d->KW > 64) return false;
+    const long long xb = (long long)d->N * d->H * d->W * d->Cin * 4 + ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
+    if (xb >= 0x7FFFFFF0LL || (long long)a.Ktot * d->Cout * 4 >= 0x7FFFFFF0LL) return false;
+    return al(a.w) && al(a.out) && al(a.z) && al(a.res) && al(a.bias) && al(a.scale) && al(a.shift) && al(a.fb_out) && al(a.fb_z) &&
+           al(a.fb_scale) && al(a.fb_mean) && al(a.fb_rstd) && al(a.fb_dy);
+}
+
 static void launch_splitk_reduction(const ConvArgs& a, hipStream_t s);
 
 template <int BM, int BN, int WM, int WN>
@@ -1020,6 +1232,16 @@ static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* 
         a.fb_dgamma = ep->dgamma; a.fb_dbeta = ep->dbeta; a.fb_dbias = ep->dbias;
         a.fb_dy = ep->dy;
         if (ep->dy && (reinterpret_cast<uintptr_t>(ep->dy) & 15)) return MRCNN_ERR_ARG;
+    }
+    // small layer that the planner would cut into K slices: one launch instead, the four waves of a workgroup split K
+    if (pl.ksplit > 1 && !pl.dma_split && conv_sk_ok(d, a) && (long long)((a.M + 31) / 32) * (d->Cout / 32) <= sk_max_tiles() &&
+        (long long)((a.M + 31) / 32) * (d->Cout / 32) >= sk_min_tiles() && a.nk >= sk_min_steps()) {
+        const long long xbytes = (long long)d->N * d->H * d->W * d->Cin * 4;
+        const long long shift = ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
+        a.ksplit = 1; a.ksteps = a.nk; a.slab = nullptr;
+        hipLaunchKernelGGL(conv_fwd_sk_kernel, dim3((unsigned)(((a.M + 31) / 32) * (d->Cout / 32))), dim3(256), 0, s, a, (unsigned)shift,
+                           (unsigned)(xbytes + shift));
+        return mrcnn_launch_status();
     }
     if (pl.dma_split && pl.ksplit > 1) {        // mid-size layer: LDS-DMA tiles, K cut into slices, slabs reduced by a second launch
         const int mt = (a.M + 127) / 128, nt = a.Cout / 128;
