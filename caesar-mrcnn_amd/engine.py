@@ -198,7 +198,8 @@ class MaskRCNNEngine(object):
         self.head_dtype = None
         self.loss_scale = 4096.0
         self.h16_wide = os.environ.get("MRCNN_H16_WIDE", "1") != "0"   # False: only the mask head in 16 bits (round-1 stages 1-2)
-        self.h16_blocks = os.environ.get("MRCNN_H16_BLOCKS", "1") != "0"   # identity blocks of res4 / res5 in 16 bits (stage 4)
+        self.h16_blocks = os.environ.get("MRCNN_H16_BLOCKS", "1") != "0"   # bottleneck blocks in 16 bits (stage 4)
+        self.h16_all_blocks = os.environ.get("MRCNN_H16_ALL_BLOCKS", "1") != "0"   # 0: only the identity blocks of res4 / res5
         self._h16 = {}
         self._h16_store = {}            # dtype -> {layer: (W^T image, data-gradient image)}, stable addresses
         self._h16_valid = False
@@ -286,7 +287,7 @@ class MaskRCNNEngine(object):
             for stage in self.stages:
                 for blk in stage:
                     if self._h16_block(blk):
-                        names += [blk.c2a.name, blk.c2b.name, blk.c2c.name]
+                        names += [blk.c2a.name, blk.c2b.name, blk.c2c.name] + ([blk.c1.name] if blk.c1 is not None else [])
         for name in names:
             op = self.op(name)
             if op.padding == "valid" and op.wshape[0] > 1:
@@ -305,9 +306,15 @@ class MaskRCNNEngine(object):
 
     @staticmethod
     def _h16_shape_ok(op):
-        """Shapes the 16-bit kernels take: forward Cin % 32 == 0, Cout % 128 == 0; weight gradient Cin % 256 == 0."""
+        """Shapes ALL 16-bit kernels take: forward Cin % 32 == 0, Cout % 128 == 0; weight gradient Cin % 256 == 0."""
         kh, kw, cin, cout = op.wshape
         return op.stride == 1 and cin % 256 == 0 and cout % 128 == 0 and kh * kw <= 64
+
+    @staticmethod
+    def _h16_fwd_ok(op):
+        """Shapes the small-tile forward / data-gradient kernel takes (both directions: Cin and Cout multiples of 64)."""
+        kh, kw, cin, cout = op.wshape
+        return cin % 64 == 0 and cout % 64 == 0 and kh * kw <= 64 and (op.stride == 1 or (kh == 1 and kw == 1))
 
     def _h16_layer(self, name):
         """True when layer `name` runs on the 16-bit matrix cores in the current mode."""
@@ -330,13 +337,31 @@ class MaskRCNNEngine(object):
         got = ops.epilogue_bwd_h16(d16, y if act != ACT_NONE else None, z, op.scale, op.mean, op.rstd, op.dgamma, op.dbeta, op.db,
                                    act, 1.0 / S, want_dy=want_dy)
         dz, dy = got if want_dy else (got, None)
-        self.wgrad_h16_async(x16, dz, op.wshape, op.dw, 1.0 / S, op.padding, accumulate_w)
+        if self._h16_shape_ok(op):
+            self.wgrad_h16_async(x16, dz, op.wshape, op.dw, 1.0 / S, op.padding, accumulate_w)
+        else:
+            self._wgrad_from_h16(op, x16, dz, 1.0 / S, accumulate_w)
         if not need_dx:
-            return (None, dy) if want_dy else None
+            return (dz, dy) if want_dy else dz                    # the caller issues the data gradient itself
         dx = self._h16_dgrad(op, dz, dx_res)
         return (dx, dy) if want_dy else dx
 
-    def _h16_dgrad(self, op, dz, dx_res=None):
+    def _wgrad_from_h16(self, op, x16, dz16, mult, accumulate):
+        """Weight gradient of a layer whose channel counts are below the 16-bit weight-gradient kernel's 256-channel tile
+        (res2 / res3, the first block of a stage): both operands are widened to float32 ON THE WEIGHT-GRADIENT STREAM and the
+        float32 kernel runs there -- off the critical path, which stays in 16 bits."""
+        ws = self.wgrad_stream
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(ws):
+            ws.wait_event(ev)
+            x32 = ops.cast_from_h16(x16)
+            dz32 = ops.cast_from_h16(dz16, mult)
+            ops.conv2d_wgrad(x32, dz32, op.wshape, op.stride, op.padding, dw=op.dw, accumulate=accumulate)
+        for t in (x16, dz16):
+            t.record_stream(ws)
+
+    def _h16_dgrad(self, op, dz, dx_res=None, out=None, out_strides=None):
         kh, kw, cin, cout = op.wshape
         if op.padding == "valid" and kh > 1:                     # FC as VALID conv: one GEMM over the flattened window
             M = dz.shape[0]
@@ -344,27 +369,48 @@ class MaskRCNNEngine(object):
                                 "valid", ACT_NONE)
             return dx.view(M, kh, kw, cin)
         return ops.conv2d_h16(dz, self._h16[op.name][1], (kh, kw, cout, cin), None, None, None, 1,
-                              ((kh - 1) // 2, (kw - 1) // 2) if op.padding == "same" else "valid", ACT_NONE, res=dx_res)
+                              ((kh - 1) // 2, (kw - 1) // 2) if op.padding == "same" else "valid", ACT_NONE, res=dx_res, out=out,
+                              out_strides=out_strides)
 
     # ---- identity bottleneck blocks in 16 bits (configs[4], stage 4) ------------------------------------------
     def _h16_block(self, blk):
-        """An identity block (mrcnn/model.py:99-131) whose three convolutions fit the 16-bit kernels -- res4 b.. and
-        res5 b, c (widths 256 / 1024 and 512 / 2048): 72 of ResNet-101's 104 convolutions."""
-        return (self.head_dtype is not None and self.h16_wide and self.h16_blocks and blk.c1 is None and
-                all(self._h16_shape_ok(o) for o in (blk.c2a, blk.c2b, blk.c2c)))
+        """A bottleneck block (mrcnn/model.py:99-172) that runs in 16 bits: every block whose convolutions fit the small-tile
+        kernel (channel counts multiples of 64: all of ResNet-50 / 101's 16 / 33 blocks) -- identity blocks and the first
+        block of each stage (projection shortcut, stride 2 on the 1x1 convolutions)."""
+        ops_ = [blk.c2a, blk.c2b, blk.c2c] + ([blk.c1] if blk.c1 is not None else [])
+        return (self.head_dtype is not None and self.h16_wide and self.h16_blocks and self.wgrad_stream is not None and
+                all(self._h16_fwd_ok(o) for o in ops_) and (self.h16_all_blocks or
+                                                             (blk.c1 is None and all(self._h16_shape_ok(o) for o in ops_))))
 
     def _block_fwd_h16(self, blk, x16, train):
         a, ca = self._h16_fwd(blk.c2a, x16, ACT_RELU, train)
         b, cb = self._h16_fwd(blk.c2b, a, ACT_RELU, train)
-        y, cc = self._h16_fwd(blk.c2c, b, ACT_RELU, train, res=x16)
-        return y, ("h16", ca, cb, cc)
+        sc, c1c = (x16, None) if blk.c1 is None else self._h16_fwd(blk.c1, x16, ACT_NONE, train)
+        y, cc = self._h16_fwd(blk.c2c, b, ACT_RELU, train, res=sc)
+        return y, ("h16", ca, cb, cc, c1c)
 
     def _block_bwd_h16(self, blk, d16, ctxs, S):
         """d16: gradient w.r.t. the block output (16 bit, times S) -> gradient w.r.t. the block input."""
-        _, ca, cb, cc = ctxs
+        _, ca, cb, cc, c1c = ctxs
         d_b, dy = self._h16_bwd(blk.c2c, d16, cc, S, want_dy=True)
         d_a = self._h16_bwd(blk.c2b, d_b, cb, S)
-        return self._h16_bwd(blk.c2a, d_a, ca, S, dx_res=dy)       # identity shortcut: dx = dgrad_2a + dy
+        if blk.c1 is None:
+            return self._h16_bwd(blk.c2a, d_a, ca, S, dx_res=dy)   # identity shortcut: dx = dgrad_2a + dy
+        # projection shortcut: dx = dgrad_1(dy) + dgrad_2a(d_a); with stride 2 both 1x1 data gradients scatter into the
+        # even pixels of a zeroed tensor (the second adds through the residual port, same strides)
+        x16 = ca[0]
+        N, H, W, C = x16.shape
+        st = blk.c2a.stride
+        dz1 = self._h16_bwd(blk.c1, dy, c1c, S, need_dx=False)
+        dza = self._h16_bwd(blk.c2a, d_a, ca, S, need_dx=False)
+        dx = ops.empty((N, H, W, C), x16.dtype, x16.device)
+        strides = None
+        if st != 1:
+            ops.fill_zero(dx)
+            strides = (H * W * C, st * W * C, st * C)
+        self._h16_dgrad(blk.c1, dz1, out=dx, out_strides=strides)
+        self._h16_dgrad(blk.c2a, dza, dx_res=dx, out=dx, out_strides=strides)
+        return dx
 
     def _S(self):
         return float(self.loss_scale) if self.head_dtype == torch.float16 else 1.0
@@ -538,7 +584,7 @@ class MaskRCNNEngine(object):
         else:
             x = ops.maxpool3x3s2(x)
         feats = []
-        x16 = None                                  # the running activation in 16 bits, between 16-bit blocks
+        x16 = None                                  # the running activation in 16 bits (valid beside or instead of x)
         for stage in self.stages:
             for blk in stage:
                 if self._h16_block(blk):
@@ -551,7 +597,8 @@ class MaskRCNNEngine(object):
                         tape[id(blk)] = ctx
                     continue
                 if x is None:
-                    x, x16 = ops.cast_from_h16(x16), None
+                    x = ops.cast_from_h16(x16)
+                x16 = None
                 a, ca = blk.c2a.forward(x, ACT_RELU, train=train)
                 b, cb = blk.c2b.forward(a, ACT_RELU, train=train)
                 if blk.c1 is not None:
@@ -561,8 +608,8 @@ class MaskRCNNEngine(object):
                 x, cc = blk.c2c.forward(b, ACT_RELU, res=sc, res_mode=RES_SAME, train=train)
                 if train:
                     tape[id(blk)] = (ca, cb, cc, c1c)
-            if x is None:                           # stage output: float32 for the FPN lateral and the next stage's first block
-                x, x16 = ops.cast_from_h16(x16), None
+            if x is None:                           # stage output in float32 for the FPN lateral (x16 stays valid for the next block)
+                x = ops.cast_from_h16(x16)
             feats.append(x)
         C2, C3, C4, C5 = feats
         P5s, tape["fpn_c5p5"] = self.op("fpn_c5p5").forward(C5, train=train)
@@ -1109,6 +1156,8 @@ class MaskRCNNEngine(object):
                         d16 = ops.cast_to_h16(d_out, self.head_dtype, multiplier=S)
                     d16 = self._block_bwd_h16(blk, d16, tape[id(blk)], S)
                     d_out = None
+                    if bi == 0 and si > 0:          # first block of a stage: its input C_(s-1) also feeds the FPN lateral
+                        d_out, d16 = ops.axpy_from_h16(d16, dC[si - 1], 1.0 / S), None
                     continue
                 if d_out is None:
                     d_out, d16 = ops.cast_from_h16(d16, 1.0 / S), None
@@ -1129,6 +1178,8 @@ class MaskRCNNEngine(object):
                 self.join_wgrad()
                 self.grad_ready(*self.grad_ranges[si + 2])
         assert not isinstance(d_out, tuple)             # the first block of the network has no block below it
+        if d_out is None:
+            d_out = ops.cast_from_h16(d16, 1.0 / S)
         am, pre_shape = tape["pool"]
         d_relu = ops.maxpool3x3s2_bwd(d_out, am, pre_shape)
         c1 = self.op("conv1")

@@ -164,9 +164,10 @@ def test_mixed_precision_training_step(dev, dtype, backbone, wide):
             forced = eng.last["rpn_rois"].clone()
         else:
             assert eng._h16_layer("rpn_conv_shared") == wide and eng._h16_layer("mrcnn_class_conv1") == wide
+            n16 = sum(eng._h16_block(b) for st in eng.stages for b in st)
             if backbone == "resnet50":
-                n16 = sum(eng._h16_block(b) for st in eng.stages for b in st)
-                assert n16 == 5 + 2, n16                    # res4 b-f, res5 b-c
+                assert n16 == 16, n16                       # every bottleneck block of ResNet-50
+            assert (n16 > 0) == wide
         res[mode] = (losses.cpu().numpy(), eng.get_weights(grads=True))
     tol = 1e-2 if dtype == torch.float16 else 4e-2
     np.testing.assert_allclose(res[dtype][0], res[None][0], rtol=tol)
@@ -177,14 +178,15 @@ def test_mixed_precision_training_step(dev, dtype, backbone, wide):
         err = float(np.abs(d).max()) / scale
         l2 = float(np.linalg.norm(d)) / max(float(np.linalg.norm(ref)), 1e-12)
         l2s.append(l2)
-        if backbone == "custom":
+        if n16 == 0:
             if err > 4 * tol:
                 bad.append((name, err))
-        elif l2 > 6 * tol:
-            # 16-bit activations AND gradients from block to block through seven bottleneck blocks: every layer rounds twice
+        elif l2 > 10 * tol:
+            # 16-bit activations AND gradients from block to block through all bottleneck blocks: every layer rounds twice
             # (11 / 8 significant bits) and an activation on the ReLU boundary may flip, which moves single elements by
-            # 5-15 % of the tensor's maximum (tools/h16_grad_diag.py: median L2 error 1.3 % f16 / 4.4 % bf16, the largest
-            # tensor 3.7 % / 9.8 %; with the blocks in float32 1.2 % / 2.6 %).  The bound is on the L2 error per tensor.
+            # 5-15 % of the tensor's maximum (tools/h16_grad_diag.py, ResNet-50: median L2 error 1.8 % f16 / 4.4 % bf16, the
+            # largest tensor 3.6 % / 9.8 %; 8.6 % on the 32-pixel res5 maps of the small test backbone; with the blocks in
+            # float32 1.2 % / 2.6 %).  The bound is on the L2 error per tensor.
             bad.append((name, l2))
     assert not bad, bad[:6]
     assert np.median(l2s) <= 2.5 * tol, np.median(l2s)
@@ -338,7 +340,7 @@ def test_conv_fwd_h16_small_tile(dev, case, dtype):
 def test_cfg5_r101_512_f16_training_step_vs_oracle(dev):
     """BASELINE configs[4] at its real sizes: ResNet-101+FPN 512x512, 512 train ROIs, 2000 proposals (2 images here: the
     float32 CPU oracle has to differentiate the same step), engine in its widest 16-bit mode (mask head, FPN smoothing,
-    shared RPN convolution, class-head FC layers, identity bottleneck blocks of res4 / res5 on the f16 MFMA; float32
+    shared RPN convolution, class-head FC layers and all 33 bottleneck blocks on the f16 MFMA; float32
     master weights / accumulation / gradients, loss scale 4096).  Against the FLOAT32 oracle's autograd on the ROIs and
     targets the engine sampled (fed to the oracle, as in test_cfg2 / cfg3):
       losses rtol 2e-2; every parameter gradient L2 error <= 8e-2 of its norm, median over tensors <= 2.5e-2
@@ -358,7 +360,7 @@ def test_cfg5_r101_512_f16_training_step_vs_oracle(dev):
     eng.sparse_mask_bwd = True
     losses = model.train_on_batch(inputs, rand_keys=keys, apply=False, keep_outputs=True)
     torch.cuda.synchronize()
-    assert sum(eng._h16_block(b) for st in eng.stages for b in st) == 22 + 2
+    assert sum(eng._h16_block(b) for st in eng.stages for b in st) == 33          # every bottleneck block of ResNet-101
     last = {k: v.cpu().numpy() for k, v in eng.last.items() if torch.is_tensor(v)}
     assert (last["counts"][:, 0] > 0).all(), last["counts"]
     eng.apply_gradients(0.0, 0.0, world_size=1)
