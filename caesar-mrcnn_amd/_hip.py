@@ -58,6 +58,11 @@ class BwdEpilogue(C.Structure):
         ("act", C.c_int32), ("dy", C.c_void_p)]
 
 
+class BwdEpilogueH16(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("out", "z", "scale", "mean", "rstd", "dgamma", "dbeta", "dbias")] + [
+        ("act", C.c_int32), ("dy", C.c_void_p), ("grad_multiplier", C.c_float)]
+
+
 class DetectionDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("R", C.c_int32), ("C", C.c_int32), ("max_instances", C.c_int32),
                 ("min_confidence", C.c_float), ("nms_threshold", C.c_float), ("bbox_std_dev", C.c_float * 4)]
@@ -108,6 +113,7 @@ _SIGNATURES = {
     "mrcnn_conv2d_fwd_h16": (C.c_int, [C.POINTER(ConvDesc), C.c_int] + [_P] * 8),
     "mrcnn_conv2d_fwd_h16_res": (C.c_int, [C.POINTER(ConvDesc), C.c_int] + [_P] * 9),
     "mrcnn_conv2d_fwd_h16_supported": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
+    "mrcnn_conv2d_dgrad_ep_h16": (C.c_int, [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, C.POINTER(BwdEpilogueH16), _P]),
     "mrcnn_conv2d_dgrad_ep": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, C.POINTER(BwdEpilogue), _P, C.c_size_t, _P]),
     "mrcnn_conv2d_wgrad_h16_workspace": (C.c_size_t, [C.POINTER(ConvDesc)]),
     "mrcnn_conv2d_wgrad_h16": (C.c_int, [C.POINTER(ConvDesc), C.c_int, _P, _P, _P, _P, C.c_size_t, C.c_int, C.c_float, _P]),

@@ -39,6 +39,9 @@ struct ConvH16Args {
     int out_mode, cmod; long long ons, ohs, ows;     // MRCNN_OUT_DECONV2: pixel-shuffle store of the 2x2 transposed conv
     const void* res;                                 // small-tile kernel: 16-bit tensor added before the activation (strides of out)
     int dense;                                       // out is plain NHWC [M][Cout]
+    // small-tile kernel as a data gradient fused with the epilogue backward of the layer below (mrcnn_conv2d_dgrad_ep_h16)
+    const void* fb_out; const void* fb_z; const float* fb_scale; const float* fb_mean; const float* fb_rstd;
+    float* fb_dgamma; float* fb_dbeta; float* fb_dbias; void* fb_dy; int fb_act; float fb_gmul;
 };
 
 #define H16_OOB_OFFSET 0xFFFFFFF0u
@@ -373,6 +376,50 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h16s_kernel(const ConvH16Args
     T* zo = (T*)p.z;
     const T* res = (const T*)p.res;
     const int n = n0 + wn * 32 + li;
+    if (p.fb_act >= 0) {
+        // data gradient: y = acc (+ res) is d(loss)/d(activated output of the layer below), times the loss scale.
+        //   g = y * act'(out_below);  dz = g * scale_below -> stored (and g as dy when asked);
+        //   dbeta += sum g, dgamma += sum g (z - mean) rstd, dbias += sum dz   (times fb_gmul = 1 / loss scale)
+        const T* bo = (const T*)p.fb_out;
+        const T* bz = (const T*)p.fb_z;
+        T* dyo = (T*)p.fb_dy;
+        const float sc = p.fb_scale ? p.fb_scale[n] : 1.f;
+        const float mu = p.fb_dgamma ? p.fb_mean[n] : 0.f, rs = p.fb_dgamma ? p.fb_rstd[n] : 0.f;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        const int mb = m0 + wm * 32 + 4 * lh;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mb + (r & 3) + 8 * (r >> 2);
+            if (m >= p.M) continue;
+            const long long addr = (long long)m * p.Cout + n;
+            float g = acc[r];
+            if (res) g += (float)res[addr];
+            if (p.fb_act == MRCNN_ACT_RELU) g = (float)bo[addr] > 0.f ? g : 0.f;
+            const float dz = g * sc;
+            out[addr] = (T)dz;
+            if (dyo) dyo[addr] = (T)g;
+            s0 += g;
+            if (p.fb_dgamma) s1 += g * ((float)bz[addr] - mu) * rs;
+            s2 += dz;
+        }
+        s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        __syncthreads();                                        // the K loop's stages are dead
+        float* red = (float*)lds;                               // [wm][64 columns][3]
+        if (lh == 0) {
+            red[(wm * 64 + wn * 32 + li) * 3 + 0] = s0;
+            red[(wm * 64 + wn * 32 + li) * 3 + 1] = s1;
+            red[(wm * 64 + wn * 32 + li) * 3 + 2] = s2;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int c = n0 + tid;
+            const float gm = p.fb_gmul;
+            if (p.fb_dbeta) atomicAdd(p.fb_dbeta + c, (red[tid * 3 + 0] + red[(64 + tid) * 3 + 0]) * gm);
+            if (p.fb_dgamma) atomicAdd(p.fb_dgamma + c, (red[tid * 3 + 1] + red[(64 + tid) * 3 + 1]) * gm);
+            if (p.fb_dbias) atomicAdd(p.fb_dbias + c, (red[tid * 3 + 2] + red[(64 + tid) * 3 + 2]) * gm);
+        }
+        return;
+    }
     const float cbias = p.bias ? p.bias[n] : 0.f;
     const float csc = p.scale ? p.scale[n] : 1.f, csh = p.scale ? p.shift[n] : 0.f;
     const int mb = m0 + wm * 32 + 4 * lh;
@@ -945,6 +992,8 @@ extern "C" int mrcnn_conv2d_wgrad_h16(const mrcnn_conv_desc* d, int dtype, const
 }
 
 
+static thread_local const mrcnn_bwd_epilogue_h16* g_h16_fb = nullptr;   // set around the call by mrcnn_conv2d_dgrad_ep_h16
+
 // Which 16-bit forward kernel a shape takes: 2 = small tile (64 x 64), 1 = large tile (256 x 128 / 256 x 256), 0 = none.
 static int h16_fwd_kernel_for(const mrcnn_conv_desc* d, const void* res) {
     if (!d || d->Cin % 32 || d->KH * d->KW > 64) return 0;
@@ -975,7 +1024,7 @@ extern "C" int mrcnn_conv2d_fwd_h16_res(const mrcnn_conv_desc* d, int dtype, con
         d->OH <= 0 || d->OW <= 0 || d->KH * d->KW > 64)
         return MRCNN_ERR_ARG;
     if (d->res_mode == MRCNN_RES_UP2 || (d->res_mode == MRCNN_RES_SAME) != (res != nullptr)) return MRCNN_ERR_ARG;
-    const int which = h16_fwd_kernel_for(d, res);
+    int which = h16_fwd_kernel_for(d, res);
     if (!which) return MRCNN_ERR_ARG;
     if (d->out_mode == MRCNN_OUT_DECONV2) {
         if (d->Cout != 4 * d->cmod || d->cmod % 128 || z_out) return MRCNN_ERR_ARG;
@@ -998,6 +1047,16 @@ extern "C" int mrcnn_conv2d_fwd_h16_res(const mrcnn_conv_desc* d, int dtype, con
     a.out_mode = d->out_mode; a.cmod = d->cmod; a.ons = d->out_n_stride; a.ohs = d->out_h_stride; a.ows = d->out_w_stride;
     a.dense = d->out_mode == MRCNN_OUT_NHWC && d->out_w_stride == d->Cout && d->out_h_stride == (int64_t)d->OW * d->Cout &&
               d->out_n_stride == (int64_t)d->OH * d->OW * d->Cout;
+    a.fb_act = -1; a.fb_out = a.fb_z = nullptr; a.fb_scale = a.fb_mean = a.fb_rstd = nullptr;
+    a.fb_dgamma = a.fb_dbeta = a.fb_dbias = nullptr; a.fb_dy = nullptr; a.fb_gmul = 1.f;
+    if (g_h16_fb) {                              // mrcnn_conv2d_dgrad_ep_h16: small-tile kernel only, dense, plain store
+        if (which != 2 && !(d->Cin % 64 == 0 && d->Cout % 64 == 0)) return MRCNN_ERR_UNSUPPORTED;
+        if (!a.dense || bias || scale || z_out || d->act != MRCNN_ACT_NONE || d->stride != 1) return MRCNN_ERR_UNSUPPORTED;
+        which = 2;
+        const mrcnn_bwd_epilogue_h16* ep = g_h16_fb;
+        a.fb_act = ep->act; a.fb_out = ep->out; a.fb_z = ep->z; a.fb_scale = ep->scale; a.fb_mean = ep->mean; a.fb_rstd = ep->rstd;
+        a.fb_dgamma = ep->dgamma; a.fb_dbeta = ep->dbeta; a.fb_dbias = ep->dbias; a.fb_dy = ep->dy; a.fb_gmul = ep->grad_multiplier;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (which == 2) {
         const unsigned blocks = (unsigned)(((M + 63) / 64) * (d->Cout / 64));
@@ -1040,6 +1099,17 @@ extern "C" int mrcnn_conv2d_fwd_h16_res(const mrcnn_conv_desc* d, int dtype, con
 extern "C" int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const void* x, const void* w_t, const float* bias,
                                     const float* scale, const float* shift, void* out, void* z_out, void* stream) {
     return mrcnn_conv2d_fwd_h16_res(d, dtype, x, w_t, bias, scale, shift, nullptr, out, z_out, stream);
+}
+
+extern "C" int mrcnn_conv2d_dgrad_ep_h16(const mrcnn_conv_desc* d, int dtype, const void* dz, const void* w_t, const void* res,
+                                         void* dz_below, const mrcnn_bwd_epilogue_h16* ep, void* stream) {
+    if (!ep) return MRCNN_ERR_ARG;
+    if ((ep->act != MRCNN_ACT_NONE && ep->act != MRCNN_ACT_RELU) || (ep->act == MRCNN_ACT_RELU && !ep->out)) return MRCNN_ERR_ARG;
+    if (ep->dgamma && (!ep->z || !ep->mean || !ep->rstd)) return MRCNN_ERR_ARG;
+    g_h16_fb = ep;
+    const int rc = mrcnn_conv2d_fwd_h16_res(d, dtype, dz, w_t, nullptr, nullptr, nullptr, res, dz_below, nullptr, stream);
+    g_h16_fb = nullptr;
+    return rc;
 }
 
 extern "C" int mrcnn_mask_out_fwd_h16(int dtype, const void* up, const float* w_mask, const float* b_mask, float* mask_out,

@@ -200,6 +200,7 @@ class MaskRCNNEngine(object):
         self.h16_wide = os.environ.get("MRCNN_H16_WIDE", "1") != "0"   # False: only the mask head in 16 bits (round-1 stages 1-2)
         self.h16_blocks = os.environ.get("MRCNN_H16_BLOCKS", "1") != "0"   # bottleneck blocks in 16 bits (stage 4)
         self.h16_all_blocks = os.environ.get("MRCNN_H16_ALL_BLOCKS", "1") != "0"   # 0: only the identity blocks of res4 / res5
+        self.h16_fused_bwd = os.environ.get("MRCNN_H16_FUSED_BWD", "1") != "0"     # 16-bit data gradients carry the lower layer's epilogue backward
         self._h16 = {}
         self._h16_store = {}            # dtype -> {layer: (W^T image, data-gradient image)}, stable addresses
         self._h16_valid = False
@@ -389,27 +390,56 @@ class MaskRCNNEngine(object):
         y, cc = self._h16_fwd(blk.c2c, b, ACT_RELU, train, res=sc)
         return y, ("h16", ca, cb, cc, c1c)
 
+    def _h16_wgrad(self, op, x16, dz, S, accumulate=False):
+        if self._h16_shape_ok(op):
+            self.wgrad_h16_async(x16, dz, op.wshape, op.dw, 1.0 / S, op.padding, accumulate)
+        else:
+            self._wgrad_from_h16(op, x16, dz, 1.0 / S, accumulate)
+
+    def _h16_dgrad_ep(self, op, dz, below, below_ctx, S):
+        """dz of layer `below` from the dz of layer `op` above it: the 16-bit data gradient with `below`'s epilogue
+        backward in its own epilogue (mrcnn_conv2d_dgrad_ep_h16); the two launches when the shape has no fused kernel."""
+        kh, kw, cin, cout = op.wshape
+        _, z, y, act = below_ctx
+        pad = ((kh - 1) // 2, (kw - 1) // 2) if op.padding == "same" else "valid"
+        if self.h16_fused_bwd and op.stride == 1:
+            got = ops.conv2d_dgrad_ep_h16(dz, self._h16[op.name][1], (kh, kw, cout, cin), pad, y if act != ACT_NONE else None, z,
+                                          below.scale, below.mean, below.rstd, below.dgamma, below.dbeta, below.db, act, 1.0 / S)
+            if got is not None:
+                return got
+        d = self._h16_dgrad(op, dz)
+        return ops.epilogue_bwd_h16(d, y if act != ACT_NONE else None, z, below.scale, below.mean, below.rstd, below.dgamma,
+                                    below.dbeta, below.db, act, 1.0 / S)
+
     def _block_bwd_h16(self, blk, d16, ctxs, S):
-        """d16: gradient w.r.t. the block output (16 bit, times S) -> gradient w.r.t. the block input."""
+        """d16: gradient w.r.t. the block output (16 bit, times S) -> gradient w.r.t. the block input.  Four launches on the
+        main stream for an identity block (output-stage backward, two data gradients that carry the backward epilogue of the
+        layer below, the last data gradient with the shortcut's gradient on its residual port); weight gradients on the side
+        stream."""
         _, ca, cb, cc, c1c = ctxs
-        d_b, dy = self._h16_bwd(blk.c2c, d16, cc, S, want_dy=True)
-        d_a = self._h16_bwd(blk.c2b, d_b, cb, S)
+        c2a, c2b, c2c = blk.c2a, blk.c2b, blk.c2c
+        dzc, dy = ops.epilogue_bwd_h16(d16, cc[2], cc[1], c2c.scale, c2c.mean, c2c.rstd, c2c.dgamma, c2c.dbeta, c2c.db, ACT_RELU,
+                                       1.0 / S, want_dy=True)
+        self._h16_wgrad(c2c, cc[0], dzc, S)
+        dzb = self._h16_dgrad_ep(c2c, dzc, c2b, cb, S)
+        self._h16_wgrad(c2b, cb[0], dzb, S)
+        dza = self._h16_dgrad_ep(c2b, dzb, c2a, ca, S)
+        self._h16_wgrad(c2a, ca[0], dza, S)
         if blk.c1 is None:
-            return self._h16_bwd(blk.c2a, d_a, ca, S, dx_res=dy)   # identity shortcut: dx = dgrad_2a + dy
-        # projection shortcut: dx = dgrad_1(dy) + dgrad_2a(d_a); with stride 2 both 1x1 data gradients scatter into the
+            return self._h16_dgrad(c2a, dza, dx_res=dy)           # identity shortcut: dx = dgrad_2a + dy
+        # projection shortcut: dx = dgrad_1(dy) + dgrad_2a(dza); with stride 2 both 1x1 data gradients scatter into the
         # even pixels of a zeroed tensor (the second adds through the residual port, same strides)
         x16 = ca[0]
         N, H, W, C = x16.shape
-        st = blk.c2a.stride
+        st = c2a.stride
         dz1 = self._h16_bwd(blk.c1, dy, c1c, S, need_dx=False)
-        dza = self._h16_bwd(blk.c2a, d_a, ca, S, need_dx=False)
         dx = ops.empty((N, H, W, C), x16.dtype, x16.device)
         strides = None
         if st != 1:
             ops.fill_zero(dx)
             strides = (H * W * C, st * W * C, st * C)
         self._h16_dgrad(blk.c1, dz1, out=dx, out_strides=strides)
-        self._h16_dgrad(blk.c2a, dza, dx_res=dx, out=dx, out_strides=strides)
+        self._h16_dgrad(c2a, dza, dx_res=dx, out=dx, out_strides=strides)
         return dx
 
     def _S(self):

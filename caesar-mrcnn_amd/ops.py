@@ -660,6 +660,26 @@ def conv2d_h16(x, w_t, kshape, bias=None, scale=None, shift=None, stride=1, padd
     return out
 
 
+def conv2d_dgrad_ep_h16(dz, w_t, kshape, padding, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, act,
+                        grad_multiplier=1.0, res=None, want_dy=False):
+    """16-bit data gradient fused with the epilogue backward of the layer below (mrcnn_conv2d_dgrad_ep_h16).  Returns
+    dz_below (or (dz_below, dy)), or None when the shape has no fused kernel."""
+    _need_cuda(dz, w_t, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, res)
+    d = conv_desc(tuple(dz.shape), tuple(kshape), 1, padding, ACT_NONE, RES_SAME if res is not None else RES_NONE)
+    ep = _hip.BwdEpilogueH16()
+    ep.out, ep.z, ep.scale, ep.mean, ep.rstd = ptr(below_out), ptr(below_z), ptr(scale), ptr(mean), ptr(rstd)
+    ep.dgamma, ep.dbeta, ep.dbias, ep.act = ptr(dgamma), ptr(dbeta), ptr(dbias), act
+    out = empty((d.N, d.OH, d.OW, d.Cout), dz.dtype, dz.device)
+    dy = empty((d.N, d.OH, d.OW, d.Cout), dz.dtype, dz.device) if want_dy else None
+    ep.dy, ep.grad_multiplier = ptr(dy), float(grad_multiplier)
+    rc = _hip.lib().mrcnn_conv2d_dgrad_ep_h16(C.byref(d), _H16[dz.dtype], ptr(dz), ptr(w_t), ptr(res), ptr(out), C.byref(ep),
+                                              current_stream())
+    if rc == ERR_UNSUPPORTED:
+        return None
+    check(rc, "mrcnn_conv2d_dgrad_ep_h16")
+    return (out, dy) if want_dy else out
+
+
 def conv2d_h16_supported(x_shape, kshape, stride=1, padding="same", res=False):
     d = conv_desc(tuple(x_shape), tuple(kshape), stride, padding)
     return bool(_hip.lib().mrcnn_conv2d_fwd_h16_supported(C.byref(d), 1 if res else 0))

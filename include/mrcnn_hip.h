@@ -267,6 +267,20 @@ int mrcnn_conv2d_fwd_h16(const mrcnn_conv_desc* d, int dtype, const void* x, con
 int mrcnn_conv2d_fwd_h16_res(const mrcnn_conv_desc* d, int dtype, const void* x, const void* w_t, const float* bias,
                              const float* scale, const float* shift, const void* res, void* out, void* z_out, void* stream);
 int mrcnn_conv2d_fwd_h16_supported(const mrcnn_conv_desc* d, int has_res);
+/* mrcnn_conv2d_dgrad_ep in 16 bits (small-tile kernel: Cin % 64 == 0, Cout % 64 == 0, stride 1, dense output): the data
+ * gradient y = conv(dz, w_t) (+ res), fused with the epilogue backward of the layer below -- stored is
+ * dz_below = y * act'(out_below) * scale_below (and dy = y * act' when asked); dbeta / dgamma / dbias accumulate in
+ * float32, multiplied by grad_multiplier (1 / loss scale).  MRCNN_ERR_UNSUPPORTED for other shapes.                */
+typedef struct mrcnn_bwd_epilogue_h16 {
+    const void* out; const void* z;              /* 16-bit activated output / pre-BN value of the layer below */
+    const float* scale; const float* mean; const float* rstd;
+    float* dgamma; float* dbeta; float* dbias;
+    int32_t act;                                 /* MRCNN_ACT_NONE or MRCNN_ACT_RELU */
+    void* dy;                                    /* optional second output (16 bit) */
+    float grad_multiplier;
+} mrcnn_bwd_epilogue_h16;
+int mrcnn_conv2d_dgrad_ep_h16(const mrcnn_conv_desc* d, int dtype, const void* dz, const void* w_t, const void* res,
+                              void* dz_below, const mrcnn_bwd_epilogue_h16* ep, void* stream);
 int mrcnn_weights_to_h16(const float* w_hwio, void* wt_fwd, void* wt_dgrad, int KH, int KW, int Cin, int Cout,
                          int dtype, void* stream);
 /* Weight gradient with 16-bit operands x [N,H,W,Cin], dy [N,OH,OW,Cout]: dw (float32, HWIO) = multiplier * sum

@@ -385,3 +385,40 @@ def test_cfg5_r101_512_f16_training_step_vs_oracle(dev):
             bad.append((name, l2))
     assert not bad, bad[:8]
     assert np.median(l2s) <= 2.5e-2, np.median(l2s)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("k,cin,cout,use_res", [(1, 1024, 256, False), (3, 256, 256, False), (1, 256, 1024, True), (3, 64, 64, False)])
+def test_conv_dgrad_ep_h16_equals_two_launches(dev, dtype, k, cin, cout, use_res):
+    """mrcnn_conv2d_dgrad_ep_h16 == mrcnn_conv2d_fwd_h16 (small tile) followed by mrcnn_epilogue_bwd_h16: the fused store rounds
+    y * act' * scale once where the pair rounds y first, so dz agrees to one 16-bit rounding (2^-10 / 2^-7 of the maximum) and
+    the float32 channel sums to the same; dy (= y * act') likewise."""
+    ops = _ops()
+    rng = np.random.default_rng(k * 1000 + cin + cout)
+    N, H, W = 3, 13, 11                                         # M = 429: ragged against the 64-row tile
+    S = 1024.0
+    dz = torch.tensor(rng.standard_normal((N, H, W, cin)).astype(np.float32), device=dev).to(dtype)
+    w = torch.tensor((rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32), device=dev)
+    wf, _ = ops.weights_to_h16(w, dtype)
+    y_below = torch.relu(torch.tensor(rng.standard_normal((N, H, W, cout)).astype(np.float32), device=dev)).to(dtype)
+    z_below = torch.tensor(rng.standard_normal((N, H, W, cout)).astype(np.float32), device=dev).to(dtype)
+    scale, mean, rstd = (torch.tensor(rng.uniform(0.5, 1.5, cout).astype(np.float32), device=dev) for _ in range(3))
+    res = torch.tensor(rng.standard_normal((N, H, W, cout)).astype(np.float32), device=dev).to(dtype) if use_res else None
+    pad = ((k - 1) // 2, (k - 1) // 2) if k > 1 else "valid"
+    os.environ["MRCNN_H16_SMALL"] = "1"
+    try:
+        sums = [torch.zeros(cout, device=dev) for _ in range(3)]
+        got = ops.conv2d_dgrad_ep_h16(dz, wf, (k, k, cin, cout), pad, y_below, z_below, scale, mean, rstd, sums[0], sums[1], sums[2], 1,
+                                      1.0 / S, res=res, want_dy=True)
+        assert got is not None
+        y = ops.conv2d_h16(dz, wf, (k, k, cin, cout), None, None, None, 1, pad, 0, res=res)
+        rs = [torch.zeros(cout, device=dev) for _ in range(3)]
+        ref, ref_dy = ops.epilogue_bwd_h16(y, y_below, z_below, scale, mean, rstd, rs[0], rs[1], rs[2], 1, 1.0 / S, want_dy=True)
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["MRCNN_H16_SMALL"]
+    for a, b, name in ((got[0], ref, "dz"), (got[1], ref_dy, "dy")):
+        err = float((a.float() - b.float()).abs().max()) / float(b.float().abs().max())
+        assert err <= 2 * TOL[dtype], (name, err)
+    for a, b in zip(sums, rs):
+        torch.testing.assert_close(a, b, rtol=4 * TOL[dtype], atol=4 * TOL[dtype] * float(b.abs().max()))
