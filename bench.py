@@ -348,6 +348,20 @@ def _detect_leg(args, res, eng, dev_inputs, dev, backbone, run_py_config, torch)
         eng.infer_graphed(x1, win)
     torch.cuda.synchronize()
     res["detect_ms"] = (time.time() - t1) / args.detect_iters * 1e3
+    # reduced precision, reported separately: the same detect with the 16-bit stages (mask head, FPN smoothing, RPN, class FCs,
+    # bottleneck blocks) -- never `detect_ms_per_image`
+    try:
+        eng.head_dtype = torch.float16
+        for _ in range(2):
+            eng.infer_graphed(x1, win)
+        torch.cuda.synchronize()
+        t1 = time.time()
+        for _ in range(args.detect_iters):
+            eng.infer_graphed(x1, win)
+        torch.cuda.synchronize()
+        res["detect_ms_f16"] = (time.time() - t1) / args.detect_iters * 1e3
+    finally:
+        eng.head_dtype = None
     # the same graph on 8 tiles at once (detect() takes a list of images): what batching buys on the latency-bound backbone
     x8 = x1.expand(8, -1, -1, -1).contiguous()
     win8 = win.expand(8, -1).contiguous()
@@ -539,6 +553,7 @@ def main():
                        "weights": "random init (Keras defaults)"},
             "detect_ms_per_image": rnd(r["detect_ms"]), "detect_ms_per_image_eager": rnd(r["detect_eager_ms"]),
             "detect_ms_per_image_batch8": rnd(r["detect_ms_b8"]),
+            "detect_ms_per_image_f16_stages": rnd(r.get("detect_ms_f16")),
             "value_exact_zero_skip": None if args.dense_only else round(r["images_per_s_sparse"], 3),
             "note_exact_zero_skip": "same step with the mask head (forward and backward) run on the <=168 positive-quota ROI "
                                     "rows per image only: the other rows are never read by the loss and carry exactly-zero "

@@ -146,6 +146,78 @@ _SIGNATURES = {
 }
 
 _lib = None
+_proxy = None
+_tape = None          # a list while a step is being recorded (engine.step_taped), else None
+
+# entry points that launch nothing (pure queries / process state): never recorded
+_NO_RECORD = ("_workspace", "_supported", "_status_offset", "_version", "mrcnn_allreduce_", "_scratch")
+
+
+class _LibProxy(object):
+    """What lib() hands out: the ctypes library with every launching entry point wrapped so that, while a tape is open,
+    the call (function, arguments) is appended to it after it ran.  Replaying the tape issues exactly the same launches
+    without re-running the Python that built their arguments (descriptors, workspace look-ups, shape logic): a step's
+    ~700-1000 launches cost 14-21 ms of Python when issued from the engine and ~2-3 ms from the tape."""
+
+    def __init__(self, real):
+        self._real = real
+
+    def __getattr__(self, name):
+        real = getattr(self._real, name)
+        if any(k in name for k in _NO_RECORD):
+            f = real
+        else:
+            def f(*args, _real=real):
+                rc = _real(*args)
+                t = _tape
+                if t is not None and not rc:    # a refusal (MRCNN_ERR_UNSUPPORTED: the caller falls back) launched nothing
+                    t.append((_real, args))
+                return rc
+        setattr(self, name, f)              # next look-up skips __getattr__
+        return f
+
+
+def tape_begin():
+    global _tape
+    _tape = []
+    return _tape
+
+
+def tape_end():
+    global _tape
+    t, _tape = _tape, None
+    return t
+
+
+def tape_replay(tape):
+    """Issue the recorded calls again.  C entry points return a status (0 = ok); torch stream / event methods return None."""
+    for f, a in tape:
+        rc = f(*a)
+        if rc:
+            raise HipPathError("replayed launch %s failed with status %r" % (getattr(f, "__name__", f), rc))
+
+
+def ev_record(stream):
+    """A new event recorded on `stream` (torch objects); part of the tape while one is open."""
+    import torch
+    ev = torch.cuda.Event()
+    ev.record(stream)
+    if _tape is not None:
+        _tape.append((ev.record, (stream,)))
+    return ev
+
+
+def ev_wait(stream, ev):
+    stream.wait_event(ev)
+    if _tape is not None:
+        _tape.append((stream.wait_event, (ev,)))
+
+
+def stream_wait(a, b):
+    """a waits for everything enqueued on b so far."""
+    a.wait_stream(b)
+    if _tape is not None:
+        _tape.append((a.wait_stream, (b,)))
 
 
 def exported_symbols():
@@ -154,8 +226,8 @@ def exported_symbols():
 
 
 def lib():
-    """Load (once) and return the kernel library; never falls back to anything else."""
-    global _lib
+    """Load (once) and return the kernel library (behind the recording proxy); never falls back to anything else."""
+    global _lib, _proxy
     if _lib is None:
         why = ""
         if not os.path.exists(LIB_PATH):
@@ -181,7 +253,8 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         _lib = l
-    return _lib
+        _proxy = _LibProxy(l)
+    return _proxy
 
 
 def check(status, what):

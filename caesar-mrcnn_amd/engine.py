@@ -15,6 +15,7 @@ import numpy as np
 import torch
 
 from . import ops
+from . import _hip as _hip_mod
 from ._hip import ACT_NONE, ACT_RELU, ACT_SIGMOID, RES_NONE, RES_SAME, RES_UP2
 from .params import ParamLayout, deconv_gemm_to_keras, deconv_keras_to_gemm, granule_coefficients, init_weights
 
@@ -182,6 +183,7 @@ class MaskRCNNEngine(object):
         self._anchor_cache = {}
         self._infer_graphs = {}
         self._train_graphs = {}
+        self._train_tapes = {}
         # contiguous gradient ranges in the order the backward pass finalises them (for overlapped
         # data-parallel reduction): heads+RPN+FPN kernels, then res5..res2, then conv1 + BatchNorm blocks
         first = lambda prefix: min(o for n_, (o, _, _) in L.offsets.items() if n_.startswith(prefix) and "/kernel" in n_)
@@ -233,10 +235,9 @@ class MaskRCNNEngine(object):
         if ws is None:
             ops.conv2d_wgrad(x, dz, wshape, stride, padding, dw=dw, accumulate=accumulate)
             return
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.dev))
+        ev = _hip_mod.ev_record(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(ws):
-            ws.wait_event(ev)
+            _hip_mod.ev_wait(ws, ev)
             ops.conv2d_wgrad(x, dz, wshape, stride, padding, dw=dw, accumulate=accumulate)
         dz.record_stream(ws)
         x.record_stream(ws)
@@ -253,10 +254,9 @@ class MaskRCNNEngine(object):
         if ws is None:
             run()
             return
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.dev))
+        ev = _hip_mod.ev_record(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(ws):
-            ws.wait_event(ev)
+            _hip_mod.ev_wait(ws, ev)
             run()
         for x, dz, *_ in items:
             dz.record_stream(ws)
@@ -267,10 +267,9 @@ class MaskRCNNEngine(object):
         if ws is None:
             ops.conv2d_wgrad_h16(x, dz, wshape, 1, padding, dw=dw, accumulate=accumulate, multiplier=multiplier)
             return
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.dev))
+        ev = _hip_mod.ev_record(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(ws):
-            ws.wait_event(ev)
+            _hip_mod.ev_wait(ws, ev)
             ops.conv2d_wgrad_h16(x, dz, wshape, 1, padding, dw=dw, accumulate=accumulate, multiplier=multiplier)
         dz.record_stream(ws)
         x.record_stream(ws)
@@ -352,10 +351,9 @@ class MaskRCNNEngine(object):
         (res2 / res3, the first block of a stage): both operands are widened to float32 ON THE WEIGHT-GRADIENT STREAM and the
         float32 kernel runs there -- off the critical path, which stays in 16 bits."""
         ws = self.wgrad_stream
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.dev))
+        ev = _hip_mod.ev_record(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(ws):
-            ws.wait_event(ev)
+            _hip_mod.ev_wait(ws, ev)
             x32 = ops.cast_from_h16(x16)
             dz32 = ops.cast_from_h16(dz16, mult)
             ops.conv2d_wgrad(x32, dz32, op.wshape, op.stride, op.padding, dw=op.dw, accumulate=accumulate)
@@ -484,7 +482,7 @@ class MaskRCNNEngine(object):
 
     def join_wgrad(self):
         if self.wgrad_stream is not None:
-            torch.cuda.current_stream(self.dev).wait_stream(self.wgrad_stream)
+            _hip_mod.stream_wait(torch.cuda.current_stream(self.dev), self.wgrad_stream)
 
     # ---- deferred mask-head weight gradients ----------------------------------------------------------
     def _mask_wgrad(self, kind, *args):
@@ -503,13 +501,12 @@ class MaskRCNNEngine(object):
         if not self._deferred:
             return
         aux, main = self.aux_stream, torch.cuda.current_stream(self.dev)
-        ev = torch.cuda.Event()
-        ev.record(main)
+        ev = _hip_mod.ev_record(main)
         if self.defer_lds_pad:
             ops.tuning_set("wgrad_lds_pad", self.defer_lds_pad)
         try:
             with torch.cuda.stream(aux):
-                aux.wait_event(ev)
+                _hip_mod.ev_wait(aux, ev)
                 for kind, a in self._deferred:
                     if kind == "f32":
                         x, dz, wshape, stride, padding, dw, acc = a
@@ -527,7 +524,7 @@ class MaskRCNNEngine(object):
 
     def join_aux(self):
         if getattr(self, "_aux_pending", False):
-            torch.cuda.current_stream(self.dev).wait_stream(self.aux_stream)
+            _hip_mod.stream_wait(torch.cuda.current_stream(self.dev), self.aux_stream)
             self._aux_pending = False
 
     # ---- weights in / out (Keras layouts at this boundary) --------------------------------------
@@ -802,11 +799,11 @@ class MaskRCNNEngine(object):
             sx.copy_(images)
             sw.copy_(windows_norm)
             side = torch.cuda.Stream(device=self.dev)
-            side.wait_stream(torch.cuda.current_stream(self.dev))
+            _hip_mod.stream_wait(side, torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(side):
                 for _ in range(2):                      # sizes every workspace / caches the anchors
                     self.infer(sx, sw)
-            torch.cuda.current_stream(self.dev).wait_stream(side)
+            _hip_mod.stream_wait(torch.cuda.current_stream(self.dev), side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self.infer(sx, sw)
@@ -850,22 +847,19 @@ class MaskRCNNEngine(object):
         # the weight-gradient stream beside the forward pass (0.2 ms off the critical path)
         prep_ev = None
         if self.wgrad_stream is not None:
-            ev0 = torch.cuda.Event()
-            ev0.record(torch.cuda.current_stream(self.dev))
+            ev0 = _hip_mod.ev_record(torch.cuda.current_stream(self.dev))
             h16_ev = None
             with torch.cuda.stream(self.wgrad_stream):
-                self.wgrad_stream.wait_event(ev0)
+                _hip_mod.ev_wait(self.wgrad_stream, ev0)
                 if self.head_dtype is not None:
                     self._ensure_h16()                 # 16-bit weight images: first needed by the FPN (wide mode) / after the trunk
-                    h16_ev = torch.cuda.Event()
-                    h16_ev.record(self.wgrad_stream)
+                    h16_ev = _hip_mod.ev_record(self.wgrad_stream)
                 ops.fill_zero(self.grads)
                 if not self.wt_valid:
                     self.refresh_wt()
-            prep_ev = torch.cuda.Event()
-            prep_ev.record(self.wgrad_stream)
+            prep_ev = _hip_mod.ev_record(self.wgrad_stream)
             if h16_ev is not None and self.h16_wide:
-                torch.cuda.current_stream(self.dev).wait_event(h16_ev)
+                _hip_mod.ev_wait(torch.cuda.current_stream(self.dev), h16_ev)
         else:
             ops.fill_zero(self.grads)
             if not self.wt_valid:
@@ -898,15 +892,14 @@ class MaskRCNNEngine(object):
         else:
             rois_m = rois
         if prep_ev is not None and self.head_dtype is not None:
-            main.wait_event(prep_ev)                    # the mask head reads the 16-bit weight images prepared on the side stream
+            _hip_mod.ev_wait(main, prep_ev)                    # the mask head reads the 16-bit weight images prepared on the side stream
         if aux is not None:
-            ev = torch.cuda.Event()
-            ev.record(main)
+            ev = _hip_mod.ev_record(main)
             with torch.cuda.stream(aux):
-                aux.wait_event(ev)
+                _hip_mod.ev_wait(aux, ev)
                 logits, probs, mbbox, ctx_cls = self._class_head_fwd(rois, pyr[:4], area, True)
             mmask, ctx_mask = self._mask_head_fwd(rois_m, pyr[:4], area, True)
-            main.wait_stream(aux)
+            _hip_mod.stream_wait(main, aux)
             for t in (logits, probs, mbbox):
                 t.record_stream(main)
             rois.record_stream(aux)
@@ -924,26 +917,24 @@ class MaskRCNNEngine(object):
                                  cfg.MASK_LOSS_FUNCTION == "dice_coef_loss")
         losses, d_rpn_logits, d_rpn_bbox, d_logits, d_mbbox, d_mmask = out
         if prep_ev is not None:
-            main.wait_event(prep_ev)
+            _hip_mod.ev_wait(main, prep_ev)
 
         # ---- pyramid gradient accumulators ------------------------------------------------------
         dP = [ops.empty_like(p) for p in pyr[:4]]
         for t in dP:
             ops.fill_zero(t)
         if aux is not None:
-            ev = torch.cuda.Event()
-            ev.record(main)
+            ev = _hip_mod.ev_record(main)
             with torch.cuda.stream(aux):
-                aux.wait_event(ev)
+                _hip_mod.ev_wait(aux, ev)
                 self._class_head_bwd(d_logits, d_mbbox, ctx_cls, rois, dP, area)
                 # the RPN backward needs nothing from the heads: it follows the class head on this stream, beside the
                 # (much longer) mask head.  Its data gradients add to dP with plain read-modify-writes, so the mask head's
                 # ROIAlign adjoint (atomics on the same maps, last thing on the main stream) waits for this event.
                 dP6 = self._rpn_bwd(d_rpn_logits, d_rpn_bbox, rpn_tape, dP)
-                ev_aux = torch.cuda.Event()
-                ev_aux.record(aux)
+                ev_aux = _hip_mod.ev_record(aux)
             self._mask_head_bwd(d_mmask, ctx_mask, rois_m, dP, area, before_adjoint=ev_aux)
-            main.wait_stream(aux)
+            _hip_mod.stream_wait(main, aux)
             for t in (d_logits, d_mbbox, d_rpn_logits, d_rpn_bbox):
                 t.record_stream(aux)
         else:
@@ -1040,7 +1031,7 @@ class MaskRCNNEngine(object):
             d = ops.cast_from_h16(d16, 1.0 / S)
         B, R = rois.shape[0], rois.shape[1]
         if before_adjoint is not None:
-            torch.cuda.current_stream(self.dev).wait_event(before_adjoint)
+            _hip_mod.ev_wait(torch.cuda.current_stream(self.dev), before_adjoint)
         # scatter form here: the gather form measured 2 ms slower on the positive rows (14x14 samples of ~150 overlapping
         # positives: >1000 rows on the hottest pixels) and the dense head relies on the skipping of exactly-zero rows
         ops.roialign_bwd(rois, d.view(B, R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1), dP, cfg.MASK_POOL_SIZE, area)
@@ -1290,7 +1281,7 @@ class MaskRCNNEngine(object):
             # two eager steps size every workspace, arena slot and weight image; they must not count as training steps
             keep = (self.params.clone(), self.momentum.clone())
             side = torch.cuda.Stream(device=self.dev)
-            side.wait_stream(main)
+            _hip_mod.stream_wait(side, main)
             with torch.cuda.stream(side):
                 for _ in range(2):
                     self.forward_backward(*static)
@@ -1299,7 +1290,7 @@ class MaskRCNNEngine(object):
                 self.momentum.copy_(keep[1])
                 self.wt_valid = self._h16_valid = False
                 self.fold_bn()
-            main.wait_stream(side)
+            _hip_mod.stream_wait(main, side)
             del keep
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
@@ -1313,6 +1304,49 @@ class MaskRCNNEngine(object):
                 s_.copy_(t, non_blocking=True)
         graph.replay()
         # the captured step ends with the optimiser: the flipped / 16-bit weight images are stale for eager callers
+        self.wt_valid = self._h16_valid = False
+        return losses
+
+    def step_taped(self, dev_inputs, learning_rate, momentum):
+        """forward_backward + apply_gradients (single rank) from a recorded launch tape (_hip.tape_*): the first call per
+        input signature / rates / mode runs the step through the engine while every launch -- C-ABI calls with their
+        descriptors and pointers, event records / waits between the three streams -- is written down; later calls copy the
+        inputs into the recording's buffers and issue the same calls again.  Same launches on the same streams in the same
+        order as the eager step (so, unlike the HIP-graph replay, the same overlap), without the engine's Python per launch.
+        Valid because the step arena, the workspaces and the weight images have stable addresses."""
+        key = (tuple((tuple(t.shape), t.dtype) for t in dev_inputs), float(learning_rate), float(momentum), self.head_dtype,
+               self.sparse_mask_bwd, self.h16_wide, self.h16_blocks, self.h16_all_blocks, id(self.cfg),
+               torch.cuda.current_stream(self.dev).cuda_stream)
+        entry = self._train_tapes.get(key)
+        if entry is None:
+            assert self.grad_ready is None, "the launch tape is single-rank: gradient hooks are not recorded"
+            static = [torch.empty_like(t) for t in dev_inputs]
+            for s_, t in zip(static, dev_inputs):
+                s_.copy_(t)
+            # one eager step settles arena slots, workspaces and weight images (rolled back: it is not a training step)
+            keep = (self.params.clone(), self.momentum.clone())
+            self.forward_backward(*static)
+            self.apply_gradients(learning_rate, momentum, 1)
+            self.params.copy_(keep[0])
+            self.momentum.copy_(keep[1])
+            self.wt_valid = self._h16_valid = False
+            self.fold_bn()
+            del keep
+            _hip_mod.tape_begin()
+            try:
+                losses = self.forward_backward(*static)
+                self.apply_gradients(learning_rate, momentum, 1)
+            finally:
+                tape = _hip_mod.tape_end()
+            # the recorded pointers are arena slots and workspaces: hold them, so a later step of another shape or mode
+            # (which replaces slots) cannot hand their memory to someone else while this tape is alive
+            self._train_tapes[key] = (tape, static, losses, list(self.arena.slots), list(ops._ws_cache.values()))
+            return losses                                   # the recording pass was this step
+        tape, static, losses = entry[:3]
+        for s_, t in zip(static, dev_inputs):
+            if s_.data_ptr() != t.data_ptr():
+                s_.copy_(t, non_blocking=True)
+        _hip_mod.tape_replay(tape)
         self.wt_valid = self._h16_valid = False
         return losses
 

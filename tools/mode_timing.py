@@ -23,9 +23,12 @@ for sparse in (False, True):
             continue
         eng.sparse_mask_bwd, eng.head_dtype = sparse, hd
         graphed = os.environ.get("MRCNN_TRAIN_GRAPH", "0") != "0"
+        taped = os.environ.get("MRCNN_TRAIN_TAPE", "0") != "0"
 
         def step():
-            if graphed:
+            if taped:
+                eng.step_taped(inp, cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM)
+            elif graphed:
                 eng.step_graphed(inp, cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM)
             else:
                 eng.forward_backward(*inp); eng.apply_gradients(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM, 1)
@@ -35,4 +38,4 @@ for sparse in (False, True):
         for _ in range(10):
             step()
         torch.cuda.synchronize(); dt = (time.time() - t0) / 10
-        print("sparse=%-5s head=%-14s %s %.2f ms/step  %.1f img/s" % (sparse, hd, "graph" if graphed else "eager", dt * 1e3, nimg / dt))
+        print("sparse=%-5s head=%-14s %s %.2f ms/step  %.1f img/s" % (sparse, hd, "tape" if taped else "graph" if graphed else "eager", dt * 1e3, nimg / dt))
