@@ -24,10 +24,12 @@ template <typename T> struct H16Traits;
 template <> struct H16Traits<_Float16> {
     typedef f16x8 v8;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 };
 template <> struct H16Traits<__bf16> {
     typedef bf16x8 v8;
     static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x4 mfma16(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 };
 
 static int h16_dtype_ok(int dtype) { return dtype == MRCNN_DTYPE_F16 || dtype == MRCNN_DTYPE_BF16; }
@@ -255,6 +257,225 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, NBUF <= 3 ? 2 : (WAVES_M * 
                 else if (p.act == MRCNN_ACT_SIGMOID) y = 1.f / (1.f + expf(-y));
                 out[addr] = (T)y;
             }
+        }
+    }
+}
+
+// Phased 256 x 256 tile for the big layers (mask head: M = 401 408, N = 256, K = 2 304): 8 waves = two groups of four
+// (wr = wave >> 2; waves w and w + 4 share a SIMD), each wave 128 pixels x 64 channels as 8 x 4 tiles of
+// v_mfma_f32_16x16x32, K-step 64, two 64 KiB stages.  A K-step is four phases of
+//     [operand reads for this phase | one quarter of a later stage by LDS-DMA | s_waitcnt vmcnt(8)]  s_barrier
+//     [16 MFMAs = one quadrant of the wave's tile x K 64, raised priority]                            s_barrier
+// and group 1 runs ONE barrier behind group 0 (it takes an extra s_barrier first): while one wave of a SIMD is in its
+// MFMA half the other is in its read/DMA half, so the matrix pipe sees MFMAs back to back instead of both waves issuing
+// loads in lockstep.  Same source for both groups -- no duplicated bodies, no spills.
+//   quadrants  P1 reads X0 (pixel rows 0..63 of the wave) + W0 (channels 0..31), P2 W1, P3 X1, P4 nothing (W0 is kept):
+//              (X0,W0) (X0,W1) (X1,W1) (X1,W0); 24 ds_read_b128 per wave and K-step.
+//   staging    a stage is cut in the four quarters the phases consume -- A0 = X0 rows of both groups, B0 = W0 channels of
+//              all four wave columns, B1, A1 -- each 16 KiB = 2 DMA pieces per wave.  With tile t (even stage) computed in
+//              phases 1-4 and t+1 (odd stage) in 5-8, the quarter issued in phase 1..8 is (t+1).B1, (t+1).A1, (t+2).A0,
+//              (t+2).B0, (t+2).B1, (t+2).A1, (t+3).A0, (t+3).B0: every quarter is re-staged >= 2 phases after its last
+//              read and has >= 4 phases to land, and "everything but the 4 youngest quarters has landed" (vmcnt(8)) before a
+//              phase's first barrier is exactly what the next phase reads.  Tiles past the end are issued out of range
+//              (zero fill, no traffic) so that the count stays uniform; an odd number of K-steps computes one zero tile.
+//   rows       128-byte LDS rows, logical 16-byte chunk c of row r at chunk c ^ ((r >> 1) & 7): source-side for the DMA,
+//              conflict-free for the ds_read_b128 lane groups of the 16-row operand tiles.
+//   output     the MFMA's A operand is the weight tile, so a lane ends with 4 CONSECUTIVE channels of one pixel: 8-byte
+//              stores, float4 bias / scale / shift.
+template <typename T>
+__global__ __launch_bounds__(512) void conv_fwd_h16p_kernel(const ConvH16Args p) {
+    typedef typename H16Traits<T>::v8 v8;
+    constexpr int STAGE = 65536, BREG = 32768;
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntiles = p.Cout >> 8;
+    const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x - mtile * ntiles;
+    const int m0 = mtile * 256, n0 = ntile * 256;
+    const int ohw = p.OH * p.OW;
+
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - p.x_shift), 0, p.x_records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.w_records, 0x00020000);
+
+    // ---- staging bookkeeping: quarter (A: qm, B: qn) x piece j; a piece = 8 tile rows x 128 bytes, lane (l >> 3, l & 7) ----
+    unsigned a_voff[2][2], a_mask[2][2], b_voff[2][2];
+    int a_lds[2][2], b_lds[2][2];                               // wave-uniform LDS byte offsets of the pieces inside a stage
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int qr0 = (wave + 8 * j) * 8;                 // first row of the piece inside the quarter (0..120)
+            {
+                const int row0 = (qr0 >> 6) * 128 + q * 64 + (qr0 & 63);
+                a_lds[q][j] = row0 * 128;
+                const int r = row0 + (lane >> 3);
+                const int cl = (lane & 7) ^ ((r >> 1) & 7);
+                const int m = m0 + r;
+                const bool ok = m < p.M;
+                const int mm = ok ? m : 0;
+                const int n = mm / ohw, rem = mm - n * ohw;
+                const int oh = rem / p.OW, ow = rem - oh * p.OW;
+                const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
+                const long long off = ((long long)n * p.H * p.W * p.Cin + ((long long)ih0 * p.W + iw0) * p.Cin + cl * 8) * 2 + p.x_shift;
+                a_voff[q][j] = (unsigned)off;
+                unsigned mk = 0u;
+                if (ok)
+                    for (int t = 0; t < p.KH * p.KW; ++t) {
+                        const int th = t / p.KW, tw = t - th * p.KW;
+                        if ((unsigned)(ih0 + th) < (unsigned)p.H && (unsigned)(iw0 + tw) < (unsigned)p.W) mk |= 1u << t;
+                    }
+                a_mask[q][j] = mk;
+            }
+            {
+                const int row0 = (qr0 >> 5) * 64 + q * 32 + (qr0 & 31);
+                b_lds[q][j] = BREG + row0 * 128;
+                const int r = row0 + (lane >> 3);
+                const int cl = (lane & 7) ^ ((r >> 1) & 7);
+                b_voff[q][j] = (unsigned)((((long long)(n0 + r)) * p.Ktot + cl * 8) * 2);
+            }
+        }
+
+    // the tile whose quarters are being issued (A0, B0, B1, A1 in that order, then advance)
+    const int nk = p.Ktot >> 6;
+    int it_kh = 0, it_kw = 0, it_tap = 0, it_ci0 = 0, it_kt = 0;
+    auto issue_a = [&](auto qc, auto bufc) {
+        constexpr int q = decltype(qc)::value;
+        char* base = lds + decltype(bufc)::value * STAGE;
+        const unsigned soff = (unsigned)(((it_kh * p.W + it_kw) * p.Cin + it_ci0) * 2);
+        const unsigned bit = it_kt < nk ? (1u << it_tap) : 0u;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned vo = (a_mask[q][j] & bit) ? a_voff[q][j] : H16_OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (h16_lds_ptr)(base + a_lds[q][j]), 16, vo, soff, 0, 0);
+        }
+    };
+    auto issue_b = [&](auto qc, auto bufc) {
+        constexpr int q = decltype(qc)::value;
+        char* base = lds + decltype(bufc)::value * STAGE;
+        const unsigned soff = (unsigned)((it_tap * p.Cin + it_ci0) * 2);
+        const unsigned dead = it_kt < nk ? 0u : H16_OOB_OFFSET;  // or-ed in: a select here becomes a branch around each load
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned vo = b_voff[q][j] | dead;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (h16_lds_ptr)(base + b_lds[q][j]), 16, vo, soff, 0, 0);
+        }
+    };
+    auto advance = [&]() {                                      // channel-chunk outer, filter-tap inner
+        ++it_kt; ++it_tap;
+        if (++it_kw == p.KW) { it_kw = 0; if (++it_kh == p.KH) { it_kh = 0; it_tap = 0; it_ci0 += 64; } }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // operand reads: 16-row tile i, k half ks (32 k): lane (l & 15, l >> 4) reads logical chunk 4 ks + (l >> 4) of its row
+    const int l15 = lane & 15, fq = lane >> 4;
+    const int xrd = (wr * 128 + l15) * 128 + ((fq ^ ((l15 >> 1) & 7)) << 4);
+    const int wrd = BREG + (wc * 64 + l15) * 128 + ((fq ^ ((l15 >> 1) & 7)) << 4);
+    v8 xf[4][2], w0[2][2], w1[2][2];
+
+    auto phase = [&](auto phc) {
+        constexpr int PH = decltype(phc)::value;                // 0..7
+        constexpr int BUF = PH >> 2, Q = PH & 3;
+        const char* sb = lds + BUF * STAGE;
+        if constexpr (Q == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) w0[i][ks] = *(const v8*)(sb + (wrd ^ (ks << 6)) + i * 2048);
+        }
+        if constexpr (Q == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) w1[i][ks] = *(const v8*)(sb + (wrd ^ (ks << 6)) + 4096 + i * 2048);
+        }
+        if constexpr (Q == 0 || Q == 2) {
+            if constexpr (Q == 0) __builtin_amdgcn_sched_barrier(0);     // the 4 W reads first: they retire first
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) xf[i][ks] = *(const v8*)(sb + (xrd ^ (ks << 6)) + (Q == 2 ? 8192 : 0) + i * 2048);
+        }
+        // one quarter of a later stage
+        if constexpr (PH == 0) issue_b(I1{}, I1{});
+        if constexpr (PH == 1) { issue_a(I1{}, I1{}); advance(); }
+        if constexpr (PH == 2) issue_a(I0{}, I0{});
+        if constexpr (PH == 3) issue_b(I0{}, I0{});
+        if constexpr (PH == 4) issue_b(I1{}, I0{});
+        if constexpr (PH == 5) { issue_a(I1{}, I0{}); advance(); }
+        if constexpr (PH == 6) issue_a(I0{}, I1{});
+        if constexpr (PH == 7) issue_b(I0{}, I1{});
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int PB = (Q >= 2) ? 4 : 0;                     // pixel tiles of this quadrant
+        constexpr int CB = (Q == 1 || Q == 2) ? 2 : 0;           // channel tiles of this quadrant
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    acc[PB + i][CB + c] = H16Traits<T>::mfma16((CB ? w1 : w0)[c][ks], xf[i][ks], acc[PB + i][CB + c]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // prologue: tile 0 whole, tile 1's A0 and B0 (the state every loop iteration starts from); group 1 drops one barrier behind
+    issue_a(I0{}, I0{}); issue_b(I0{}, I0{}); issue_b(I1{}, I0{}); issue_a(I1{}, I0{}); advance();
+    issue_a(I0{}, I1{}); issue_b(I0{}, I1{});
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nk; t += 2)
+        h16_static_for([&](auto phc) { phase(phc); }, std::make_integer_sequence<int, 8>{});
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the out-of-range tail DMAs still target this workgroup's LDS
+
+    // ---- epilogue: bias, frozen-BN affine, activation in float32; one rounding; 4 consecutive channels per lane ----
+    T* out = (T*)p.out;
+    T* zo = (T*)p.z;
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    f32x4 cbias[4], csc[4], csh[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int n = n0 + wc * 64 + c * 16 + fq * 4;
+        cbias[c] = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+        csc[c] = p.scale ? *(const f32x4*)(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
+        csh[c] = p.scale ? *(const f32x4*)(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + wr * 128 + i * 16 + l15;
+        if (m >= p.M) continue;
+        const long long rowaddr = (long long)m * p.Cout + n0 + wc * 64 + fq * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            t4 yv, zv4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float zv = acc[i][c][j] + cbias[c][j];
+                zv4[j] = (T)zv;
+                float y = csc[c][j] * zv + csh[c][j];
+                if (p.act == MRCNN_ACT_RELU) y = fmaxf(y, 0.f);
+                else if (p.act == MRCNN_ACT_SIGMOID) y = 1.f / (1.f + expf(-y));
+                yv[j] = (T)y;
+            }
+            if (zo) *(t4*)(zo + rowaddr + c * 16) = zv4;
+            *(t4*)(out + rowaddr + c * 16) = yv;
         }
     }
 }
@@ -1078,6 +1299,13 @@ extern "C" int mrcnn_conv2d_fwd_h16_res(const mrcnn_conv_desc* d, int dtype, con
     // tried (branch-duplicated bodies: 175 TFLOP/s; two-trip selector loop: 256 VGPRs + 260 B scratch).
     bool big = false;
     if (tile && !strcmp(tile, "big")) big = d->Cout % 256 == 0;
+    const bool phased_ok = d->Cout % 256 == 0 && d->Cin % 64 == 0 && a.dense && d->KH * d->KW <= 32 && !res;
+    if (phased_ok && tile && !strcmp(tile, "phase")) {
+        const unsigned blocks = (unsigned)big_tiles;
+        if (dtype == MRCNN_DTYPE_F16) hipLaunchKernelGGL(conv_fwd_h16p_kernel<_Float16>, dim3(blocks), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL(conv_fwd_h16p_kernel<__bf16>, dim3(blocks), dim3(512), 0, s, a);
+        return mrcnn_launch_status();
+    }
     const bool ring = (tile && !strcmp(tile, "ring")) || getenv("MRCNN_H16_RING") != nullptr;
     if (big) {
         const unsigned blocks = (unsigned)big_tiles;

@@ -37,13 +37,15 @@ H16_CASES = [
     (300, 7, 7, 256, 1024, 7, "valid", 1, True),     # class-head FC as 7x7 VALID conv (49 taps, 64-bit tap mask)
     (7, 14, 14, 32, 512, 3, "same", 1, False),       # Ktot = 288 = 9 K-steps: ring prologue / drain with nk % 4 == 1, ragged M
     (2, 5, 5, 64, 256, 1, "valid", 0, True),         # 2 K-steps only: fewer steps than ring slots
+    (9, 12, 12, 64, 512, 3, "same", 1, True),        # phased tile: 9 K-steps of 64 (odd: one zero tile), two N tiles, ragged M
 ]
 
 
-@pytest.fixture(params=["small", "big"])
+@pytest.fixture(params=["small", "big", "phase"])
 def h16_tile(request):
     """Both forward tilings on every eligible shape: MRCNN_H16_TILE is read per call (256 x 128 / 4 waves / double
-    buffered, and 256 x 256 / 8 waves / 4-stage ring with counted waits; the second needs Cout % 256 == 0)."""
+    buffered; 256 x 256 / 8 waves / 4-stage ring with counted waits; 256 x 256 / 8 waves in two staggered groups, phased
+    K-steps -- the last two need Cout % 256 == 0, the phased one also Cin % 64 == 0, else the call takes the default)."""
     os.environ["MRCNN_H16_TILE"] = request.param
     yield request.param
     del os.environ["MRCNN_H16_TILE"]
@@ -54,7 +56,7 @@ def h16_tile(request):
 def test_conv_fwd_h16(dev, case, dtype, h16_tile):
     ops = _ops()
     N, H, W, Cin, Cout, k, padding, act, bn = case
-    if h16_tile == "big" and Cout % 256:
+    if h16_tile in ("big", "phase") and (Cout % 256 or (h16_tile == "phase" and Cin % 64)):
         pytest.skip("256 x 256 tile needs Cout % 256 == 0")
     rng = np.random.default_rng(sum(case[:6]))
     x = torch.tensor(rng.standard_normal((N, H, W, Cin)).astype(np.float32)).to(dtype)
@@ -80,7 +82,7 @@ def test_conv_fwd_h16(dev, case, dtype, h16_tile):
         err = float((got.float().cpu() - ref).abs().max()) / float(ref.abs().max())
         assert err <= TOL[dtype], "%s: max error %.3g of max |ref| (allowed %.3g)" % (name, err, TOL[dtype])
     # data gradient: the same kernel on dz with the rotated weight image
-    if (padding == "same" or k == 1) and Cin % 128 == 0 and not (h16_tile == "big" and Cin % 256):
+    if (padding == "same" or k == 1) and Cin % 128 == 0 and not (h16_tile in ("big", "phase") and Cin % 256):
         xg = x.float().clone().requires_grad_(True)
         yy = orc.conv2d_nhwc(xg, w.float(), None, 1, padding)
         dz = torch.tensor(rng.standard_normal(tuple(yy.shape)).astype(np.float32)).to(dtype)
