@@ -26,6 +26,15 @@ def _hipcc():
     return exe
 
 
+def _isa_check():
+    """isa_check.py next to this file (build.py is also loaded by path, outside the package: __graft_entry__.build)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_mrcnn_isa_check", os.path.join(PKG_DIR, "isa_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
@@ -74,6 +83,15 @@ def _build_locked(force, verbose, extra_flags):
                     sys.stderr.write("[build] %s\n%s" % (os.path.basename(cmd[-3]), out))
                 if rc:
                     raise RuntimeError("hipcc failed for %s:\n%s" % (cmd[-3], out[-4000:]))
+        # machine-code check of what was just compiled (isa_check.py: wide buffer stores vs. vector writes of their data)
+        isa_check = _isa_check()
+        if isa_check.tools_available():
+            for cmd in jobs:
+                try:
+                    isa_check.check_object(cmd[-1])
+                except RuntimeError:
+                    os.remove(cmd[-1])                     # never link (or skip as up to date) an object that failed the check
+                    raise
     if jobs or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < _newest(objs):
         tmp = LIB_PATH + ".tmp.%d" % os.getpid()
         cmd, rc, out = run([_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", tmp] + objs)

@@ -16,10 +16,27 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //   the small latency-bound kernels of another stream (the engine sets it around the weight gradients it runs beside the
 //   backbone's backward pass, see engine.py "deferred mask-head weight gradients").
 extern int g_mrcnn_wgrad_lds_pad;
+//   h16_phase: 1 (default) lets the 16-bit forward pick the persistent 256 x 256 kernel by itself; 0 keeps it off.  One
+//   workgroup of it fills a CU's LDS, so beside another stream's big kernels (the mask head's weight gradients run next to
+//   its data gradients) the statically assigned tiles start late on the CUs the other kernel held.
+extern int g_mrcnn_h16_phase;
 
 static inline int mrcnn_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? MRCNN_OK : MRCNN_ERR_LAUNCH;
+}
+
+// Compute units of the current device (persistent kernels launch one workgroup per CU); queried once per device.
+static inline int mrcnn_num_cus() {
+    static int cus[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
 }
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

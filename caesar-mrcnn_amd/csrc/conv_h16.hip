@@ -13,6 +13,7 @@
 //   cast kernels          float32 <-> 16-bit, elementwise.
 #include "common.h"
 #include <string.h>
+#include <algorithm>
 #include <type_traits>
 #include <utility>
 
@@ -37,7 +38,10 @@ static int h16_dtype_ok(int dtype) { return dtype == MRCNN_DTYPE_F16 || dtype ==
 struct ConvH16Args {
     const void* x; const void* wt; const float* bias; const float* scale; const float* shift; void* out; void* z;
     int N, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, OH, OW, act, M, Ktot;
-    unsigned x_shift, x_records, w_records;
+    unsigned x_shift, x_records, w_records, out_records;
+    unsigned mg_ohw, sh_ohw, mg_ow, sh_ow;           // m / (OH*OW) and rem / OW as multiply-high + shift (0 = divisor 1)
+    int ptiles, mtile0;                              // phased kernel: tiles it owns; small-tile kernel: first 64-row tile (remainder launch)
+    unsigned long long* dbg;                         // phased kernel: cycle stamps of workgroup 0 (tools/h16p_trace.py), else null
     int out_mode, cmod; long long ons, ohs, ows;     // MRCNN_OUT_DECONV2: pixel-shuffle store of the 2x2 transposed conv
     const void* res;                                 // small-tile kernel: 16-bit tensor added before the activation (strides of out)
     int dense;                                       // out is plain NHWC [M][Cout]
@@ -261,6 +265,26 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, NBUF <= 3 ? 2 : (WAVES_M * 
     }
 }
 
+// The 16-byte buffer stores of the phased kernel's epilogue and the vector unit.  gfx950 reads the data of a
+// buffer_store_dwordx4 a few cycles after issue; a vector instruction that overwrites one of the four registers in the next
+// slot wins the race for the lanes read last.  LLVM's hazard recogniser inserts the wait state only for the form with a
+// CONSTANT soffset (the ISA manual exempts an SGPR soffset), yet tools/h16p_first_call.py caught exactly this on the SGPR
+// form: the first dword of lanes 12-15 / 28-31 / 44-47 / 60-63 of a store that was followed by a v_mul into its first data
+// register held the multiply's result -- about one first call in ten of a fresh process (cold instruction cache), and it
+// is how a 16-bit training run picked up its first non-finite activation.  So the stores of a chunk sit between two
+// scheduling barriers with s_nop 2 behind the last one: nothing but stores and scalar bookkeeping follows a store for three
+// slots.  (The stores stay compiler builtins: as inline asm the recogniser no longer sees their SGPR operands, and the
+// "vector write of an SGPR, then a memory instruction reads it" wait states go missing -- measured: wrong addresses.)
+template <int N> __device__ __forceinline__ void h16p_wait() {        // s_waitcnt vmcnt(min(N, 63)): the field has 6 bits
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+    else if constexpr (N == 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+    else if constexpr (N == 56) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+    else { static_assert(N > 56, "add the count"); asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); }
+}
+
 // Phased 256 x 256 tile for the big layers (mask head: M = 401 408, N = 256, K = 2 304): 8 waves = two groups of four
 // (wr = wave >> 2; waves w and w + 4 share a SIMD), each wave 128 pixels x 64 channels as 8 x 4 tiles of
 // v_mfma_f32_16x16x32, K-step 64, two 64 KiB stages.  A K-step is four phases of
@@ -282,24 +306,45 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, NBUF <= 3 ? 2 : (WAVES_M * 
 //              conflict-free for the ds_read_b128 lane groups of the 16-row operand tiles.
 //   output     the MFMA's A operand is the weight tile, so a lane ends with 4 CONSECUTIVE channels of one pixel: 8-byte
 //              stores, float4 bias / scale / shift.
-template <typename T>
+template <typename T, bool ZOUT>
 __global__ __launch_bounds__(512) void conv_fwd_h16p_kernel(const ConvH16Args p) {
     typedef typename H16Traits<T>::v8 v8;
-    constexpr int STAGE = 65536, BREG = 32768;
-    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE];
+    constexpr int STAGE = 65536, BREG = 32768, PRM = 2 * STAGE, MAXC = 512;
+    // ONE LDS object (a second one beside a DMA-filled array makes hipcc drain vmcnt before every operand read): two
+    // stages, then bias / scale / shift of all output channels -- the epilogue takes them from LDS because an ordinary
+    // global load inside the persistent loop would make the compiler wait for vmcnt(0), i.e. drain the DMA stream
+    constexpr int STG = PRM + 3 * MAXC * 4;                     // 2 KiB per wave: one 16-pixel x 64-channel output tile, transposed to rows
+    constexpr int TRC = STG + 8 * 2048, NTRC = 512;             // cycle stamps (debug): waves 0 and 4, NTRC each
+    __shared__ __attribute__((aligned(16))) char lds[2 * STAGE + 3 * MAXC * 4 + 8 * 2048 + 2 * NTRC * 8];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int ntiles = p.Cout >> 8;
-    const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x - mtile * ntiles;
-    const int m0 = mtile * 256, n0 = ntile * 256;
+    const int total = p.ptiles;                                 // the host may keep a last partial round for the small-tile kernel
+    {   // y = max(acc * P0 + P1, floor), z = acc + P2
+        float* prm = (float*)(lds + PRM);
+        for (int c = tid; c < p.Cout; c += 512) {
+            const float bi = p.bias ? p.bias[c] : 0.f, sc = p.scale ? p.scale[c] : 1.f, sh = p.scale ? p.shift[c] : 0.f;
+            prm[c] = sc;
+            prm[MAXC + c] = sc * bi + sh;
+            prm[2 * MAXC + c] = bi;
+        }
+        __syncthreads();
+    }
+    // taps as bit t = th * KW + tw (KH * KW <= 31): all rows' first columns, for the branch-free validity masks below
+    unsigned tap_rows = 0u;
+    for (int th = 0; th < p.KH; ++th) tap_rows |= 1u << (th * p.KW);
     const int ohw = p.OH * p.OW;
+    const int nk = p.Ktot >> 6, nk2 = (nk + 1) & ~1;            // K-steps of a tile, padded to whole 8-phase rounds
 
     const __amdgpu_buffer_rsrc_t rsrc_a =
         __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - p.x_shift), 0, p.x_records, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.w_records, 0x00020000);
 
     // ---- staging bookkeeping: quarter (A: qm, B: qn) x piece j; a piece = 8 tile rows x 128 bytes, lane (l >> 3, l & 7) ----
+    // The workgroup is persistent (tiles blockIdx.x, + gridDim.x, ...) and the DMA stream runs on across tile borders:
+    // while the last K-steps of a tile are computed the first ones of the next tile are already being staged, and the
+    // epilogue's stores drain under the next tile's MFMAs.
     unsigned a_voff[2][2], a_mask[2][2], b_voff[2][2];
     int a_lds[2][2], b_lds[2][2];                               // wave-uniform LDS byte offsets of the pieces inside a stage
 #pragma unroll
@@ -307,39 +352,50 @@ __global__ __launch_bounds__(512) void conv_fwd_h16p_kernel(const ConvH16Args p)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int qr0 = (wave + 8 * j) * 8;                 // first row of the piece inside the quarter (0..120)
-            {
-                const int row0 = (qr0 >> 6) * 128 + q * 64 + (qr0 & 63);
-                a_lds[q][j] = row0 * 128;
-                const int r = row0 + (lane >> 3);
-                const int cl = (lane & 7) ^ ((r >> 1) & 7);
-                const int m = m0 + r;
-                const bool ok = m < p.M;
-                const int mm = ok ? m : 0;
-                const int n = mm / ohw, rem = mm - n * ohw;
-                const int oh = rem / p.OW, ow = rem - oh * p.OW;
-                const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
-                const long long off = ((long long)n * p.H * p.W * p.Cin + ((long long)ih0 * p.W + iw0) * p.Cin + cl * 8) * 2 + p.x_shift;
-                a_voff[q][j] = (unsigned)off;
-                unsigned mk = 0u;
-                if (ok)
-                    for (int t = 0; t < p.KH * p.KW; ++t) {
-                        const int th = t / p.KW, tw = t - th * p.KW;
-                        if ((unsigned)(ih0 + th) < (unsigned)p.H && (unsigned)(iw0 + tw) < (unsigned)p.W) mk |= 1u << t;
-                    }
-                a_mask[q][j] = mk;
-            }
-            {
-                const int row0 = (qr0 >> 5) * 64 + q * 32 + (qr0 & 31);
-                b_lds[q][j] = BREG + row0 * 128;
-                const int r = row0 + (lane >> 3);
-                const int cl = (lane & 7) ^ ((r >> 1) & 7);
-                b_voff[q][j] = (unsigned)((((long long)(n0 + r)) * p.Ktot + cl * 8) * 2);
-            }
+            a_lds[q][j] = ((qr0 >> 6) * 128 + q * 64 + (qr0 & 63)) * 128;
+            b_lds[q][j] = BREG + ((qr0 >> 5) * 64 + q * 32 + (qr0 & 31)) * 128;
         }
+    const int lane_ = lane;
+    auto setup = [&](int tile) {                                // per-lane source offsets of output tile `tile` (none: all out of range)
+        const int mtile = tile / ntiles, ntile = tile - mtile * ntiles;
+        const bool live = tile < total;
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));                          // as in the epilogue: nothing of this is worth a register in the K loop
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                {
+                    const int r = a_lds[q][j] / 128 + (lane >> 3);
+                    const int cl = (lane & 7) ^ ((r >> 1) & 7);
+                    const int m = mtile * 256 + r;
+                    const bool ok = live && m < p.M;
+                    const int mm = ok ? m : 0;
+                    const int n = p.mg_ohw ? (int)(__umulhi((unsigned)mm, p.mg_ohw) >> p.sh_ohw) : mm, rem = mm - n * ohw;
+                    const int oh = p.mg_ow ? (int)(__umulhi((unsigned)rem, p.mg_ow) >> p.sh_ow) : rem, ow = rem - oh * p.OW;
+                    const int ih0 = oh * p.stride - p.pad_t, iw0 = ow * p.stride - p.pad_l;
+                    const long long off = ((long long)n * p.H * p.W * p.Cin + ((long long)ih0 * p.W + iw0) * p.Cin + cl * 8) * 2 + p.x_shift;
+                    a_voff[q][j] = (unsigned)off;
+                    // valid taps: rows th in [rlo, rhi), columns tw in [clo, chi) -- contiguous ranges, so the mask is a product
+                    const int rlo = max(0, -ih0), rhi = min(p.KH, p.H - ih0), clo = max(0, -iw0), chi = min(p.KW, p.W - iw0);
+                    unsigned mk = 0u;
+                    if (ok && rhi > rlo && chi > clo) {
+                        const unsigned cols = ((1u << chi) - 1u) & ~((1u << clo) - 1u);
+                        const unsigned rows = tap_rows & ((1u << (rhi * p.KW)) - 1u) & ~((1u << (rlo * p.KW)) - 1u);
+                        mk = cols * rows;
+                    }
+                    a_mask[q][j] = mk;
+                }
+                {
+                    const int r = (b_lds[q][j] - BREG) / 128 + (lane >> 3);
+                    const int cl = (lane & 7) ^ ((r >> 1) & 7);
+                    b_voff[q][j] = live ? (unsigned)((((long long)(ntile * 256 + r)) * p.Ktot + cl * 8) * 2) : H16_OOB_OFFSET;
+                }
+            }
+    };
 
-    // the tile whose quarters are being issued (A0, B0, B1, A1 in that order, then advance)
-    const int nk = p.Ktot >> 6;
-    int it_kh = 0, it_kw = 0, it_tap = 0, it_ci0 = 0, it_kt = 0;
+    // the K-step whose quarters are being issued (A0, B0, B1, A1 in that order, then advance)
+    int it_tile = blockIdx.x, it_kh = 0, it_kw = 0, it_tap = 0, it_ci0 = 0, it_kt = 0;
     auto issue_a = [&](auto qc, auto bufc) {
         constexpr int q = decltype(qc)::value;
         char* base = lds + decltype(bufc)::value * STAGE;
@@ -354,7 +410,7 @@ __global__ __launch_bounds__(512) void conv_fwd_h16p_kernel(const ConvH16Args p)
     auto issue_b = [&](auto qc, auto bufc) {
         constexpr int q = decltype(qc)::value;
         char* base = lds + decltype(bufc)::value * STAGE;
-        const unsigned soff = (unsigned)((it_tap * p.Cin + it_ci0) * 2);
+        const unsigned soff = it_kt < nk ? (unsigned)((it_tap * p.Cin + it_ci0) * 2) : 0u;
         const unsigned dead = it_kt < nk ? 0u : H16_OOB_OFFSET;  // or-ed in: a select here becomes a branch around each load
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -362,9 +418,15 @@ __global__ __launch_bounds__(512) void conv_fwd_h16p_kernel(const ConvH16Args p)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (h16_lds_ptr)(base + b_lds[q][j]), 16, vo, soff, 0, 0);
         }
     };
-    auto advance = [&]() {                                      // channel-chunk outer, filter-tap inner
-        ++it_kt; ++it_tap;
-        if (++it_kw == p.KW) { it_kw = 0; if (++it_kh == p.KH) { it_kh = 0; it_tap = 0; it_ci0 += 64; } }
+    auto advance = [&]() {                                      // channel-chunk outer, filter-tap inner; then the next tile
+        if (++it_kt == nk2) {
+            it_kt = it_kh = it_kw = it_tap = it_ci0 = 0;
+            it_tile += gridDim.x;
+            setup(it_tile);
+        } else {
+            ++it_tap;
+            if (++it_kw == p.KW) { it_kw = 0; if (++it_kh == p.KH) { it_kh = 0; it_tap = 0; it_ci0 += 64; } }
+        }
     };
     typedef std::integral_constant<int, 0> I0;
     typedef std::integral_constant<int, 1> I1;
@@ -381,10 +443,97 @@ __global__ __launch_bounds__(512) void conv_fwd_h16p_kernel(const ConvH16Args p)
     const int wrd = BREG + (wc * 64 + l15) * 128 + ((fq ^ ((l15 >> 1) & 7)) << 4);
     v8 xf[4][2], w0[2][2], w1[2][2];
 
-    auto phase = [&](auto phc) {
+    // ---- epilogue of one half of the wave's tile (4 pixel tiles x all 4 channel tiles, complete after phases 6 / 8 of a
+    // tile's last K-step): bias, frozen-BN affine, activation in float32, one rounding.  A lane holds 4 consecutive channels
+    // of one pixel -- stored like that, every store instruction touches 16 cache lines with 32 bytes each, and the write
+    // path, not the arithmetic, set the cost of a tile border (4 400-7 700 cycles per chunk, tools/h16p_trace.py).  So each
+    // 16 x 64 tile goes through 2 KiB of LDS (8-byte writes, chunk-swizzled rows) and leaves as whole 128-byte rows: two
+    // dwordx4 buffer stores of 8 full lines each (rows past M fall outside the descriptor). ----
+    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(p.z, 0, ZOUT ? p.out_records : 0u, 0x00020000);
+    const float act_floor = p.act == MRCNN_ACT_RELU ? 0.f : -INFINITY;  // no per-element branch on the activation
+    constexpr int ES = ZOUT ? 16 : 8;                           // stores per chunk
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto epilogue = [&](auto halfc, const int tile) {
+        constexpr int PB = decltype(halfc)::value * 4;
+        const int mtile = tile / ntiles, ntile = tile - mtile * ntiles;
+        const int nb = ntile * 256 + wc * 64;
+        char* stg = lds + STG + wave * 2048;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                            // per-call lane arithmetic: hoisted out of the K loop it costs registers there
+        const int l15 = ln & 15, fq = ln >> 4;
+        const int wbase = l15 * 128 + (fq & 1) * 8, wsw = l15 & 7;
+        const int r8 = ln >> 3;
+        const int rbase = r8 * 128 + (((ln & 7) ^ (r8 & 7)) << 4);
+        const unsigned voff = (unsigned)(((mtile * 256 + wr * 128 + r8) * p.Cout + nb) * 2 + (ln & 7) * 16);
+        f32x4 p0[4], p1[4], p2[4];                              // this lane's 16 channels: loaded once, not per pixel tile
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int n = nb + c * 16 + fq * 4;
+            p0[c] = *(const f32x4*)(lds + PRM + n * 4);
+            p1[c] = *(const f32x4*)(lds + PRM + (MAXC + n) * 4);
+            if constexpr (ZOUT) p2[c] = *(const f32x4*)(lds + PRM + (2 * MAXC + n) * 4);
+        }
+        // software pipeline over the 4 pixel tiles: LDS executes a wave's operations in order, so "write tile i, read it
+        // back as rows, write tile i + 1, ..." needs no wait between them; the rows of tile i are stored while tile i + 1
+        // is converted (a single wave has nobody else to hide the LDS round trip behind)
+        u32x4 o0[4], o1[4], z0[4], z1[4];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if (i < 4) {
+                t4 yv[4], zv4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) yv[c][j] = (T)fmaxf(acc[PB + i][c][j] * p0[c][j] + p1[c][j], act_floor);  // RELU / NONE only (the host checks)
+                    if constexpr (ZOUT) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) zv4[c][j] = (T)(acc[PB + i][c][j] + p2[c][j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[PB + i][c][j] = 0.f;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) *(t4*)(stg + wbase + (((c * 2 + (fq >> 1)) ^ wsw) << 4)) = yv[c];
+                o0[i] = *(const u32x4*)(stg + rbase); o1[i] = *(const u32x4*)(stg + rbase + 1024);
+                if constexpr (ZOUT) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) *(t4*)(stg + wbase + (((c * 2 + (fq >> 1)) ^ wsw) << 4)) = zv4[c];
+                    z0[i] = *(const u32x4*)(stg + rbase); z1[i] = *(const u32x4*)(stg + rbase + 1024);
+                }
+            }
+            if (i > 0) {
+                const unsigned soff = (unsigned)(((PB + i - 1) * 16 * p.Cout) * 2), soff8 = soff + (unsigned)(8 * p.Cout * 2);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_raw_buffer_store_b128(o0[i - 1], rsrc_o, voff, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o1[i - 1], rsrc_o, voff, soff8, 0);
+                if constexpr (ZOUT) {
+                    __builtin_amdgcn_raw_buffer_store_b128(z0[i - 1], rsrc_z, voff, soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(z1[i - 1], rsrc_z, voff, soff8, 0);
+                }
+                asm volatile("s_nop 2");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    int ntrc = 0;
+    auto phase = [&](auto phc, const int t, const int tile) {
         constexpr int PH = decltype(phc)::value;                // 0..7
         constexpr int BUF = PH >> 2, Q = PH & 3;
         const char* sb = lds + BUF * STAGE;
+        auto stamp = [&]() {
+            if (p.dbg && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0 && ntrc < NTRC)
+                ((unsigned long long*)(lds + TRC))[wr * NTRC + ntrc++] = __builtin_readcyclecounter();
+        };
+        stamp();
+        // the epilogue of the half tile the previous two phases completed, in the last K-step of a tile (pixel tiles 0..3) and
+        // in the first phase after it (4..7): here it runs beside the OTHER group's MFMAs
+        const bool last = t + 2 >= nk2, after = t == 0 && tile != (int)blockIdx.x;
+        if constexpr (PH == 6) { if (last) epilogue(I0{}, tile); }
+        if constexpr (PH == 0) { if (after) epilogue(I1{}, tile - (int)gridDim.x); }
+        __builtin_amdgcn_sched_barrier(0);                           // epilogue registers are free before the operands load
         if constexpr (Q == 0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -413,7 +562,12 @@ __global__ __launch_bounds__(512) void conv_fwd_h16p_kernel(const ConvH16Args p)
         if constexpr (PH == 5) { issue_a(I1{}, I0{}); advance(); }
         if constexpr (PH == 6) issue_a(I0{}, I1{});
         if constexpr (PH == 7) issue_b(I0{}, I1{});
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // "everything but the 4 youngest quarters": the epilogue chunks' stores (ES each, issued before this phase's DMA in
+        // phase 7 of the last K-step and in phase 1 after it) count too while they are among the 4 youngest phases
+        if constexpr (PH >= 6) { if (last) h16p_wait<8 + ES>(); else h16p_wait<8>(); }
+        else if constexpr (PH <= 1) { if (after) h16p_wait<8 + 2 * ES>(); else h16p_wait<8>(); }
+        else if constexpr (PH <= 3) { if (after) h16p_wait<8 + ES>(); else h16p_wait<8>(); }
+        else h16p_wait<8>();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -433,51 +587,25 @@ __global__ __launch_bounds__(512) void conv_fwd_h16p_kernel(const ConvH16Args p)
         __builtin_amdgcn_s_barrier();
     };
 
-    // prologue: tile 0 whole, tile 1's A0 and B0 (the state every loop iteration starts from); group 1 drops one barrier behind
+    // prologue: K-step 0 whole, K-step 1's A0 and B0 (the state every 8-phase round starts from); group 1 drops one barrier behind
+    setup(it_tile);
     issue_a(I0{}, I0{}); issue_b(I0{}, I0{}); issue_b(I1{}, I0{}); issue_a(I1{}, I0{}); advance();
     issue_a(I0{}, I1{}); issue_b(I0{}, I1{});
     if (wr == 1) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < nk; t += 2)
-        h16_static_for([&](auto phc) { phase(phc); }, std::make_integer_sequence<int, 8>{});
+
+    int tile = blockIdx.x;
+    for (; tile < total; tile += gridDim.x)
+        for (int t = 0; t < nk2; t += 2)
+            h16_static_for([&](auto phc) { phase(phc, t, tile); }, std::make_integer_sequence<int, 8>{});
+    epilogue(I1{}, tile - (int)gridDim.x);                                  // grid <= tiles: every workgroup had one
     if (wr == 0) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the out-of-range tail DMAs still target this workgroup's LDS
-
-    // ---- epilogue: bias, frozen-BN affine, activation in float32; one rounding; 4 consecutive channels per lane ----
-    T* out = (T*)p.out;
-    T* zo = (T*)p.z;
-    typedef T t4 __attribute__((ext_vector_type(4)));
-    f32x4 cbias[4], csc[4], csh[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int n = n0 + wc * 64 + c * 16 + fq * 4;
-        cbias[c] = p.bias ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-        csc[c] = p.scale ? *(const f32x4*)(p.scale + n) : f32x4{1.f, 1.f, 1.f, 1.f};
-        csh[c] = p.scale ? *(const f32x4*)(p.shift + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = m0 + wr * 128 + i * 16 + l15;
-        if (m >= p.M) continue;
-        const long long rowaddr = (long long)m * p.Cout + n0 + wc * 64 + fq * 4;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            t4 yv, zv4;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float zv = acc[i][c][j] + cbias[c][j];
-                zv4[j] = (T)zv;
-                float y = csc[c][j] * zv + csh[c][j];
-                if (p.act == MRCNN_ACT_RELU) y = fmaxf(y, 0.f);
-                else if (p.act == MRCNN_ACT_SIGMOID) y = 1.f / (1.f + expf(-y));
-                yv[j] = (T)y;
-            }
-            if (zo) *(t4*)(zo + rowaddr + c * 16) = zv4;
-            *(t4*)(out + rowaddr + c * 16) = yv;
-        }
-    }
+    if (p.dbg && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0)
+        for (int i = 0; i < NTRC; ++i)
+            p.dbg[wr * NTRC + i] = i < ntrc ? ((unsigned long long*)(lds + TRC))[wr * NTRC + i] : 0ull;
 }
 
 // Small-tile variant for the layers of the trunk (feature maps of 1 024 .. 16 384 pixels, Cin / Cout multiples of 64):
@@ -501,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_h16s_kernel(const ConvH16Args
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int ntiles = p.Cout / BN;
-    const int mtile = blockIdx.x / ntiles, ntile = blockIdx.x % ntiles;
+    const int mtile = blockIdx.x / ntiles + p.mtile0, ntile = blockIdx.x % ntiles;
     const int m0 = mtile * BM, n0 = ntile * BN;
     const int ohw = p.OH * p.OW;
 
@@ -1213,6 +1341,15 @@ extern "C" int mrcnn_conv2d_wgrad_h16(const mrcnn_conv_desc* d, int dtype, const
 }
 
 
+// x / d for x < 2^31 as (umulhi(x, mg) >> sh): mg = ceil(2^(31+s) / d), s = ceil(log2 d), sh = s - 1; d = 1 -> mg = 0 (no division)
+static void h16_magic(unsigned d, unsigned* mg, unsigned* sh) {
+    if (d <= 1) { *mg = 0; *sh = 0; return; }
+    unsigned sft = 0;
+    while ((1ull << sft) < d) ++sft;
+    *mg = (unsigned)(((1ull << (31 + sft)) + d - 1) / d);
+    *sh = sft - 1;
+}
+
 static thread_local const mrcnn_bwd_epilogue_h16* g_h16_fb = nullptr;   // set around the call by mrcnn_conv2d_dgrad_ep_h16
 
 // Which 16-bit forward kernel a shape takes: 2 = small tile (64 x 64), 1 = large tile (256 x 128 / 256 x 256), 0 = none.
@@ -1265,9 +1402,15 @@ extern "C" int mrcnn_conv2d_fwd_h16_res(const mrcnn_conv_desc* d, int dtype, con
     a.stride = d->stride; a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.OH = d->OH; a.OW = d->OW; a.act = d->act;
     a.M = (int)M; a.Ktot = d->KH * d->KW * d->Cin;
     a.x_shift = (unsigned)shift_b; a.x_records = (unsigned)(xbytes + shift_b); a.w_records = (unsigned)wbytes;
+    a.out_records = (unsigned)std::min<long long>(M * d->Cout * 2, 0xFFFFFFF0LL);
     a.out_mode = d->out_mode; a.cmod = d->cmod; a.ons = d->out_n_stride; a.ohs = d->out_h_stride; a.ows = d->out_w_stride;
     a.dense = d->out_mode == MRCNN_OUT_NHWC && d->out_w_stride == d->Cout && d->out_h_stride == (int64_t)d->OW * d->Cout &&
               d->out_n_stride == (int64_t)d->OH * d->OW * d->Cout;
+    a.ptiles = 0; a.mtile0 = 0;
+    a.dbg = nullptr;
+    h16_magic((unsigned)(d->OH * d->OW), &a.mg_ohw, &a.sh_ohw);
+    h16_magic((unsigned)d->OW, &a.mg_ow, &a.sh_ow);
+    if (const char* t = getenv("MRCNN_H16P_TRACE")) a.dbg = (unsigned long long*)strtoull(t, nullptr, 0);   // device buffer of 1024 x u64
     a.fb_act = -1; a.fb_out = a.fb_z = nullptr; a.fb_scale = a.fb_mean = a.fb_rstd = nullptr;
     a.fb_dgamma = a.fb_dbeta = a.fb_dbias = nullptr; a.fb_dy = nullptr; a.fb_gmul = 1.f;
     if (g_h16_fb) {                              // mrcnn_conv2d_dgrad_ep_h16: small-tile kernel only, dense, plain store
@@ -1287,23 +1430,47 @@ extern "C" int mrcnn_conv2d_fwd_h16_res(const mrcnn_conv_desc* d, int dtype, con
     }
     // Large tiles (read per call so that tests and A/B timings can switch: MRCNN_H16_TILE = big | small | ring):
     //   big    256 x 256, 8 waves, 4-stage ring, one workgroup per CU -- Cout % 256 == 0
-    //   small  256 x 128, 4 waves, double buffered, 3 workgroups per CU (the round-1 kernel; the default)
+    //   phase  256 x 256, 8 waves in two staggered groups, persistent (default from one full round of tiles on)
+    //   small  256 x 128, 4 waves, double buffered, 3 workgroups per CU (the round-1 kernel; the default below that)
     //   ring   256 x 128 with a 3-slot ring (round-1 experiment)
     const char* tile = getenv("MRCNN_H16_TILE");
     const long long big_tiles = ((M + 255) / 256) * (d->Cout / 256);
-    // default: small.  Isolated, big is 3-5 % faster on the mask-head shape (770-810 vs 745-795 TFLOP/s); in the training
-    // step its 128 KiB of LDS cannot share a CU with the weight-gradient stream's 48 KiB workgroups.  Both stop at ~30 %
-    // of the matrix peak: per K-step a wave spends about as long issuing its LDS-DMA pieces and waiting for operand reads
-    // as the matrix pipe needs for its 16 MFMAs, and the two waves of a SIMD do it in lockstep.  De-phasing them in HIP
-    // source (second wave group computes before it prefetches) made hipcc spill the 128 accumulator registers both ways
-    // tried (branch-duplicated bodies: 175 TFLOP/s; two-trip selector loop: 256 VGPRs + 260 B scratch).
+    // small and big stop at ~30 % of the matrix peak (745-810 TFLOP/s on the mask-head shape): per K-step a wave spends
+    // about as long issuing its LDS-DMA pieces and waiting for operand reads as the matrix pipe needs for its MFMAs, and
+    // the two waves of a SIMD do it in lockstep.  De-phasing them with duplicated bodies or a selector loop made hipcc spill
+    // the accumulators; the phased kernel gets the stagger from one extra barrier instead (1.0-1.06 PFLOP/s here, 1.15-1.2
+    // where the tiles are whole rounds; measured shader clock under it: 1.96 GHz, tools/h16p_trace.py).
     bool big = false;
     if (tile && !strcmp(tile, "big")) big = d->Cout % 256 == 0;
-    const bool phased_ok = d->Cout % 256 == 0 && d->Cin % 64 == 0 && a.dense && d->KH * d->KW <= 32 && !res;
-    if (phased_ok && tile && !strcmp(tile, "phase")) {
-        const unsigned blocks = (unsigned)big_tiles;
-        if (dtype == MRCNN_DTYPE_F16) hipLaunchKernelGGL(conv_fwd_h16p_kernel<_Float16>, dim3(blocks), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL(conv_fwd_h16p_kernel<__bf16>, dim3(blocks), dim3(512), 0, s, a);
+    const bool phased_ok = d->Cout % 256 == 0 && d->Cout <= 512 && d->Cin % 64 == 0 && a.dense && d->KH * d->KW <= 31 && !res &&
+                           (d->act == MRCNN_ACT_NONE || d->act == MRCNN_ACT_RELU) && M * d->Cout * 2 < 0xFFFFFFF0LL;
+    // phase: persistent 256 x 256 tiles (see conv_fwd_h16p_kernel), the default where a shape has at least one full round of
+    // them; a last partial round of at most half the CUs goes to the small-tile kernel instead (a 256-row tile costs a full
+    // tile time however few there are; 64-row tiles spread the same rows over the whole chip)
+    const int cus = mrcnn_num_cus();
+    const bool want_phase = tile ? !strcmp(tile, "phase") : (big_tiles >= cus && g_mrcnn_h16_phase);
+    if (phased_ok && want_phase) {
+        const int ntn = d->Cout / 256;
+        long long own = big_tiles;
+        const long long full = big_tiles / cus * cus / ntn * ntn;
+        if (full > 0 && big_tiles - full > 0 && (big_tiles - full) * 2 <= cus && !getenv("MRCNN_H16P_NO_SPLIT")) own = full;
+        a.ptiles = (int)own;
+        unsigned blocks = (unsigned)std::min<long long>(own, cus);   // one workgroup per CU (LDS)
+        if (const char* g = getenv("MRCNN_H16P_GRID")) blocks = (unsigned)std::min<long long>(own, atoi(g));   // experiments
+        if (dtype == MRCNN_DTYPE_F16) {
+            if (z_out) hipLaunchKernelGGL((conv_fwd_h16p_kernel<_Float16, true>), dim3(blocks), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((conv_fwd_h16p_kernel<_Float16, false>), dim3(blocks), dim3(512), 0, s, a);
+        } else {
+            if (z_out) hipLaunchKernelGGL((conv_fwd_h16p_kernel<__bf16, true>), dim3(blocks), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((conv_fwd_h16p_kernel<__bf16, false>), dim3(blocks), dim3(512), 0, s, a);
+        }
+        if (own < big_tiles) {
+            const long long mdone = own / ntn * 256;
+            a.mtile0 = (int)(mdone / 64);
+            const unsigned rblocks = (unsigned)(((M - mdone + 63) / 64) * (d->Cout / 64));
+            if (dtype == MRCNN_DTYPE_F16) hipLaunchKernelGGL(conv_fwd_h16s_kernel<_Float16>, dim3(rblocks), dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(conv_fwd_h16s_kernel<__bf16>, dim3(rblocks), dim3(256), 0, s, a);
+        }
         return mrcnn_launch_status();
     }
     const bool ring = (tile && !strcmp(tile, "ring")) || getenv("MRCNN_H16_RING") != nullptr;

@@ -504,12 +504,18 @@ extern "C" int mrcnn_fill_zero(void* dst, size_t bytes, void* stream) {
 }
 
 int g_mrcnn_wgrad_lds_pad = 0;
+int g_mrcnn_h16_phase = 1;
 
 extern "C" int mrcnn_tuning_set(const char* key, long long value) {
     if (!key) return MRCNN_ERR_ARG;
     if (!strcmp(key, "wgrad_lds_pad")) {
         if (value < 0 || value > 32768) return MRCNN_ERR_ARG;
         g_mrcnn_wgrad_lds_pad = (int)value;
+        return MRCNN_OK;
+    }
+    if (!strcmp(key, "h16_phase")) {
+        if (value < 0 || value > 1) return MRCNN_ERR_ARG;
+        g_mrcnn_h16_phase = (int)value;
         return MRCNN_OK;
     }
     return MRCNN_ERR_UNSUPPORTED;

@@ -207,9 +207,16 @@ class MaskRCNNEngine(object):
         self._h16_store = {}            # dtype -> {layer: (W^T image, data-gradient image)}, stable addresses
         self._h16_valid = False
         self.fused_mask_out_bwd = True  # single-pass backward of the mask-head output stage
+        # the persistent 256 x 256 16-bit kernel for the mask head's DATA gradients too (they run beside the weight gradients
+        # of the other stream; MRCNN_H16_PHASE_BWD=0 keeps them on the small-LDS kernel that shares CUs)
+        self.h16_phase_bwd = os.environ.get("MRCNN_H16_PHASE_BWD", "1") != "0"
         self.fused_dgrad_epilogue = True  # data-gradient convs of the mask head apply the lower layer's epilogue backward
-        self.wgrad_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
-        self.aux_stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        # stream priorities (HIP: -1 high, 0 normal, 1 low where the runtime has three levels): the weight gradients are off the
+        # critical path, so their stream may be given a lower priority than the chain of data gradients it runs beside
+        wprio = int(os.environ.get("MRCNN_WGRAD_PRIO", "0"))
+        aprio = int(os.environ.get("MRCNN_AUX_PRIO", "0"))
+        self.wgrad_stream = torch.cuda.Stream(device=device, priority=wprio) if torch.device(device).type == "cuda" else None
+        self.aux_stream = torch.cuda.Stream(device=device, priority=aprio) if torch.device(device).type == "cuda" else None
         # A/B switch, default OFF (measured, DESIGN.md "rejected"): the mask head's weight gradients feed nothing in the
         # backward chain, so they can be held back and issued (auxiliary stream) when the backbone's backward pass starts,
         # to fill the chip beside its ~330 small launches; "wgrad_lds_pad" then keeps one workgroup slot per CU free for
@@ -971,6 +978,15 @@ class MaskRCNNEngine(object):
         self._mask_head_bwd_rows(g.view((B * R,) + tuple(g.shape[2:])), ctxs, rois, dP, area, before_adjoint)
 
     def _mask_head_bwd_rows(self, g, ctxs, rois, dP, area, before_adjoint=None):
+        if not self.h16_phase_bwd:
+            ops.tuning_set("h16_phase", 0)
+        try:
+            self._mask_head_bwd_rows_impl(g, ctxs, rois, dP, area, before_adjoint)
+        finally:
+            if not self.h16_phase_bwd:
+                ops.tuning_set("h16_phase", 1)
+
+    def _mask_head_bwd_rows_impl(self, g, ctxs, rois, dP, area, before_adjoint=None):
         cfg = self.cfg
         c1, c2, c3, c4, cdec, cm = ctxs
         mop, dc = self.op("mrcnn_mask"), self.op("mrcnn_mask_deconv")

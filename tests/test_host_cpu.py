@@ -31,6 +31,42 @@ def test_cabi_library_exports_header_symbols():
     assert b"gfx950" in lib.mrcnn_hip_version()
 
 
+def test_built_objects_have_no_store_data_hazard():
+    """Machine-code check of the built kernel objects (caesar-mrcnn_amd/isa_check.py): a > 64-bit buffer store with an SGPR
+    soffset must not be followed within two slots by a vector write of its data registers -- gfx950 loses that race on a
+    cold instruction cache and LLVM's recogniser does not cover the SGPR form (the phased 16-bit convolution stored stray
+    dwords that way).  The scanner itself is checked on the pattern that was found."""
+    import glob
+    import __graft_entry__ as ge
+    from caesar_mrcnn_amd import isa_check
+    listing = """
+0000000000001000 <kern>:
+	buffer_store_dwordx4 v[62:65], v82, s[40:43], s0 offen  // 00000001D84C: E07C1000
+	v_mul_f32_e32 v62, v34, v66                              // 00000001D854: 0A7C8522
+	buffer_store_dwordx4 v[58:61], v82, s[40:43], s0 offen
+	v_readlane_b32 s0, v234, 2
+	v_mul_f32_e32 v58, v42, v74
+	buffer_store_dwordx4 v[58:61], v82, s[40:43], s0 offen
+	s_nop 2
+	v_mul_f32_e32 v58, v42, v74
+	buffer_store_dwordx4 v[58:61], v82, s[40:43], 0 offen
+	v_mul_f32_e32 v58, v42, v74
+	buffer_store_dwordx4 v[58:61], v82, s[40:43], s0 offen
+	v_mul_f32_e32 v57, v42, v74
+	v_mul_f32_e32 v62, v42, v74
+	v_cmp_gt_f32_e32 vcc, v58, v74
+"""
+    hits = isa_check.store_data_hazards(listing)
+    assert [h[2] for h in hits] == ["v_mul_f32_e32 v62, v34, v66", "v_mul_f32_e32 v58, v42, v74"], hits
+    if not isa_check.tools_available():
+        pytest.skip("llvm-objcopy / clang-offload-bundler / llvm-objdump not found")
+    ge.build()
+    objs = sorted(glob.glob(os.path.join(ROOT, "caesar-mrcnn_amd", "build", "*.o")))
+    assert len(objs) >= 10
+    for o in objs:
+        isa_check.check_object(o)
+
+
 def test_product_path_has_no_cpu_fallback():
     import torch
     from caesar_mrcnn_amd import ops, _hip

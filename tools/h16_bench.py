@@ -27,10 +27,16 @@ for dtype in (torch.float16, torch.bfloat16):
     wf, wd = ops.weights_to_h16(w, dtype)
     b = torch.zeros(256, device=dev); sc = torch.ones(256, device=dev)
     out = torch.empty(N, 14, 14, 256, device=dev, dtype=dtype)
-    for tile in ("small", "big", "phase") * 2:                        # interleaved rounds in one process
-        os.environ["MRCNN_H16_TILE"] = tile
+    for tile in ("small", "big", "phase", "phase-nosplit") * 2:       # interleaved rounds in one process
+        os.environ["MRCNN_H16_TILE"] = tile.split("-")[0]
+        os.environ.pop("MRCNN_H16P_NO_SPLIT", None)
+        os.environ.pop("MRCNN_H16P_GRID", None)
+        if "nosplit" in tile:
+            os.environ["MRCNN_H16P_NO_SPLIT"] = "1"
+        if "-g" in tile:
+            os.environ["MRCNN_H16P_GRID"] = tile.split("-g")[1]
         ms = timed(lambda: ops.conv2d_h16(x, wf, (3, 3, 256, 256), b, sc, b, 1, "same", 1, out=out))
-        print("%s fwd tile=%-5s N=%d: %.3f ms  %.1f TFLOP/s" % (dtype, tile, N, ms, fl / ms / 1e9), flush=True)
+        print("%s fwd tile=%-22s N=%d: %.3f ms  %.1f TFLOP/s" % (dtype, tile, N, ms, fl / ms / 1e9), flush=True)
     del os.environ["MRCNN_H16_TILE"]
     dy = torch.randn(N, 14, 14, 256, device=dev).to(dtype)
     dw = torch.empty(3, 3, 256, 256, device=dev)

@@ -15,6 +15,11 @@ model = MaskRCNN("training", cfg, "/tmp/mrcnn_bench_logs", device=dev, seed=0)
 model.compile(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM)
 inp = model._to_device(bench.synthetic_batch(cfg, nimg, seed=1234))
 eng = model.engine
+if os.environ.get("MRCNN_LR"):                                 # e.g. 0: time the same weights every step
+    cfg.LEARNING_RATE = float(os.environ["MRCNN_LR"])
+if os.environ.get("MRCNN_MAIN_PRIO"):                          # run the step from a stream of this priority (-1 = high)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ["MRCNN_MAIN_PRIO"])))
 only = sys.argv[3] if len(sys.argv) > 3 else ""            # e.g. "sparse-f32": profile a single mode
 for sparse in (False, True):
     for hd in (None, torch.float16, torch.bfloat16):
@@ -34,8 +39,12 @@ for sparse in (False, True):
                 eng.forward_backward(*inp); eng.apply_gradients(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM, 1)
         for _ in range(3):
             step()
-        torch.cuda.synchronize(); t0 = time.time()
-        for _ in range(10):
-            step()
-        torch.cuda.synchronize(); dt = (time.time() - t0) / 10
-        print("sparse=%-5s head=%-14s %s %.2f ms/step  %.1f img/s" % (sparse, hd, "tape" if taped else "graph" if graphed else "eager", dt * 1e3, nimg / dt))
+        runs = []
+        for _ in range(int(os.environ.get("MRCNN_TIMING_RUNS", "1"))):       # several runs of 10: the streams' races make single runs bimodal
+            torch.cuda.synchronize(); t0 = time.time()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize(); runs.append((time.time() - t0) / 10)
+        dt = sorted(runs)[len(runs) // 2]
+        print("sparse=%-5s head=%-14s %s %.2f ms/step  %.1f img/s%s" % (sparse, hd, "tape" if taped else "graph" if graphed else "eager", dt * 1e3, nimg / dt,
+              "   (runs: %s)" % " ".join("%.2f" % (r * 1e3) for r in runs) if len(runs) > 1 else ""))
