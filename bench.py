@@ -467,6 +467,7 @@ def measure_config4(args, rank, local_rank, world):
         out["value_" + tag] = round(nimg / t, 3)
         out["ms_per_step_" + tag] = round(t * 1e3, 3)
         out["losses_" + tag] = [round(float(v), 5) for v in losses.cpu().numpy()]
+    out["skipped_steps_f16"] = eng.skipped_step_count()      # guarded optimiser: steps with non-finite float16 gradients
     eng.sparse_mask_bwd, eng.head_dtype = True, None
     # roofline of the dominant 16-bit kernel (mask-head 3x3 convolution, forward / data gradient), live HIP events
     M_rois = nimg * cfg.TRAIN_ROIS_PER_IMAGE
@@ -488,9 +489,26 @@ def measure_config4(args, rank, local_rank, world):
         ach = flops / (k_ms * 1e-3) / 1e12
         out["roofline_" + tag] = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
                                   "frac": round(ach / 2500.0, 4), "traffic": None,
-                                  "kernel": "conv_fwd_h16_kernel<%s>, 256x128 tile (mask-head 3x3 conv, M=%d N=256 K=2304, %.1f "
-                                            "GFLOP/launch, %.3f ms/launch)" % (tag, M_rois * 196, flops / 1e9, k_ms)}
-        del xm, om
+                                  "kernel": "conv_fwd_h16p_kernel<%s>, persistent 256x256 tiles in two staggered wave groups "
+                                            "(+ conv_fwd_h16s_kernel for the last partial round); mask-head 3x3 conv, M=%d N=256 "
+                                            "K=2304, %.1f GFLOP/launch, %.3f ms/launch" % (tag, M_rois * 196, flops / 1e9, k_ms)}
+        # the same layer's weight gradient (pixel table + kernel + slab reduction), as the step runs it
+        dym = torch.randn((M_rois, 14, 14, 256), device=dev).to(dt)
+        dwm = torch.empty((3, 3, 256, 256), device=dev)
+        for _ in range(3):
+            ops.conv2d_wgrad_h16(xm, dym, (3, 3, 256, 256), 1, "same", dw=dwm)
+        e0.record()
+        for _ in range(20):
+            ops.conv2d_wgrad_h16(xm, dym, (3, 3, 256, 256), 1, "same", dw=dwm)
+        e1.record()
+        torch.cuda.synchronize()
+        k_ms = e0.elapsed_time(e1) / 20
+        ach = flops / (k_ms * 1e-3) / 1e12
+        out["roofline_wgrad_" + tag] = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                        "frac": round(ach / 2500.0, 4), "traffic": None,
+                                        "kernel": "conv_wgrad_h16_kernel<%s> + pixel table + slab reduction (same layer, %.3f "
+                                                  "ms/launch)" % (tag, k_ms)}
+        del xm, om, dym
     return out
 
 

@@ -134,6 +134,7 @@ _SIGNATURES = {
     "mrcnn_grad_prepare": (C.c_int, [_P, _P, C.c_float, _P, C.c_int64, _P, _P]),
     "mrcnn_sumsq": (C.c_int, [_P, C.c_int64, _P, _P]),
     "mrcnn_sgd_momentum": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, C.c_int64, _P]),
+    "mrcnn_sgd_momentum_guarded": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, C.c_int64, _P, _P]),
     "mrcnn_allreduce_load": (C.c_int, [C.c_char_p]),
     "mrcnn_allreduce_unique_id": (C.c_int, [_P]),
     "mrcnn_allreduce_init": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int]),

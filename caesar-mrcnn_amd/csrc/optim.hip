@@ -80,9 +80,14 @@ __global__ __launch_bounds__(256) void grad_prepare_kernel(f32x4* grads, const f
 
 __global__ __launch_bounds__(256) void sgd_kernel(f32x4* params, f32x4* mom, const f32x4* __restrict__ grads,
                                                   const float* __restrict__ sumsq, float clipnorm, float lr,
-                                                  float momentum, const float* __restrict__ gran_coef, int64_t n4) {
+                                                  float momentum, const float* __restrict__ gran_coef, int64_t n4,
+                                                  unsigned* skipped) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (skipped && !isfinite(sumsq[0])) {                  // guarded form: an overflowed step leaves weights and momentum alone
+        if (i == 0) atomicAdd(skipped, 1u);
+        return;
+    }
     float clip = 1.f;
     if (clipnorm > 0.f) {
         const float norm = sqrtf(sumsq[0]);
@@ -109,7 +114,22 @@ extern "C" int mrcnn_sgd_momentum(float* params, float* momentum_buf, const floa
     int64_t blocks = cdiv64(n / 4, 256 * 2);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (f32x4*)params,
-                       (f32x4*)momentum_buf, (const f32x4*)grads, sumsq, clipnorm, lr, momentum, gran_coef, n / 4);
+                       (f32x4*)momentum_buf, (const f32x4*)grads, sumsq, clipnorm, lr, momentum, gran_coef, n / 4,
+                       (unsigned*)nullptr);
+    return mrcnn_launch_status();
+}
+
+// Mixed-precision form (not in the reference, whose graph is float32 throughout): float16 gradients can overflow under the
+// static loss scale; when the global squared norm is not finite the step is skipped on the device -- no host
+// synchronisation -- and *skipped_steps counts it, so that the host can lower the loss scale when it next looks.
+extern "C" int mrcnn_sgd_momentum_guarded(float* params, float* momentum_buf, const float* grads, const float* sumsq,
+                                          float clipnorm, float lr, float momentum, const float* gran_coef, int64_t n,
+                                          unsigned* skipped_steps, void* stream) {
+    if (!params || !momentum_buf || !grads || !sumsq || !gran_coef || !skipped_steps || n <= 0 || (n & 63)) return MRCNN_ERR_ARG;
+    int64_t blocks = cdiv64(n / 4, 256 * 2);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sgd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (f32x4*)params,
+                       (f32x4*)momentum_buf, (const f32x4*)grads, sumsq, clipnorm, lr, momentum, gran_coef, n / 4, skipped_steps);
     return mrcnn_launch_status();
 }
 

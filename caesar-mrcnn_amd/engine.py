@@ -199,6 +199,8 @@ class MaskRCNNEngine(object):
         # gradient buffer stay float32.  None (default) = float32 everywhere.  loss_scale guards float16 gradients.
         self.head_dtype = None
         self.loss_scale = 4096.0
+        self.skipped_steps = torch.zeros(1, dtype=torch.int32, device=device)   # steps the guarded optimiser refused (float16)
+        self._skipped_seen = 0
         self.h16_wide = os.environ.get("MRCNN_H16_WIDE", "1") != "0"   # False: only the mask head in 16 bits (round-1 stages 1-2)
         self.h16_blocks = os.environ.get("MRCNN_H16_BLOCKS", "1") != "0"   # bottleneck blocks in 16 bits (stage 4)
         self.h16_all_blocks = os.environ.get("MRCNN_H16_ALL_BLOCKS", "1") != "0"   # 0: only the identity blocks of res4 / res5
@@ -1369,12 +1371,31 @@ class MaskRCNNEngine(object):
     # =========================================================================================
     #  optimiser (MaskRCNN.compile, model.py:2255-2291)
     # =========================================================================================
+    def skipped_step_count(self):
+        """Steps whose float16 gradients were not finite (skipped on the device).  Synchronises: call it where the host
+        reads the losses anyway."""
+        return int(self.skipped_steps.item())
+
+    def adapt_loss_scale(self, floor=1.0):
+        """Dynamic part of the loss scaling, done wherever the host looks (MaskRCNN.train: once per epoch): halve the scale
+        once for every step skipped since the last look.  Returns the number of newly skipped steps."""
+        n = self.skipped_step_count()
+        new = n - self._skipped_seen
+        self._skipped_seen = n
+        if new > 0:
+            self.loss_scale = max(float(floor), self.loss_scale / (2.0 ** min(new, 8)))
+        return new
+
     def apply_gradients(self, learning_rate, momentum, world_size=1):
         """grads (already summed over ranks) -> /world, + L2 term, global-norm clip, SGD-momentum."""
         cfg = self.cfg
         ops.grad_prepare(self.grads, self.params, 1.0 / world_size, self.gran_coef, self.sumsq)
+        # float16 mode: a gradient that overflowed under the static loss scale must not reach the weights -- the guarded form
+        # skips the update on the device and counts it (skipped_step_count / adapt_loss_scale); float32 and bfloat16 keep the
+        # reference's plain Keras semantics
+        guard = self.skipped_steps if self.head_dtype == torch.float16 else None
         ops.sgd_momentum(self.params, self.momentum, self.grads, self.sumsq, cfg.GRADIENT_CLIP_NORM, learning_rate,
-                         momentum, self.gran_coef)
+                         momentum, self.gran_coef, skipped=guard)
         self.wt_valid = False
         self._h16_valid = False
         self.fold_bn()

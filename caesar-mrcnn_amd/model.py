@@ -284,6 +284,9 @@ class MaskRCNN(object):
                 inputs, _ = next(train_gen)
                 acc += self.train_on_batch(inputs, reducer=reducer, world_size=world)
             tr = allreduce_mean_scalars(acc / cfg.STEPS_PER_EPOCH, world).cpu().numpy()
+            skipped = self.engine.adapt_loss_scale()          # float16 mode: overflowed steps were skipped on the device
+            if skipped and rank == 0:
+                print("%d step(s) skipped (non-finite float16 gradients); loss scale now %g" % (skipped, self.engine.loss_scale))
             vacc = torch.zeros(5, device=self.engine.dev)
             for step in range(cfg.VALIDATION_STEPS):
                 inputs, _ = next(val_gen)

@@ -577,8 +577,15 @@ def sumsq(g, out):
     check(_hip.lib().mrcnn_sumsq(ptr(g), g.numel(), ptr(out), current_stream()), "mrcnn_sumsq")
 
 
-def sgd_momentum(params, mom, grads, sumsq_t, clipnorm, lr, momentum, gran_coef):
-    _need_cuda(params, mom, grads, sumsq_t, gran_coef)
+def sgd_momentum(params, mom, grads, sumsq_t, clipnorm, lr, momentum, gran_coef, skipped=None):
+    """skipped (int32 device tensor, 1 element): the guarded mixed-precision form -- a non-finite gradient norm skips the
+    update on the device and counts the step there."""
+    _need_cuda(params, mom, grads, sumsq_t, gran_coef, skipped)
+    if skipped is not None:
+        check(_hip.lib().mrcnn_sgd_momentum_guarded(ptr(params), ptr(mom), ptr(grads), ptr(sumsq_t), float(clipnorm), float(lr),
+                                                    float(momentum), ptr(gran_coef), params.numel(), ptr(skipped),
+                                                    current_stream()), "mrcnn_sgd_momentum_guarded")
+        return
     check(_hip.lib().mrcnn_sgd_momentum(ptr(params), ptr(mom), ptr(grads), ptr(sumsq_t), float(clipnorm), float(lr),
                                         float(momentum), ptr(gran_coef), params.numel(), current_stream()),
           "mrcnn_sgd_momentum")

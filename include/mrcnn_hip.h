@@ -374,6 +374,12 @@ int mrcnn_sumsq(const float* g, int64_t n, float* out_scalar, void* stream);
 int mrcnn_sgd_momentum(float* params, float* momentum_buf, const float* grads, const float* sumsq,
                        float clipnorm, float lr, float momentum, const float* gran_coef, int64_t n,
                        void* stream);
+/* Mixed-precision form (BASELINE configs[4]; no counterpart in the float32 reference): when *sumsq is not finite -- a
+ * float16 gradient overflowed under the loss scale -- the update is skipped on the device (weights and momentum untouched,
+ * no host synchronisation) and *skipped_steps (device, 32-bit) is incremented.                                              */
+int mrcnn_sgd_momentum_guarded(float* params, float* momentum_buf, const float* grads, const float* sumsq,
+                               float clipnorm, float lr, float momentum, const float* gran_coef, int64_t n,
+                               unsigned* skipped_steps, void* stream);
 
 /* ---- data-parallel gradient exchange over RCCL / xGMI ---------------------------------------------------------------
  * Replaces the in-graph tower aggregation of mrcnn/parallel_model.py:54-104 (weights shared between towers, gradients

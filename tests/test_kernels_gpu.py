@@ -644,6 +644,39 @@ def test_losses(dev, dice):
         torch.testing.assert_close(got.cpu(), ref.grad, rtol=1e-4, atol=1e-7)
 
 
+def test_guarded_sgd_skips_non_finite_steps(dev):
+    """Mixed-precision form of the optimiser step (mrcnn_sgd_momentum_guarded): bitwise the plain step while the squared
+    gradient norm is finite; with an overflowed float16 gradient (inf / NaN in the buffer -> non-finite norm out of
+    grad_prepare) weights and momentum stay bit-identical and the device counter moves."""
+    ops = _ops()
+    rng = np.random.default_rng(52)
+    n = 64 * 40
+    P, G, V = _rand(rng, n), _rand(rng, n, scale=3.0), _rand(rng, n, scale=0.1)
+    gran = np.full(n // 64, 1e-5, np.float32)
+    gd = torch.tensor(gran, device=dev)
+    skipped = torch.zeros(1, dtype=torch.int32, device=dev)
+    res = []
+    for guarded in (False, True):
+        Pd, Gd, Vd = (torch.tensor(a, device=dev) for a in (P, G, V))
+        ss = torch.zeros(1, device=dev)
+        ops.grad_prepare(Gd, Pd, 1.0, gd, ss)
+        ops.sgd_momentum(Pd, Vd, Gd, ss, 5.0, 0.01, 0.9, gd, skipped=skipped if guarded else None)
+        res.append((Pd.cpu().numpy(), Vd.cpu().numpy()))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    assert int(skipped.item()) == 0 and not np.array_equal(res[0][0], P)
+    for k, poison in enumerate((np.inf, np.nan, -np.inf)):
+        Gbad = G.copy(); Gbad[1234] = poison
+        Pd, Gd, Vd = (torch.tensor(a, device=dev) for a in (P, Gbad, V))
+        ss = torch.zeros(1, device=dev)
+        ops.grad_prepare(Gd, Pd, 1.0, gd, ss)
+        assert not np.isfinite(float(ss))
+        ops.sgd_momentum(Pd, Vd, Gd, ss, 5.0, 0.01, 0.9, gd, skipped=skipped)
+        np.testing.assert_array_equal(Pd.cpu().numpy(), P)
+        np.testing.assert_array_equal(Vd.cpu().numpy(), V)
+        assert int(skipped.item()) == k + 1
+
+
 def test_sgd_step(dev):
     ops = _ops()
     rng = np.random.default_rng(51)
