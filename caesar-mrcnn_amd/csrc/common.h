@@ -41,6 +41,16 @@ static inline int mrcnn_num_cus() {
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Workgroups are dealt to the 8 XCDs round robin (workgroup b runs on XCD b % 8), and every XCD has its own L2.  This maps
+// the hardware id to a LOGICAL id such that consecutive logical ids share an XCD: XCD x owns the logical range
+// [x * per + min(x, rem), ...) with per = blocks / 8, rem = blocks % 8.  A bijection on [0, blocks).  Kernels whose
+// neighbouring workgroups read the same operands (the pixel splits of a weight gradient: all (tap, channel tile) workgroups
+// of one split) index their work with it, so that the operands are fetched into ONE L2 instead of eight.
+__device__ __forceinline__ unsigned mrcnn_xcd_contiguous(unsigned b, unsigned blocks) {
+    const unsigned per = blocks >> 3, rem = blocks & 7u, x = b & 7u, slot = b >> 3;
+    return x * per + (x < rem ? x : rem) + slot;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -1092,7 +1092,7 @@ typedef __attribute__((address_space(3))) s16x4* h16_tr_ptr;
 
 struct WgradH16Args {
     const void* x; const void* dy; float* out; const PixelEntry* table;
-    int N, H, W, Cin, Cout, KH, KW, OH, OW, M, Ktot, splits, chunk;
+    int N, H, W, Cin, Cout, KH, KW, OH, OW, M, Ktot, splits, chunk, xcd_order;
     unsigned x_shift, x_records;
 };
 
@@ -1111,7 +1111,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(const WgradH16Ar
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int ntiles = p.Cout / BN, itiles = p.Ktot / BI;
-    int bid = blockIdx.x;
+    // all (tap, channel-tile) workgroups of one pixel split read the same dY rows and -- shifted by a tap -- the same X
+    // rows: keep them on one XCD (PMC: FETCH_SIZE 2.57 GB per launch on the mask-head shape with the plain order, 6.2 x
+    // the algorithmic bytes, profiles/r02_pmc_h16_kernels.txt)
+    int bid = p.xcd_order ? (int)mrcnn_xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int ntile = bid % ntiles; bid /= ntiles;
     const int itile = bid % itiles;
     const int split = bid / itiles;
@@ -1325,6 +1328,8 @@ extern "C" int mrcnn_conv2d_wgrad_h16(const mrcnn_conv_desc* d, int dtype, const
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.OH = d->OH; a.OW = d->OW;
     a.M = (int)M; a.Ktot = d->KH * d->KW * d->Cin; a.splits = pl.splits; a.chunk = pl.chunk;
     a.x_shift = (unsigned)shift_b; a.x_records = (unsigned)(xbytes + shift_b);
+    static const int xcd_env = getenv("MRCNN_WGRAD_XCD") ? atoi(getenv("MRCNN_WGRAD_XCD")) : 1;
+    a.xcd_order = xcd_env;
     const unsigned blocks = (unsigned)((a.Ktot / 256) * (a.Cout / 128) * pl.splits);
     if (dtype == MRCNN_DTYPE_F16)
         hipLaunchKernelGGL(conv_wgrad_h16_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, a);
