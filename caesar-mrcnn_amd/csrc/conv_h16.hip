@@ -1253,6 +1253,224 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_h16_kernel(const WgradH16Ar
         }
 }
 
+// Phased weight gradient for the big stride-1 "same" layers (mask head: M = 401 408 pixels, 9 taps x 256 x 256): the
+// schedule of conv_fwd_h16p_kernel turned to the pixel contraction.  A workgroup owns one 256 (tap, ci) x 256 co tile of dW
+// over one pixel split (tiles x splits ~ one workgroup per CU, one round); 8 waves = two staggered groups of four
+// (wr = wave >> 2: 128 input channels, wc = wave & 3: 64 output channels), each wave 8 x 4 tiles of v_mfma_f32_16x16x32
+// (A = dY^T, B = X: a lane ends with 4 consecutive co of one (tap, ci) row), K-step = 64 pixels, two 64 KiB stages.
+//   phases     as in the forward kernel: four per K-step, [operand reads | one quarter of a later stage by LDS-DMA |
+//              s_waitcnt vmcnt(8)] s_barrier [16 MFMAs] s_barrier, group 1 one barrier behind group 0; quadrants
+//              (X0,Y0) (X0,Y1) (X1,Y1) (X1,Y0) with X0 / X1 = the wave's input channels 0..63 / 64..127 and Y0 / Y1 = its
+//              output channels 0..31 / 32..63; quarter issue order (t+1).B1 (t+1).A1 (t+2).A0 (t+2).B0 (t+2).B1 (t+2).A1
+//              (t+3).A0 (t+3).B0 -- every quarter is re-staged >= 2 phases after its last read, lands >= 4 phases later.
+//   staging    both operands are pixel-major in memory, so a quarter is [64 pixels][128 channels] (256-byte rows): A0 / A1 =
+//              the X0 / X1 channels of both groups, B0 / B1 = the Y0 / Y1 channels of the four wave columns; a DMA piece =
+//              4 pixel rows, 2 pieces per wave and quarter.  The contraction index is the ROW index of both tiles: every MFMA
+//              operand is two ds_read_b64_tr_b16 (4 pixels x 16 channels each).  One such read touches pixel rows
+//              8 fq + q (fq = lane >> 4, q = (lane & 15) >> 2), 32 bytes in each; rows are 256 bytes = all 64 banks apart, so
+//              logical 16-byte chunk c of pixel row r is stored at chunk c ^ (((r & 3) | ((r >> 3) & 1) << 2) << 1) -- the 16
+//              rows of a read then cover every 32-byte bank group exactly twice (the minimum for 512 bytes), applied on the
+//              DMA's source side and in the read addresses.
+//   addresses  stride 1 and OH == H, OW == W make the input row of (pixel m, tap) linear: m + kh * W + kw rows behind the
+//              shifted base; only the tap's validity needs (oh, ow), two multiply-high divisions per piece.  No table, no
+//              ordinary global load in the loop (the counted vmcnt waits see DMA pieces only).  Rows past the split's end
+//              fall outside the dY descriptor (zeros); X rows there are switched off too (0 x NaN).
+static void h16_magic(unsigned d, unsigned* mg, unsigned* sh);
+
+struct WgradH16PArgs {
+    const void* x; const void* dy; float* out;
+    int H, W, Cin, Cout, KW, pad_t, pad_l, M, Ktot, chunk, nk, itiles, ntiles, ohw;
+    unsigned x_shift, x_records, mg_ohw, sh_ohw, mg_ow, sh_ow;
+};
+
+template <typename T>
+__global__ __launch_bounds__(512) void conv_wgrad_h16p_kernel(const WgradH16PArgs p) {
+    typedef typename H16Traits<T>::v8 v8;
+    constexpr int QBYTES = 16384, ROW = 256;
+    // EIGHT LDS objects, one per (stage, quarter): hipcc orders an LDS read after every LDS-DMA it cannot tell apart from the
+    // read's object -- with one array it put s_waitcnt vmcnt(0) in front of the transposed reads of every phase.  A phase
+    // never reads the quarter it stages, so with separate objects the only waits the compiler adds are for the DMA that
+    // filled the quarter being read (>= 4 phases old: weaker than the kernel's own vmcnt(8)).
+    __shared__ __attribute__((aligned(16))) char q_a0_s0[QBYTES];
+    __shared__ __attribute__((aligned(16))) char q_b0_s0[QBYTES];
+    __shared__ __attribute__((aligned(16))) char q_b1_s0[QBYTES];
+    __shared__ __attribute__((aligned(16))) char q_a1_s0[QBYTES];
+    __shared__ __attribute__((aligned(16))) char q_a0_s1[QBYTES];
+    __shared__ __attribute__((aligned(16))) char q_b0_s1[QBYTES];
+    __shared__ __attribute__((aligned(16))) char q_b1_s1[QBYTES];
+    __shared__ __attribute__((aligned(16))) char q_a1_s1[QBYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    int bid = blockIdx.x;
+    const int ntile = bid % p.ntiles; bid /= p.ntiles;
+    const int itile = bid % p.itiles;
+    const int split = bid / p.itiles;
+    const int i0 = itile * 256, n0 = ntile * 256;
+    const int tap = i0 / p.Cin, ci0 = i0 - tap * p.Cin;
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int dh = kh - p.pad_t, dw_ = kw - p.pad_l;
+    const int m_begin = split * p.chunk;
+    const int m_end = (m_begin + p.chunk < p.M) ? m_begin + p.chunk : p.M;
+    const int nk = p.nk, nk2 = (nk + 1) & ~1;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - p.x_shift), 0, p.x_records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_y =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (unsigned)((long long)m_end * p.Cout * 2), 0x00020000);
+    const unsigned soff_x = (unsigned)(((kh * p.W + kw) * p.Cin + ci0) * 2);
+    const unsigned soff_y = (unsigned)(n0 * 2);
+
+    // ---- DMA pieces: piece pc = wave + 8 j of a quarter = pixel rows 4 pc .. 4 pc + 3; lane -> (row r4, physical chunk) ----
+    const int r4 = lane >> 4, pchunk = lane & 15;
+    unsigned a_chan[2][2], b_chan[2][2];            // [quarter 0/1][piece j]: byte offset of this lane's 8 channels inside the pixel row
+    int row_in_step[2];                             // pixel row of the piece inside the K-step
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = 4 * (wave + 8 * j) + r4;
+        row_in_step[j] = r;
+        const int lc = pchunk ^ ((((r & 3) | (((r >> 3) & 1) << 2)) << 1));
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            a_chan[q][j] = (unsigned)(((lc >> 3) * 128 + q * 64 + (lc & 7) * 8) * 2);
+            b_chan[q][j] = (unsigned)(((lc >> 2) * 64 + q * 32 + (lc & 3) * 8) * 2);
+        }
+    }
+    const int piece_lds0 = wave * 1024, piece_lds1 = (wave + 8) * 1024;
+
+    int it_kt = 0;                                  // the K-step whose quarters are being issued
+    auto issue_a = [&](auto qc, auto bufc) {
+        constexpr int q = decltype(qc)::value;
+        char* base = decltype(bufc)::value ? (q ? q_a1_s1 : q_a0_s1) : (q ? q_a1_s0 : q_a0_s0);
+        const int mb = m_begin + it_kt * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = mb + row_in_step[j];
+            const unsigned n = p.mg_ohw ? (__umulhi((unsigned)m, p.mg_ohw) >> p.sh_ohw) : (unsigned)m;
+            const unsigned pos = (unsigned)m - n * (unsigned)p.ohw;
+            const unsigned oh = p.mg_ow ? (__umulhi(pos, p.mg_ow) >> p.sh_ow) : pos;
+            const unsigned ow = pos - oh * (unsigned)p.W;
+            const bool ok = (unsigned)((int)oh + dh) < (unsigned)p.H && (unsigned)((int)ow + dw_) < (unsigned)p.W && m < m_end &&
+                            it_kt < nk;
+            const unsigned vo = ok ? (unsigned)m * (unsigned)(p.Cin * 2) + a_chan[q][j] : H16_OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (h16_lds_ptr)(base + (j ? piece_lds1 : piece_lds0)), 16, vo, soff_x, 0, 0);
+        }
+    };
+    auto issue_b = [&](auto qc, auto bufc) {
+        constexpr int q = decltype(qc)::value;
+        char* base = decltype(bufc)::value ? (q ? q_b1_s1 : q_b0_s1) : (q ? q_b1_s0 : q_b0_s0);
+        const int mb = m_begin + it_kt * 64;
+        const unsigned dead = it_kt < nk ? 0u : H16_OOB_OFFSET;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned vo = ((unsigned)(mb + row_in_step[j]) * (unsigned)(p.Cout * 2) + b_chan[q][j]) | dead;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, (h16_lds_ptr)(base + (j ? piece_lds1 : piece_lds0)), 16, vo, soff_y, 0, 0);
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- transposed operand reads: lane (g = lane & 15, fq = lane >> 4) addresses pixel row 8 fq + (g >> 2) (+ 4, + 32 ks) and
+    // the 8 bytes of channels 4 (g & 3) .. + 3 of the 16-channel tile; it receives channel g of those four pixels ----
+    const int g = lane & 15, fq = lane >> 4, q4 = g >> 2, sb = g & 3;
+    const int fsw = (q4 | ((fq & 1) << 2)) << 1;
+    const int rd_row = (8 * fq + q4) * ROW + (sb & 1) * 8;
+    int x_rd[4], y_rd[2];                           // per 16-channel tile of a quarter: (logical chunk ^ swizzle) * 16, + row part
+#pragma unroll
+    for (int a = 0; a < 4; ++a) x_rd[a] = rd_row + ((((8 * wr + 2 * a) ^ fsw) + (sb >> 1)) << 4);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) y_rd[b] = rd_row + ((((4 * wc + 2 * b) ^ fsw) + (sb >> 1)) << 4);
+    auto rd8 = [&](const char* ptr) -> v8 {
+        union { s16x4 h[2]; v8 v; } u;
+        u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_tr_ptr)ptr);
+        u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((h16_tr_ptr)(ptr + 4 * ROW));
+        return u.v;
+    };
+    v8 xf[4][2], y0[2][2], y1[2][2];
+
+    auto phase = [&](auto phc) {
+        constexpr int PH = decltype(phc)::value;                // 0..7
+        constexpr int BUF = PH >> 2, Q = PH & 3;
+        if constexpr (Q == 0) {
+            const char* yq = BUF ? q_b0_s1 : q_b0_s0;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) y0[b][ks] = rd8(yq + y_rd[b] + ks * 32 * ROW);
+        }
+        if constexpr (Q == 1) {
+            const char* yq = BUF ? q_b1_s1 : q_b1_s0;
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) y1[b][ks] = rd8(yq + y_rd[b] + ks * 32 * ROW);
+        }
+        if constexpr (Q == 0 || Q == 2) {
+            if constexpr (Q == 0) __builtin_amdgcn_sched_barrier(0);
+            const char* xq = BUF ? (Q == 2 ? q_a1_s1 : q_a0_s1) : (Q == 2 ? q_a1_s0 : q_a0_s0);
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) xf[a][ks] = rd8(xq + x_rd[a] + ks * 32 * ROW);
+        }
+        // one quarter of a later stage
+        if constexpr (PH == 0) issue_b(I1{}, I1{});
+        if constexpr (PH == 1) { issue_a(I1{}, I1{}); ++it_kt; }
+        if constexpr (PH == 2) issue_a(I0{}, I0{});
+        if constexpr (PH == 3) issue_b(I0{}, I0{});
+        if constexpr (PH == 4) issue_b(I1{}, I0{});
+        if constexpr (PH == 5) { issue_a(I1{}, I0{}); ++it_kt; }
+        if constexpr (PH == 6) issue_a(I0{}, I1{});
+        if constexpr (PH == 7) issue_b(I0{}, I1{});
+        h16p_wait<8>();                                         // everything but the 4 youngest quarters has landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int AB = (Q >= 2) ? 4 : 0;                     // input-channel tiles of this quadrant
+        constexpr int CB = (Q == 1 || Q == 2) ? 2 : 0;           // output-channel tiles of this quadrant
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[AB + a][CB + b] = H16Traits<T>::mfma16((CB ? y1 : y0)[b][ks], xf[a][ks], acc[AB + a][CB + b]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // prologue: K-step 0 whole, K-step 1's A0 and B0; group 1 drops one barrier behind
+    issue_a(I0{}, I0{}); issue_b(I0{}, I0{}); issue_b(I1{}, I0{}); issue_a(I1{}, I0{}); ++it_kt;
+    issue_a(I0{}, I1{}); issue_b(I0{}, I1{});
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+
+    for (int t = 0; t < nk2; t += 2)
+        h16_static_for([&](auto phc) { phase(phc); }, std::make_integer_sequence<int, 8>{});
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the out-of-range tail DMAs still target this workgroup's LDS
+
+    // slab [split][Ktot][Cout]: lane (g, fq) holds rows (tap, ci) = .. + g, columns co = .. + 4 fq .. + 3
+    float* dst = p.out + (long long)split * p.Ktot * p.Cout;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const long long row = (long long)(i0 + wr * 128 + a * 16 + g) * p.Cout + n0 + wc * 64 + 4 * fq;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) *(f32x4*)(dst + row + b * 16) = acc[a][b];
+    }
+}
+
 __global__ void wgrad_h16_reduce_kernel(const float* __restrict__ slabs, float* dw, long long n, int splits, int acc, float mul) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1295,6 +1513,35 @@ static WgradH16Plan plan_wgrad_h16(const mrcnn_conv_desc* d) {
     return pl;
 }
 
+// Phased kernel (conv_wgrad_h16p_kernel): stride 1, output as large as the input, 256-channel tiles on both sides, one
+// workgroup per CU in one round, enough K-steps per split for the pipeline to matter.
+struct WgradH16PPlan { int ok, splits, chunk, nk, itiles, ntiles; size_t slab_bytes; };
+
+static WgradH16PPlan plan_wgrad_h16p(const mrcnn_conv_desc* d) {
+    WgradH16PPlan pl;
+    memset(&pl, 0, sizeof(pl));
+    // MRCNN_WGRAD_H16_PHASE (read per call: tests and A/B timings switch it): 0 never, 1 where it pays (default), 2 on every
+    // shape the kernel can take (tests: short and ragged pixel ranges)
+    const char* env = getenv("MRCNN_WGRAD_H16_PHASE");
+    const int enabled = env ? atoi(env) : 1;
+    const long long M = (long long)d->N * d->OH * d->OW;
+    if (!enabled || d->stride != 1 || d->OH != d->H || d->OW != d->W || d->Cin % 256 || d->Cout % 256 || d->KH * d->KW > 64 ||
+        d->pad_t < 0 || d->pad_l < 0 || d->pad_t >= d->KH || d->pad_l >= d->KW || M * d->Cout * 2 >= 0xFFFFFF00LL)
+        return pl;
+    const int cus = mrcnn_num_cus();
+    pl.itiles = d->KH * d->KW * d->Cin / 256; pl.ntiles = d->Cout / 256;
+    const long long tiles = (long long)pl.itiles * pl.ntiles;
+    long long splits = cus / tiles;
+    if (splits < 1) splits = 1;
+    if (splits > 64) splits = 64;
+    const long long chunk = ((M + splits - 1) / splits + 63) / 64 * 64;
+    splits = (M + chunk - 1) / chunk;
+    if (enabled < 2 && (chunk < 64 * 32 || tiles * splits * 2 < cus)) return pl;   // short K loops / half-empty chip: the table kernel's case
+    pl.ok = 1; pl.splits = (int)splits; pl.chunk = (int)chunk; pl.nk = (int)(chunk / 64);
+    pl.slab_bytes = (size_t)splits * d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
+    return pl;
+}
+
 static int wgrad_h16_shape_ok(const mrcnn_conv_desc* d) {
     return d && d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0 &&
            d->OH > 0 && d->OW > 0 && d->KH * d->KW <= 64 && d->Cin % 256 == 0 && d->Cout % 128 == 0;
@@ -1303,7 +1550,9 @@ static int wgrad_h16_shape_ok(const mrcnn_conv_desc* d) {
 extern "C" size_t mrcnn_conv2d_wgrad_h16_workspace(const mrcnn_conv_desc* d) {
     if (!wgrad_h16_shape_ok(d)) return 0;
     const WgradH16Plan pl = plan_wgrad_h16(d);
-    return pl.table_bytes + pl.slab_bytes + 256;
+    const WgradH16PPlan pp = plan_wgrad_h16p(d);
+    const size_t slabs = pl.slab_bytes > pp.slab_bytes ? pl.slab_bytes : pp.slab_bytes;
+    return pl.table_bytes + slabs + 512;
 }
 
 extern "C" int mrcnn_conv2d_wgrad_h16(const mrcnn_conv_desc* d, int dtype, const void* x, const void* dy, float* dw,
@@ -1320,6 +1569,24 @@ extern "C" int mrcnn_conv2d_wgrad_h16(const mrcnn_conv_desc* d, int dtype, const
     PixelEntry* table = (PixelEntry*)ws;
     float* slabs = (float*)(ws + ((pl.table_bytes + 255) & ~(size_t)255));
     hipStream_t s = (hipStream_t)stream;
+    const WgradH16PPlan pp = plan_wgrad_h16p(d);
+    if (pp.ok && ((reinterpret_cast<uintptr_t>(slabs) | reinterpret_cast<uintptr_t>(dw)) & 15) == 0) {
+        WgradH16PArgs b;
+        b.x = x; b.dy = dy; b.out = slabs;
+        b.H = d->H; b.W = d->W; b.Cin = d->Cin; b.Cout = d->Cout; b.KW = d->KW; b.pad_t = d->pad_t; b.pad_l = d->pad_l;
+        b.M = (int)M; b.Ktot = d->KH * d->KW * d->Cin; b.chunk = pp.chunk; b.nk = pp.nk; b.itiles = pp.itiles; b.ntiles = pp.ntiles;
+        b.ohw = d->OH * d->OW;
+        b.x_shift = (unsigned)shift_b; b.x_records = (unsigned)(xbytes + shift_b);
+        h16_magic((unsigned)(d->OH * d->OW), &b.mg_ohw, &b.sh_ohw);
+        h16_magic((unsigned)d->OW, &b.mg_ow, &b.sh_ow);
+        const unsigned pblocks = (unsigned)(pp.itiles * pp.ntiles * pp.splits);
+        if (dtype == MRCNN_DTYPE_F16) hipLaunchKernelGGL(conv_wgrad_h16p_kernel<_Float16>, dim3(pblocks), dim3(512), 0, s, b);
+        else hipLaunchKernelGGL(conv_wgrad_h16p_kernel<__bf16>, dim3(pblocks), dim3(512), 0, s, b);
+        const long long n = (long long)b.Ktot * b.Cout;                  // Cout % 256 == 0: the vector reduction always fits
+        hipLaunchKernelGGL(wgrad_h16_reduce_vec_kernel, dim3((unsigned)cdiv64(n / 4, 256)), dim3(256), 0, s, slabs, dw, n / 4,
+                           pp.splits, beta_acc, multiplier);
+        return mrcnn_launch_status();
+    }
     const int rows = (int)M + 32;
     hipLaunchKernelGGL(pixel_table_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, table, d->N, d->H, d->W, d->Cin,
                        d->KH, d->KW, d->stride, d->pad_t, d->pad_l, d->OH, d->OW, (int)M, rows, (unsigned)shift_b, 2);

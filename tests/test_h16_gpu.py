@@ -96,19 +96,34 @@ def test_conv_fwd_h16(dev, case, dtype, h16_tile):
 
 WGRAD_H16_CASES = [
     # N, H, W, Cin, Cout, k, padding
-    (64, 14, 14, 256, 256, 3, "same"),       # mask-head conv, several pixel splits
+    (64, 14, 14, 256, 256, 3, "same"),       # mask-head conv, several pixel splits; phased: 7 K-steps per split (odd: one zero step)
     (3, 13, 11, 256, 128, 3, "same"),        # M = 429: pixel tail inside a 32-row step, odd H/W
     (37, 7, 7, 256, 1024, 7, "valid"),       # class-head FC as 7x7 VALID conv: 49 taps, one pixel per ROI
     (5, 16, 16, 512, 128, 1, "valid"),       # 1x1, two channel tiles in one tap
+    (3, 13, 11, 256, 256, 3, "same"),        # phased kernel: M = 429 -> one K-step per split, ragged last split, odd H/W
+    (5, 16, 16, 512, 256, 1, "valid"),       # phased kernel: 1x1, two input-channel tiles
+    (4, 16, 16, 256, 512, 3, "same"),        # phased kernel: two output-channel tiles
+    (2, 12, 12, 256, 256, 5, "same"),        # phased kernel: 25 taps, padding 2
 ]
+
+
+@pytest.fixture(params=["table", "phase"])
+def wgrad_h16_kernel(request):
+    """MRCNN_WGRAD_H16_PHASE is read per call: 0 = the table-driven 256 x 128 kernel, 2 = the phased 256 x 256 kernel on every
+    shape it can take (stride 1, output as large as the input, channel counts multiples of 256; other shapes fall through)."""
+    os.environ["MRCNN_WGRAD_H16_PHASE"] = "0" if request.param == "table" else "2"
+    yield request.param
+    del os.environ["MRCNN_WGRAD_H16_PHASE"]
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("case", WGRAD_H16_CASES)
-def test_conv_wgrad_h16(dev, case, dtype):
+def test_conv_wgrad_h16(dev, case, dtype, wgrad_h16_kernel):
     """float32 result of exact 16-bit products: only the summation order differs from the oracle (2e-4 of max)."""
     ops = _ops()
     N, H, W, Cin, Cout, k, padding = case
+    if wgrad_h16_kernel == "phase" and (Cout % 256 or padding == "valid" and k > 1):
+        pytest.skip("phased kernel: Cout % 256 == 0, output as large as the input")
     rng = np.random.default_rng(sum(case[:6]) + 1)
     x = torch.tensor(rng.standard_normal((N, H, W, Cin)).astype(np.float32)).to(dtype)
     w = torch.zeros((k, k, Cin, Cout), requires_grad=True)
