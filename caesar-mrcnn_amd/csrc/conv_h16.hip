@@ -306,7 +306,7 @@ template <int N> __device__ __forceinline__ void h16p_wait() {        // s_waitc
 //              conflict-free for the ds_read_b128 lane groups of the 16-row operand tiles.
 //   output     the MFMA's A operand is the weight tile, so a lane ends with 4 CONSECUTIVE channels of one pixel: 8-byte
 //              stores, float4 bias / scale / shift.
-template <typename T, bool ZOUT>
+template <typename T, bool ZOUT, bool DECONV>
 __global__ __launch_bounds__(512) void conv_fwd_h16p_kernel(const ConvH16Args p) {
     typedef typename H16Traits<T>::v8 v8;
     constexpr int STAGE = 65536, BREG = 32768, PRM = 2 * STAGE, MAXC = 512;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(512) void conv_fwd_h16p_kernel(const ConvH16Args p)
     const int total = p.ptiles;                                 // the host may keep a last partial round for the small-tile kernel
     {   // y = max(acc * P0 + P1, floor), z = acc + P2
         float* prm = (float*)(lds + PRM);
-        for (int c = tid; c < p.Cout; c += 512) {
+        for (int c = tid; c < (DECONV ? p.cmod : p.Cout); c += 512) {       // DECONV: column (a*2+b)*cmod + c shares channel c's parameters
             const float bi = p.bias ? p.bias[c] : 0.f, sc = p.scale ? p.scale[c] : 1.f, sh = p.scale ? p.shift[c] : 0.f;
             prm[c] = sc;
             prm[MAXC + c] = sc * bi + sh;
@@ -459,6 +459,9 @@ __global__ __launch_bounds__(512) void conv_fwd_h16p_kernel(const ConvH16Args p)
         constexpr int PB = decltype(halfc)::value * 4;
         const int mtile = tile / ntiles, ntile = tile - mtile * ntiles;
         const int nb = ntile * 256 + wc * 64;
+        // DECONV (MRCNN_OUT_DECONV2): the 64 columns are channels cnb .. cnb + 63 of output pixel (2 oh + a, 2 ow + b),
+        // (a, b) = ab >> 1, ab & 1 -- still one 128-byte row per input pixel, only the row's address changes
+        const int ab = DECONV ? nb / p.cmod : 0, cnb = DECONV ? nb - ab * p.cmod : nb;
         char* stg = lds + STG + wave * 2048;
         int ln = lane;
         asm volatile("" : "+v"(ln));                            // per-call lane arithmetic: hoisted out of the K loop it costs registers there
@@ -467,10 +470,19 @@ __global__ __launch_bounds__(512) void conv_fwd_h16p_kernel(const ConvH16Args p)
         const int r8 = ln >> 3;
         const int rbase = r8 * 128 + (((ln & 7) ^ (r8 & 7)) << 4);
         const unsigned voff = (unsigned)(((mtile * 256 + wr * 128 + r8) * p.Cout + nb) * 2 + (ln & 7) * 16);
+        auto deconv_off = [&](int m) -> unsigned {              // byte offset of input pixel m's row of this chunk
+            if (m >= p.M) return H16_OOB_OFFSET;
+            const unsigned n = p.mg_ohw ? (__umulhi((unsigned)m, p.mg_ohw) >> p.sh_ohw) : (unsigned)m;
+            const unsigned rem = (unsigned)m - n * (unsigned)ohw;
+            const unsigned oh = p.mg_ow ? (__umulhi(rem, p.mg_ow) >> p.sh_ow) : rem;
+            const unsigned ow = rem - oh * (unsigned)p.OW;
+            return (n * (unsigned)p.ons + (2u * oh + (unsigned)(ab >> 1)) * (unsigned)p.ohs + (2u * ow + (unsigned)(ab & 1)) * (unsigned)p.ows +
+                    (unsigned)cnb) * 2u + (unsigned)(ln & 7) * 16u;
+        };
         f32x4 p0[4], p1[4], p2[4];                              // this lane's 16 channels: loaded once, not per pixel tile
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int n = nb + c * 16 + fq * 4;
+            const int n = cnb + c * 16 + fq * 4;
             p0[c] = *(const f32x4*)(lds + PRM + n * 4);
             p1[c] = *(const f32x4*)(lds + PRM + (MAXC + n) * 4);
             if constexpr (ZOUT) p2[c] = *(const f32x4*)(lds + PRM + (2 * MAXC + n) * 4);
@@ -504,13 +516,19 @@ __global__ __launch_bounds__(512) void conv_fwd_h16p_kernel(const ConvH16Args p)
                 }
             }
             if (i > 0) {
-                const unsigned soff = (unsigned)(((PB + i - 1) * 16 * p.Cout) * 2), soff8 = soff + (unsigned)(8 * p.Cout * 2);
+                unsigned soff = (unsigned)(((PB + i - 1) * 16 * p.Cout) * 2), soff8 = soff + (unsigned)(8 * p.Cout * 2);
+                unsigned vo0 = voff, vo8 = voff;
+                if constexpr (DECONV) {
+                    const int mrow = mtile * 256 + wr * 128 + (PB + i - 1) * 16 + r8;
+                    vo0 = deconv_off(mrow); vo8 = deconv_off(mrow + 8);
+                    soff = 0u; soff8 = 0u;
+                }
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_raw_buffer_store_b128(o0[i - 1], rsrc_o, voff, soff, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(o1[i - 1], rsrc_o, voff, soff8, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o0[i - 1], rsrc_o, vo0, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o1[i - 1], rsrc_o, vo8, soff8, 0);
                 if constexpr (ZOUT) {
-                    __builtin_amdgcn_raw_buffer_store_b128(z0[i - 1], rsrc_z, voff, soff, 0);
-                    __builtin_amdgcn_raw_buffer_store_b128(z1[i - 1], rsrc_z, voff, soff8, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(z0[i - 1], rsrc_z, vo0, soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(z1[i - 1], rsrc_z, vo8, soff8, 0);
                 }
                 asm volatile("s_nop 2");
                 __builtin_amdgcn_sched_barrier(0);
@@ -927,6 +945,91 @@ __global__ void mask_out_bwd_h16_kernel(const float* __restrict__ dmask, const f
         float s_ = 0.f;
         for (int pl = 0; pl < np; ++pl) s_ += sdz[pl * CP + ci];
         atomicAdd(&dbm[ci], s_);
+    }
+}
+
+// The same pass for Cd == 256 with 16-byte accesses: a pixel's 256 channels are 32 lanes x 8 channels, a workgroup walks
+// 8 pixels at a time (slot = thread >> 5), 4 loads in flight per thread.  The one-thread-per-channel kernel above moves 2
+// bytes per lane and instruction and keeps 4 x 128 bytes per wave in flight: 1.0 ms for 1.64 GB at 2048 ROIs (1.6 TB/s,
+// latency bound); this one is bound by HBM.  Per-channel sums: registers per (slot, channel), LDS atomics across the 8
+// slots, then the same global atomics per workgroup as before.
+template <typename T, int CP>
+__global__ __launch_bounds__(256) void mask_out_bwd_h16_v8_kernel(const float* __restrict__ dmask, const float* __restrict__ mask,
+                                                                  const T* __restrict__ up, const float* __restrict__ wm, T* dzg,
+                                                                  float* dWm, float* dbm, float* dbd, long long npix, int H, int W,
+                                                                  int C, float lscale) {
+    typedef T t8 __attribute__((ext_vector_type(8)));
+    constexpr int PPB = 512, Cd = 256;
+    __shared__ __attribute__((aligned(16))) float sdz[PPB * CP];
+    __shared__ float ssum[Cd * (CP + 1)];
+    const int tid = threadIdx.x, cg = tid & 31, slot = tid >> 5;
+    const long long p0 = (long long)blockIdx.x * PPB;
+    const int np = (int)((npix - p0) < PPB ? (npix - p0) : PPB);
+    for (int i = tid; i < PPB * CP; i += 256) {
+        const int pl = i / CP, c = i - pl * CP;
+        float v = 0.f;
+        if (pl < np && c < C) {
+            const float g = dmask[(p0 + pl) * C + c], q = mask[(p0 + pl) * C + c];
+            v = g * q * (1.f - q);
+        }
+        sdz[i] = v;
+    }
+    for (int i = tid; i < Cd * (CP + 1); i += 256) ssum[i] = 0.f;
+    float wrow[8][CP], aw[8][CP], abd[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        abd[e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CP; ++c) { wrow[e][c] = c < C ? wm[(long long)(cg * 8 + e) * C + c] : 0.f; aw[e][c] = 0.f; }
+    }
+    __syncthreads();
+    const int hw = H * W, W2 = W >> 1, H2 = H >> 1;
+    const T* upp = up + p0 * Cd + cg * 8;
+#pragma unroll 4
+    for (int pl = slot; pl < np; pl += 8) {
+        const t8 u = *(const t8*)(upp + (long long)pl * Cd);
+        float z[CP];
+#pragma unroll
+        for (int c4 = 0; c4 < CP; c4 += 4) {
+            const f32x4 zz = *(const f32x4*)&sdz[pl * CP + c4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[c4 + e] = zz[e];
+        }
+        t8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float uf = (float)u[e];
+            float d = 0.f;
+#pragma unroll
+            for (int c = 0; c < CP; ++c) { d += z[c] * wrow[e][c]; aw[e][c] += uf * z[c]; }
+            const float dzu = uf > 0.f ? d : 0.f;
+            abd[e] += dzu;
+            o[e] = (T)(dzu * lscale);
+        }
+        const long long pix = p0 + pl;
+        const long long n = pix / hw;
+        const int rem = (int)(pix - n * hw);
+        const int y = rem / W, x = rem - y * W;
+        *(t8*)(dzg + (((n * H2 + (y >> 1)) * W2 + (x >> 1)) * 4 + ((y & 1) * 2 + (x & 1))) * Cd + cg * 8) = o;
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c) atomicAdd(&ssum[(cg * 8 + e) * (CP + 1) + c], aw[e][c]);
+        atomicAdd(&ssum[(cg * 8 + e) * (CP + 1) + CP], abd[e]);
+    }
+    __syncthreads();
+    {
+        const int ci = tid;                                     // 256 threads = 256 channels
+#pragma unroll
+        for (int c = 0; c < CP; ++c)
+            if (c < C) atomicAdd(&dWm[(long long)ci * C + c], ssum[ci * (CP + 1) + c]);
+        atomicAdd(&dbd[ci], ssum[ci * (CP + 1) + CP]);
+        if (ci < C) {
+            float s_ = 0.f;
+            for (int pl = 0; pl < np; ++pl) s_ += sdz[pl * CP + ci];
+            atomicAdd(&dbm[ci], s_);
+        }
     }
 }
 
@@ -1714,8 +1817,10 @@ extern "C" int mrcnn_conv2d_fwd_h16_res(const mrcnn_conv_desc* d, int dtype, con
     // where the tiles are whole rounds; measured shader clock under it: 1.96 GHz, tools/h16p_trace.py).
     bool big = false;
     if (tile && !strcmp(tile, "big")) big = d->Cout % 256 == 0;
-    const bool phased_ok = d->Cout % 256 == 0 && d->Cout <= 512 && d->Cin % 64 == 0 && a.dense && d->KH * d->KW <= 31 && !res &&
-                           (d->act == MRCNN_ACT_NONE || d->act == MRCNN_ACT_RELU) && M * d->Cout * 2 < 0xFFFFFFF0LL;
+    // the transposed convolution's pixel-shuffle store (MRCNN_OUT_DECONV2) is the same kernel with another row address
+    const bool deconv_p = d->out_mode == MRCNN_OUT_DECONV2 && d->cmod % 64 == 0 && d->cmod <= 512 && d->Cout == 4 * d->cmod && !z_out;
+    const bool phased_ok = d->Cout % 256 == 0 && (deconv_p || (d->Cout <= 512 && a.dense)) && d->Cin % 64 == 0 && d->KH * d->KW <= 31 &&
+                           !res && (d->act == MRCNN_ACT_NONE || d->act == MRCNN_ACT_RELU) && M * d->Cout * 2 < 0xFFFFFFF0LL;
     // phase: persistent 256 x 256 tiles (see conv_fwd_h16p_kernel), the default where a shape has at least one full round of
     // them; a last partial round of at most half the CUs goes to the small-tile kernel instead (a 256-row tile costs a full
     // tile time however few there are; 64-row tiles spread the same rows over the whole chip)
@@ -1725,16 +1830,19 @@ extern "C" int mrcnn_conv2d_fwd_h16_res(const mrcnn_conv_desc* d, int dtype, con
         const int ntn = d->Cout / 256;
         long long own = big_tiles;
         const long long full = big_tiles / cus * cus / ntn * ntn;
-        if (full > 0 && big_tiles - full > 0 && (big_tiles - full) * 2 <= cus && !getenv("MRCNN_H16P_NO_SPLIT")) own = full;
+        if (full > 0 && big_tiles - full > 0 && (big_tiles - full) * 2 <= cus && !getenv("MRCNN_H16P_NO_SPLIT") && !deconv_p) own = full;
         a.ptiles = (int)own;
         unsigned blocks = (unsigned)std::min<long long>(own, cus);   // one workgroup per CU (LDS)
         if (const char* g = getenv("MRCNN_H16P_GRID")) blocks = (unsigned)std::min<long long>(own, atoi(g));   // experiments
-        if (dtype == MRCNN_DTYPE_F16) {
-            if (z_out) hipLaunchKernelGGL((conv_fwd_h16p_kernel<_Float16, true>), dim3(blocks), dim3(512), 0, s, a);
-            else hipLaunchKernelGGL((conv_fwd_h16p_kernel<_Float16, false>), dim3(blocks), dim3(512), 0, s, a);
+        if (deconv_p) {
+            if (dtype == MRCNN_DTYPE_F16) hipLaunchKernelGGL((conv_fwd_h16p_kernel<_Float16, false, true>), dim3(blocks), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((conv_fwd_h16p_kernel<__bf16, false, true>), dim3(blocks), dim3(512), 0, s, a);
+        } else if (dtype == MRCNN_DTYPE_F16) {
+            if (z_out) hipLaunchKernelGGL((conv_fwd_h16p_kernel<_Float16, true, false>), dim3(blocks), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((conv_fwd_h16p_kernel<_Float16, false, false>), dim3(blocks), dim3(512), 0, s, a);
         } else {
-            if (z_out) hipLaunchKernelGGL((conv_fwd_h16p_kernel<__bf16, true>), dim3(blocks), dim3(512), 0, s, a);
-            else hipLaunchKernelGGL((conv_fwd_h16p_kernel<__bf16, false>), dim3(blocks), dim3(512), 0, s, a);
+            if (z_out) hipLaunchKernelGGL((conv_fwd_h16p_kernel<__bf16, true, false>), dim3(blocks), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL((conv_fwd_h16p_kernel<__bf16, false, false>), dim3(blocks), dim3(512), 0, s, a);
         }
         if (own < big_tiles) {
             const long long mdone = own / ntn * 256;
@@ -1806,6 +1914,12 @@ template <typename T>
 static void launch_mask_out_bwd_h16(const float* dm, const float* m, const void* up, const float* wm, void* dzg, float* dw, float* dbm,
                                     float* dbd, long long npix, int H, int W, int Cd, int C, float ls, hipStream_t s) {
     const dim3 grid((unsigned)cdiv64(npix, 512)), block(Cd);
+    static const int v8 = getenv("MRCNN_MASK_OUT_BWD_V8") ? atoi(getenv("MRCNN_MASK_OUT_BWD_V8")) : 1;
+    if (v8 && Cd == 256 && C <= 4 && ((reinterpret_cast<uintptr_t>(up) | reinterpret_cast<uintptr_t>(dzg)) & 15) == 0) {
+        hipLaunchKernelGGL((mask_out_bwd_h16_v8_kernel<T, 4>), grid, dim3(256), 0, s, dm, m, (const T*)up, wm, (T*)dzg, dw, dbm, dbd, npix,
+                           H, W, C, ls);
+        return;
+    }
     if (C <= 4)
         hipLaunchKernelGGL((mask_out_bwd_h16_kernel<T, 4>), grid, block, 0, s, dm, m, (const T*)up, wm, (T*)dzg, dw, dbm, dbd, npix, H, W, Cd, C, ls);
     else if (C <= 8)

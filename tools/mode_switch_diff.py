@@ -42,3 +42,5 @@ def window(seg, title):
             print("  q%s %8.3f .. %8.3f  (%7.1f us)  %-50s %d" % (qu, (s - a[0]) / 1e6, (e - a[0]) / 1e6, (e - s) / 1e3, n[:50], wgs))
 if fast and slow:
     window(fast[len(fast) // 2], "FAST step"); window(slow[len(slow) // 2], "SLOW step")
+elif len(sys.argv) > 2 and sys.argv[2] == "window":                # no mode switch in the trace: the window of a middle step
+    window(steps[len(steps) // 2][1], "step %d" % (len(steps) // 2))
