@@ -419,7 +419,8 @@ def _roofline_leg(res, ops, torch, dev, nimg, cfg):
     w_ach = flops / (w_ms * 1e-3) / 1e12
     # what the step gets: in the backward pass a layer's data gradient (main stream) and weight gradient (side stream) run
     # side by side; the pair's sustained rate is the in-step figure for both kernels
-    side = torch.cuda.Stream(device=dev)
+    from caesar_mrcnn_amd.engine import _side_streams
+    side = _side_streams(dev)[0]                        # the engines' weight-gradient stream (one per process)
     main = torch.cuda.current_stream(dev)
 
     def pair():
@@ -470,8 +471,11 @@ def measure_config4(args, rank, local_rank, world):
         for _ in range(nsteps):
             losses = eng.forward_backward(*dev_inputs)
             eng.apply_gradients(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM, 1)
+        host_issue.append((time.time() - t0) / nsteps)          # launches issued; the device may still be running
         torch.cuda.synchronize()
         return (time.time() - t0) / nsteps, losses
+
+    host_issue = []
 
     out = {"workload": "BASELINE.json configs[4]: resnet101+FPN 512x512, nimg_per_gpu=4, train step, 16-bit weights/activations "
                        "on the 16-bit MFMA where built (mask head, FPN smoothing, shared RPN conv, class FCs, identity blocks of "
@@ -484,6 +488,7 @@ def measure_config4(args, rank, local_rank, world):
         t, losses = timed(steps)
         out["value_" + tag] = round(nimg / t, 3)
         out["ms_per_step_" + tag] = round(t * 1e3, 3)
+        out["host_issue_ms_per_step_" + tag] = round(host_issue[-1] * 1e3, 3)
         out["losses_" + tag] = [round(float(v), 5) for v in losses.cpu().numpy()]
     out["skipped_steps_f16"] = eng.skipped_step_count()      # guarded optimiser: steps with non-finite float16 gradients
     eng.sparse_mask_bwd, eng.head_dtype = True, None
