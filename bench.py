@@ -445,8 +445,10 @@ def measure_config4(args, rank, local_rank, world):
     """BASELINE.json configs[4]: ResNet-101 with 16-bit weight images / activations on the 16-bit matrix cores, 512 x 512
     tiles, 4 images per GPU.  Mixed precision as built so far: mask head, FPN smoothing, shared RPN
     convolution, class-head FC layers and the identity bottleneck blocks of res4 / res5 in 16 bits (forward, data and
-    weight gradient); stem, res2, res3, the first block of each stage, laterals and the small output layers float32;
-    float32 master weights, accumulation, gradients; loss scale 4096 for float16.  Own object, never the headline."""
+    weight gradient); every bottleneck block's convolutions in 16 bits (res2 / res3 weight gradients widened to float32 on the
+    side stream); stem, laterals and the small output layers float32; float32 master weights, accumulation, gradients; loss
+    scale 4096 for float16 with the guarded optimiser step (non-finite gradients skip the update).  Own object, never the
+    headline."""
     import contextlib
     import torch
     import torch.distributed as dist
@@ -478,8 +480,9 @@ def measure_config4(args, rank, local_rank, world):
     host_issue = []
 
     out = {"workload": "BASELINE.json configs[4]: resnet101+FPN 512x512, nimg_per_gpu=4, train step, 16-bit weights/activations "
-                       "on the 16-bit MFMA where built (mask head, FPN smoothing, shared RPN conv, class FCs, identity blocks of "
-                       "res4/res5), float32 elsewhere; float32 master weights and gradients, loss scale 4096 (f16)",
+                       "on the 16-bit MFMA where built (mask head, FPN smoothing, shared RPN conv, class FCs, every bottleneck "
+                       "block), float32 elsewhere (stem, laterals, small output layers); float32 master weights and gradients, "
+                       "loss scale 4096 + guarded optimiser step (f16)",
            "unit": "images/s"}
     steps = max(5, args.steps // 2)
     for tag, sparse, dt in (("f32", False, None), ("f16", False, torch.float16), ("bf16", False, torch.bfloat16),
@@ -529,8 +532,8 @@ def measure_config4(args, rank, local_rank, world):
         ach = flops / (k_ms * 1e-3) / 1e12
         out["roofline_wgrad_" + tag] = {"bound": "mfma", "achieved": round(ach, 1), "peak": 2500.0, "unit": "TFLOP/s",
                                         "frac": round(ach / 2500.0, 4), "traffic": None,
-                                        "kernel": "conv_wgrad_h16_kernel<%s> + pixel table + slab reduction (same layer, %.3f "
-                                                  "ms/launch)" % (tag, k_ms)}
+                                        "kernel": "conv_wgrad_h16p_kernel<%s> (256x256 tile per pixel split, two staggered wave "
+                                                  "groups) + slab reduction (same layer, %.3f ms/launch)" % (tag, k_ms)}
         del xm, om, dym
     return out
 

@@ -1382,7 +1382,7 @@ static void h16_magic(unsigned d, unsigned* mg, unsigned* sh);
 
 struct WgradH16PArgs {
     const void* x; const void* dy; float* out;
-    int H, W, Cin, Cout, KW, pad_t, pad_l, M, Ktot, chunk, nk, itiles, ntiles, ohw;
+    int H, W, Cin, Cout, KW, pad_t, pad_l, M, Ktot, chunk, nk, itiles, ntiles, ohw, xcd_order;
     unsigned x_shift, x_records, mg_ohw, sh_ohw, mg_ow, sh_ow;
 };
 
@@ -1405,7 +1405,10 @@ __global__ __launch_bounds__(512) void conv_wgrad_h16p_kernel(const WgradH16PArg
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    int bid = blockIdx.x;
+    // the (tap, channel-tile) workgroups of one pixel split read the same dY rows and -- shifted by a tap -- the same X rows:
+    // logical ids that are neighbours share an XCD and with it an L2 (PMC before: FETCH_SIZE 3.2 GB per launch on the
+    // mask-head layer, 7.7 x the algorithmic bytes at ~7 TB/s -- the kernel was fabric-bound)
+    int bid = p.xcd_order ? (int)mrcnn_xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x;
     const int ntile = bid % p.ntiles; bid /= p.ntiles;
     const int itile = bid % p.itiles;
     const int split = bid / p.itiles;
@@ -1679,6 +1682,7 @@ extern "C" int mrcnn_conv2d_wgrad_h16(const mrcnn_conv_desc* d, int dtype, const
         b.H = d->H; b.W = d->W; b.Cin = d->Cin; b.Cout = d->Cout; b.KW = d->KW; b.pad_t = d->pad_t; b.pad_l = d->pad_l;
         b.M = (int)M; b.Ktot = d->KH * d->KW * d->Cin; b.chunk = pp.chunk; b.nk = pp.nk; b.itiles = pp.itiles; b.ntiles = pp.ntiles;
         b.ohw = d->OH * d->OW;
+        { const char* xe = getenv("MRCNN_WGRAD_XCD"); b.xcd_order = xe ? atoi(xe) : 1; }
         b.x_shift = (unsigned)shift_b; b.x_records = (unsigned)(xbytes + shift_b);
         h16_magic((unsigned)(d->OH * d->OW), &b.mg_ohw, &b.sh_ohw);
         h16_magic((unsigned)d->OW, &b.mg_ow, &b.sh_ow);
