@@ -21,6 +21,8 @@ struct ConvArgs {
     FastDiv d_ohw, d_ow;               // exact division of output-pixel indices (non-dense stores: deconv, concat, UP2)
     FastDiv d_c4;                      // Cout / 4 (vector split-K epilogue)
     float* slab; int ksplit, ksteps;   // split-K: partial sums [ksplit][M][Cout], K-steps per split
+    int mtile0;                        // LDS-DMA split-K kernel as the TAIL launch of a large layer: first 128-row tile it owns; slab rows
+                                       // are relative to it ([ksplit][M - 128 mtile0][Cout])
     // fused backward epilogue (mrcnn_conv2d_dgrad_ep, LDS-DMA kernel only): the result y is the gradient w.r.t. the
     // activated output of the layer below; that layer's epilogue backward is applied before the store
     const float* fb_out; const float* fb_z; const float* fb_scale; const float* fb_mean; const float* fb_rstd;
@@ -483,10 +485,11 @@ __device__ __forceinline__ void conv_fwd_blds_body(const ConvArgs& p, const unsi
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int ntiles = p.Cout / BN;
-    const int tiles = ((p.M + BM - 1) / BM) * ntiles;
+    const int mt0 = SPLIT ? p.mtile0 : 0;                               // tail launch of a large layer: first tile it owns
+    const int tiles = ((p.M + BM - 1) / BM - mt0) * ntiles;
     const int kz = SPLIT ? (int)blockIdx.x / tiles : 0;                 // split-K slice (mid-size layers)
     const int tile = (int)blockIdx.x - kz * tiles;
-    const int mtile = tile / ntiles, ntile = tile % ntiles;
+    const int mtile = tile / ntiles + mt0, ntile = tile % ntiles;
     const int m0 = mtile * BM, n0 = ntile * BN;
     const int ohw = p.OH * p.OW;
 
@@ -602,12 +605,13 @@ __device__ __forceinline__ void conv_fwd_blds_body(const ConvArgs& p, const unsi
     }
     const int mw0 = m0 + wm * 64 + 4 * lh, nw0 = n0 + wn * 64 + li;
     if constexpr (SPLIT) {                                      // partial sums -> slab kz; the reduction kernel applies the epilogue
-        float* slab = p.slab + (long long)kz * p.M * p.Cout;
+        const int mrel0 = mt0 * BM;                               // slab rows are relative to the launch's first tile
+        float* slab = p.slab + (long long)kz * (p.M - mrel0) * p.Cout;
         auto put = [&](const f32x16& c, int mbase, int n) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mbase + (r & 3) + 8 * (r >> 2);
-                if (m < p.M) slab[(long long)m * p.Cout + n] = c[r];
+                if (m < p.M) slab[(long long)(m - mrel0) * p.Cout + n] = c[r];
             }
         };
         put(acc[0][0], mw0, nw0);
@@ -1147,10 +1151,57 @@ static ConvPlan plan_conv(const mrcnn_conv_desc* d, bool allow_dma_split = true)
     return pl;
 }
 
+// Tail of a large LDS-DMA layer.  The unsplit kernel keeps 5 workgroups per CU resident; a grid of r.f rounds costs
+// ceil(r.f) rounds (M = 200 704, Cout = 256: 3136 tiles on 1280 slots = 2.45 rounds -> 3, 76 % of the 128-row kernel's rate).
+// When the last round would be at most 60 % full, the whole rounds go to the unsplit kernel and the remaining tiles to the
+// split-K variant with K cut so that they fill one round of shorter workgroups; their slabs (rows relative to the first
+// tail tile) are reduced by the usual second launch on the tail rows.
+struct ConvTailPlan { int ok, mt_full, ksplit, ksteps; size_t slab_bytes; };
+
+static ConvTailPlan plan_conv_tail(const mrcnn_conv_desc* d) {
+    ConvTailPlan t = {0, 0, 0, 0, 0};
+    // OFF by default (MRCNN_CONV_TAIL_SPLIT=1 turns it on, read per call).  Measured on M = 200 704, Cout = 256, K = 2304:
+    // alone 1.88 -> 1.82 ms (79.9 -> 82.9 % of the matrix peak) for the forward, nothing for the data gradient with the fused
+    // backward epilogue; INSIDE the ResNet-50 step 30.99 -> 31.35 ms -- there the weight-gradient stream already fills the
+    // slots of the partial round, and the two extra launches only cost.
+    const char* env = getenv("MRCNN_CONV_TAIL_SPLIT");
+    const int enabled = env ? atoi(env) : 0;
+    const long long M = (long long)d->N * d->OH * d->OW;
+    if (!enabled || d->Cout % 128 || d->Cin % 16) return t;
+    const long long mt = (M + 127) / 128, nt = d->Cout / 128, tiles = mt * nt;
+    const long long slots = 5LL * mrcnn_num_cus();
+    const long long full = tiles / slots * slots / nt * nt, tail = tiles - full;
+    const int nk = d->KH * d->KW * d->Cin / 16;
+    if (full <= 0 || tail <= 0 || tail * 10 > slots * 6 || nk < 32) return t;
+    // K slices: the split variant keeps 4 workgroups per CU (123 VGPRs); tail * ks workgroups of 1 / ks length cost
+    // ceil(tail * ks / slots4) / ks rounds, every slice adds one slab of the tail rows to write and read back (~4.5 TB/s,
+    // against ~4.4 us per K-step of a workgroup at full occupancy).  Slices start on a channel-chunk boundary (tap 0).
+    const long long slots4 = 4LL * mrcnn_num_cus();
+    const int taps = d->KH * d->KW;
+    const double slab_cost = (double)(M - full / nt * 128) * d->Cout * 8.0 / 4.5e12 / (nk * 4.4e-6);
+    double best = 1.0;                                          // the unsplit tail: one more round of the unsplit kernel
+    long long ks = 1, steps = nk;
+    for (long long k = 2; k <= 8; ++k) {
+        long long st = (nk + k - 1) / k;
+        st = (st + taps - 1) / taps * taps;
+        const long long kk = (nk + st - 1) / st;
+        if (kk < 2) continue;
+        const double cost = (double)((tail * kk + slots4 - 1) / slots4) * st / nk + slab_cost * kk;
+        if (cost < best - 0.05) { best = cost; ks = kk; steps = st; }
+    }
+    if (ks < 2) return t;
+    t.ok = 1; t.mt_full = (int)(full / nt); t.ksplit = (int)ks; t.ksteps = (int)steps;
+    t.slab_bytes = (size_t)ks * (size_t)(M - (long long)t.mt_full * 128) * d->Cout * sizeof(float);
+    return t;
+}
+
 extern "C" size_t mrcnn_conv2d_fwd_workspace(const mrcnn_conv_desc* d) {
     if (!d || d->N <= 0 || d->OH <= 0 || d->OW <= 0 || d->Cout <= 0 || d->KH <= 0 || d->KW <= 0 || d->Cin <= 0) return 0;
     ConvPlan pl = plan_conv(d);
-    if (pl.ksplit <= 1) return 0;
+    if (pl.ksplit <= 1) {
+        if (pl.bm == 128 && pl.bn == 128) return plan_conv_tail(d).slab_bytes;     // 0 unless the tail split applies
+        return 0;
+    }
     return (size_t)pl.ksplit * d->N * d->OH * d->OW * d->Cout * sizeof(float);
 }
 
@@ -1184,7 +1235,7 @@ static int conv_fill_args(const mrcnn_conv_desc* d, const float* x, const float*
     a.vecB = (d->Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
     a.dense = d->out_mode == MRCNN_OUT_NHWC && d->out_w_stride == d->Cout &&
               d->out_h_stride == (int64_t)d->OW * d->Cout && d->out_n_stride == (int64_t)d->OH * d->OW * d->Cout;
-    a.ksplit = 1; a.ksteps = a.nk; a.slab = nullptr;
+    a.ksplit = 1; a.ksteps = a.nk; a.slab = nullptr; a.mtile0 = 0;
     a.fb_act = -1;
     a.fb_out = a.fb_z = a.fb_scale = a.fb_mean = a.fb_rstd = nullptr;
     a.fb_dgamma = a.fb_dbeta = a.fb_dbias = nullptr;
@@ -1258,10 +1309,38 @@ static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* 
         const long long xbytes = (long long)d->N * d->H * d->W * d->Cin * 4;
         const long long shift = ((long long)d->pad_t * d->W + d->pad_l) * d->Cin * 4;
         const long long wbytes = (long long)a.Ktot * d->Cout * 4;
-        if (xbytes + shift < 0x7FFFFFF0LL && wbytes < 0x7FFFFFF0LL && !mrcnn_force_flat_glds())
-            hipLaunchKernelGGL(conv_fwd_blds_kernel, dim3((unsigned)(mt * nt)), dim3(256), 0, s, a, (unsigned)shift,
+        if (xbytes + shift < 0x7FFFFFF0LL && wbytes < 0x7FFFFFF0LL && !mrcnn_force_flat_glds()) {
+            const ConvTailPlan tp = plan_conv_tail(d);
+            auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+            const bool pow2c = d->Cout >= 16 && (d->Cout & (d->Cout - 1)) == 0;
+            const bool tail_ok = tp.ok && a.dense && d->res_mode != MRCNN_RES_UP2 && d->out_mode == MRCNN_OUT_NHWC && workspace &&
+                                 workspace_bytes >= tp.slab_bytes && al(workspace) &&
+                                 (a.fb_act < 0 || (pow2c && !ep->dy && al(out) && al(res) && al(ep->out) && al(ep->z) && al(ep->scale) &&
+                                                   al(ep->mean) && al(ep->rstd)));
+            if (!tail_ok) {
+                hipLaunchKernelGGL(conv_fwd_blds_kernel, dim3((unsigned)(mt * nt)), dim3(256), 0, s, a, (unsigned)shift,
+                                   (unsigned)(xbytes + shift));
+                return mrcnn_launch_status();
+            }
+            // whole rounds: unsplit kernel with its fused epilogue; tail tiles: K slices + slab reduction on the tail rows
+            hipLaunchKernelGGL(conv_fwd_blds_kernel, dim3((unsigned)(tp.mt_full * nt)), dim3(256), 0, s, a, (unsigned)shift,
                                (unsigned)(xbytes + shift));
-        else
+            ConvArgs t = a;
+            t.mtile0 = tp.mt_full; t.ksplit = tp.ksplit; t.ksteps = tp.ksteps; t.slab = (float*)workspace;
+            hipLaunchKernelGGL(conv_fwd_blds_splitk_kernel, dim3((unsigned)((mt - tp.mt_full) * nt * tp.ksplit)), dim3(256), 0, s, t,
+                               (unsigned)shift, (unsigned)(xbytes + shift));
+            const long long m1 = (long long)tp.mt_full * 128, off = m1 * d->Cout;
+            ConvArgs r = t;                       // the reduction sees the tail rows as a problem of its own (dense NHWC)
+            r.M = (int)(a.M - m1); r.mtile0 = 0;
+            r.out = a.out + off;
+            if (a.z) r.z = a.z + off;
+            if (a.res) r.res = a.res + off;
+            if (a.fb_act >= 0) {
+                if (a.fb_out) r.fb_out = a.fb_out + off;
+                if (a.fb_z) r.fb_z = a.fb_z + off;
+            }
+            launch_splitk_reduction(r, s);
+        } else
             hipLaunchKernelGGL(conv_fwd_glds_kernel, dim3((unsigned)(mt * nt)), dim3(256), 0, s, a);
         return mrcnn_launch_status();
     }

@@ -48,11 +48,21 @@ CONV_CASES = [
     (64, 14, 14, 256, 256, 3, 1, "same", 1, True, 1),    # LDS-DMA 128x128 kernel: padded taps, residual
     (90, 13, 11, 128, 256, 3, 1, "same", 1, False, 0),   # LDS-DMA kernel, ragged M (12870 = 100 x 128 + 70), odd H/W
     (3, 64, 64, 256, 128, 1, 1, "valid", 0, False, 0),   # LDS-DMA kernel, 1x1, one N tile
+    (457, 14, 14, 64, 256, 3, 1, "same", 1, True, 1),    # LDS-DMA kernel with the TAIL SPLIT: 700 x 2 tiles = 1.09 rounds of 1280 slots ->
+                                                         # 640 row tiles unsplit, 60 (ragged M = 89572) as 4 K slices + slab reduction; BN, residual, z
 ]
 
 
+@pytest.fixture
+def tail_split_env():
+    """MRCNN_CONV_TAIL_SPLIT is read per call (default off: measured slower inside the step); on for the shapes that test it."""
+    os.environ["MRCNN_CONV_TAIL_SPLIT"] = "1"
+    yield
+    del os.environ["MRCNN_CONV_TAIL_SPLIT"]
+
+
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_fwd(dev, case):
+def test_conv_fwd(dev, case, tail_split_env):
     ops = _ops()
     N, H, W, Cin, Cout, k, stride, padding, act, bn, res = case
     rng = np.random.default_rng(1000 + sum(int(v) if isinstance(v, int) else 7 for v in case))
@@ -777,7 +787,7 @@ def test_conv_dgrad_fused_with_epilogue_backward_splitk(dev):
 
 
 @pytest.mark.parametrize("k,res", [(3, False), (1, True)])
-def test_conv_dgrad_fused_with_epilogue_backward(dev, k, res):
+def test_conv_dgrad_fused_with_epilogue_backward(dev, k, res, tail_split_env):
     """mrcnn_conv2d_dgrad_ep == mrcnn_conv2d_fwd followed by mrcnn_epilogue_bwd (both checked against the oracle above):
     identical dz, channel sums equal up to the order of the float32 atomics; small layers report 'unsupported'."""
     ops = _ops()
