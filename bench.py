@@ -174,7 +174,7 @@ def _train_loop_leg(args, res, model, cfg, nimg, world, rank):
             wait += time.time() - t1
             used = np.flatnonzero(np.any(inputs[4] != 0, axis=0))
             n_used = int(used[-1]) + 1 if used.size else 0
-            h2d += inputs[0].nbytes + inputs[6][..., :n_used].size + inputs[4].nbytes + inputs[5].nbytes + 4 * inputs[5].size
+            h2d += inputs[0].nbytes + inputs[6][..., :(n_used + 7) // 8].size + inputs[4].nbytes + inputs[5].nbytes + 4 * inputs[5].size
             model.train_on_batch(inputs)
         torch.cuda.synchronize()
         dt = time.time() - t0
@@ -189,8 +189,8 @@ def _train_loop_leg(args, res, model, cfg, nimg, world, rank):
         eng.sparse_mask_bwd = True
     res["train_loop"] = dict(dense, steps=steps, loader_threads=nw, exact_zero_skip=sparse,
         what="MaskRCNN.train()'s own iteration: Prefetcher threads over data_generator on 32 synthetic FITS tiles "
-             "(read_fits + zscale + uint8 RGB + resize + extract_bboxes), per-step H2D of images and used GT-mask planes "
-             "(uint8), RPN targets built on the device; dense mask head like `value`, and the product-default step under "
+             "(read_fits + zscale + uint8 RGB + resize + extract_bboxes), per-step H2D of images and the used GT-mask planes, "
+             "bit-packed (8 instances per byte), RPN targets built on the device; dense mask head like `value`, and the product-default step under "
              "exact_zero_skip; feed-inclusive, never `value`")
 
 

@@ -487,6 +487,29 @@ extern "C" int mrcnn_copy2d(void* dst, size_t dst_pitch, const void* src, size_t
     return e == hipSuccess ? MRCNN_OK : MRCNN_ERR_LAUNCH;
 }
 
+// GT instance masks cross PCIe bit-packed (mrcnn/model.py:1721-1904 feeds [B, H, W, MAX_GT_INSTANCES] bool per batch): byte
+// b of a pixel carries instances 8b .. 8b + 7, least significant bit first (numpy.packbits(..., bitorder="little") along the
+// instance axis).  Unpacked here to the uint8 planes the target kernels read; instances >= n_used (the padding up to G) are
+// written as zeros, so the host never uploads them.
+__global__ __launch_bounds__(256) void unpack_mask_bits_kernel(const unsigned char* __restrict__ packed, unsigned char* out,
+                                                               long long npix, int nbytes, int n_used, int G) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix * G) return;
+    const long long pix = i / G;
+    const int g = (int)(i - pix * G);
+    out[i] = g < n_used ? (unsigned char)((packed[pix * nbytes + (g >> 3)] >> (g & 7)) & 1u) : (unsigned char)0;
+}
+
+extern "C" int mrcnn_unpack_mask_bits(const void* packed, void* out, int64_t npix, int nbytes_per_pixel, int n_used, int G,
+                                      void* stream) {
+    if (!out || npix <= 0 || G <= 0 || n_used < 0 || n_used > G || nbytes_per_pixel < (n_used + 7) / 8 || (n_used > 0 && !packed))
+        return MRCNN_ERR_ARG;
+    const long long total = (long long)npix * G;
+    hipLaunchKernelGGL(unpack_mask_bits_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned char*)packed, (unsigned char*)out, (long long)npix, nbytes_per_pixel, n_used, G);
+    return mrcnn_launch_status();
+}
+
 extern "C" int mrcnn_fill_zero(void* dst, size_t bytes, void* stream) {
     if (!dst || bytes == 0) return MRCNN_ERR_ARG;
     if (((reinterpret_cast<uintptr_t>(dst) | bytes) & 15) == 0) {

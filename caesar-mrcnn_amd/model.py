@@ -193,8 +193,8 @@ class MaskRCNN(object):
     def _to_device(self, inputs, rand_keys=None, rpn_keys=None):
         """Generator batch -> device tensors of engine.forward_backward.  With rpn_match / rpn_bbox None the RPN
         targets are built on the GPU from the GT boxes (``rpn_keys`` [B, A] uniform floats, drawn here when not
-        given).  Only the GT-mask planes of real instances cross PCIe; the MAX_GT_INSTANCES padding is written
-        on the device."""
+        given).  Only the GT-mask planes of real instances cross PCIe, bit-packed (8 instances per byte); the unpacking and
+        the MAX_GT_INSTANCES padding are written on the device."""
         import torch
         from . import ops
         dev = self.engine.dev
@@ -223,12 +223,16 @@ class MaskRCNN(object):
         G = gt_masks.shape[-1]
         used = np.flatnonzero(np.any(np.asarray(gt_class_ids) != 0, axis=0))
         n_used = int(used[-1]) + 1 if used.size else 0
-        if n_used < G and not gt_masks[..., n_used:].any():
-            masks_d = torch.zeros(gt_masks.shape, dtype=torch.uint8, device=dev)
-            if n_used:
-                masks_d[..., :n_used] = t(gt_masks[..., :n_used], np.uint8)
+        if n_used < G and gt_masks[..., n_used:].any():
+            n_used = G                                                    # masks without a class id: upload them all
+        # bit-packed across PCIe (8 instances per byte), unpacked on the device; the padding planes are written there
+        self.last_mask_h2d_bytes = 0
+        if n_used:
+            packed = np.packbits(np.asarray(gt_masks[..., :n_used]) != 0, axis=-1, bitorder="little")
+            self.last_mask_h2d_bytes = packed.nbytes
+            masks_d = ops.unpack_mask_bits(t(packed, np.uint8), n_used, G)
         else:
-            masks_d = t(gt_masks, np.uint8)
+            masks_d = torch.zeros(gt_masks.shape, dtype=torch.uint8, device=dev)
         return (t(images, np.float32), rpn_match_d, rpn_bbox_d, cls_d, t(gtn, np.float32), masks_d,
                 t(active, np.int32), t(rand_keys, np.float32))
 

@@ -611,6 +611,20 @@ def copy2d(dst_ptr, dst_pitch, src_ptr, src_pitch, row_bytes, rows):
           "mrcnn_copy2d")
 
 
+def unpack_mask_bits(packed, n_used, G):
+    """packed [..., ceil(n_used / 8)] uint8 (numpy.packbits along the instance axis, bitorder="little") -> [..., G] uint8 planes,
+    zeros from n_used on."""
+    _need_cuda(packed)
+    lead = tuple(packed.shape[:-1])
+    out = torch.empty(lead + (G,), dtype=torch.uint8, device=packed.device)
+    npix = 1
+    for v in lead:
+        npix *= v
+    check(_hip.lib().mrcnn_unpack_mask_bits(ptr(packed), ptr(out), npix, packed.shape[-1], n_used, G, current_stream()),
+          "mrcnn_unpack_mask_bits")
+    return out
+
+
 def fill_zero(t):
     _need_cuda(t)
     check(_hip.lib().mrcnn_fill_zero(ptr(t), t.numel() * t.element_size(), current_stream()), "mrcnn_fill_zero")

@@ -180,6 +180,10 @@ int mrcnn_mask_out_bwd(const float* d_mask_out, const float* mask_out, const flo
 int mrcnn_copy2d(void* dst, size_t dst_pitch, const void* src, size_t src_pitch, size_t row_bytes,
                  size_t rows, void* stream);
 int mrcnn_fill_zero(void* dst, size_t bytes, void* stream);
+/* GT instance masks of a batch (mrcnn/model.py:1721-1904: [B, H, W, MAX_GT_INSTANCES] bool from data_generator) cross PCIe
+ * bit-packed: byte b of a pixel = instances 8b .. 8b+7, least significant bit first.  out [npix, G] uint8 (0 / 1); instances
+ * >= n_used are written as zeros.                                                                                           */
+int mrcnn_unpack_mask_bits(const void* packed, void* out, int64_t npix, int nbytes_per_pixel, int n_used, int G, void* stream);
 
 /* Elementwise helpers on flat buffers. */
 int mrcnn_add_inplace(float* dst, const float* src, int64_t n, void* stream);

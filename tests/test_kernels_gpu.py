@@ -654,6 +654,27 @@ def test_losses(dev, dice):
         torch.testing.assert_close(got.cpu(), ref.grad, rtol=1e-4, atol=1e-7)
 
 
+@pytest.mark.parametrize("n_used,G", [(0, 12), (1, 12), (7, 12), (8, 8), (13, 300), (300, 300)])
+def test_unpack_mask_bits(dev, n_used, G):
+    """mrcnn_unpack_mask_bits: GT instance masks cross PCIe as numpy.packbits(..., bitorder="little") along the instance
+    axis; the device writes the uint8 planes the target kernels read, zeros for the padding instances.  Bit-exact."""
+    ops = _ops()
+    rng = np.random.default_rng(60 + n_used)
+    B, H, W = 2, 9, 7
+    masks = np.zeros((B, H, W, G), np.uint8)
+    masks[..., :n_used] = rng.integers(0, 2, (B, H, W, n_used))
+    if n_used == 0:                                   # nothing to read: all planes are padding
+        got = ops.unpack_mask_bits(torch.zeros((B, H, W, 1), dtype=torch.uint8, device=dev), 0, G)
+        torch.cuda.synchronize()
+        assert tuple(got.shape) == (B, H, W, G) and int(got.sum()) == 0
+        return
+    packed = np.packbits(masks[..., :n_used] != 0, axis=-1, bitorder="little")
+    assert packed.shape[-1] == (n_used + 7) // 8
+    got = ops.unpack_mask_bits(torch.tensor(packed, device=dev), n_used, G)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(got.cpu().numpy(), masks)
+
+
 def test_guarded_sgd_skips_non_finite_steps(dev):
     """Mixed-precision form of the optimiser step (mrcnn_sgd_momentum_guarded): bitwise the plain step while the squared
     gradient norm is finite; with an overflowed float16 gradient (inf / NaN in the buffer -> non-finite norm out of
