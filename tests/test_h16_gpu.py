@@ -94,6 +94,38 @@ def test_conv_fwd_h16(dev, case, dtype, h16_tile):
         assert err <= TOL[dtype], "dgrad: max error %.3g (allowed %.3g)" % (err, TOL[dtype])
 
 
+def test_float16_overflow_skips_the_step_and_lowers_the_loss_scale(dev):
+    """Float16 mode end to end: with an absurd loss scale the 16-bit gradients overflow, the flat gradient buffer's norm is
+    not finite, the guarded optimiser step leaves weights and momentum untouched and counts the step on the device;
+    adapt_loss_scale (what MaskRCNN.train calls once per epoch) halves the scale per skipped step.  With the scale back in
+    range the same batch trains: weights move, nothing is skipped."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_engine_gpu as T
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = T._small_cfg("resnet50", 128)
+    w = T._weights(cfg, 31, damp=0.5)
+    inputs, keys = T._train_inputs(cfg, 2, 33)
+    model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+    model.compile(0.001, 0.9)
+    eng = model.engine
+    eng.head_dtype = torch.float16
+    eng.loss_scale = 2.0 ** 40                                   # every scaled float16 gradient overflows
+    before = eng.params.clone()
+    for _ in range(2):
+        model.train_on_batch(inputs, rand_keys=keys)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.params, before), "a step with non-finite gradients changed the weights"
+    assert bool(torch.isfinite(eng.params).all()) and float(eng.momentum.abs().max()) == 0.0
+    assert eng.skipped_step_count() == 2
+    assert eng.adapt_loss_scale() == 2 and eng.loss_scale == 2.0 ** 38
+    assert eng.adapt_loss_scale() == 0 and eng.loss_scale == 2.0 ** 38
+    eng.loss_scale = 4096.0
+    losses = model.train_on_batch(inputs, rand_keys=keys)
+    torch.cuda.synchronize()
+    assert np.isfinite(losses.cpu().numpy()).all() and eng.skipped_step_count() == 2
+    assert not torch.equal(eng.params, before) and bool(torch.isfinite(eng.params).all())
+
+
 def test_phased_kernels_at_full_size_agree_with_the_reference_kernels(dev):
     """At BASELINE's full mask-head size (2048 ROIs: M = 401 408) and on the one-tile-per-workgroup shape the CPU oracle is too
     slow, so the phased kernels are checked against the independently written 256 x 128 / table-driven kernels (themselves
