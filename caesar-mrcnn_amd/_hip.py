@@ -121,6 +121,7 @@ _SIGNATURES = {
     "mrcnn_mask_out_fwd_h16": (C.c_int, [C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "mrcnn_mask_out_bwd_h16": (C.c_int, [C.c_int] + [_P] * 8 + [C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P]),
     "mrcnn_weights_to_h16": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mrcnn_weights_to_h16_batched": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_cast_to_h16": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "mrcnn_epilogue_bwd_h16": (C.c_int, [C.c_int] + [_P] * 10 + [C.c_int64, C.c_int, C.c_int, C.c_float, _P]),
     "mrcnn_epilogue_bwd_h16_dy": (C.c_int, [C.c_int] + [_P] * 11 + [C.c_int64, C.c_int, C.c_int, C.c_float, _P]),

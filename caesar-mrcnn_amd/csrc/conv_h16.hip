@@ -1947,6 +1947,59 @@ extern "C" int mrcnn_mask_out_bwd_h16(int dtype, const float* d_mask_out, const 
     return mrcnn_launch_status();
 }
 
+// Every 16-bit weight image of the model in ONE launch: table[l] = {offset of the float32 HWIO kernel in the flat parameter
+// buffer (floats), W^T image pointer, data-gradient image pointer (or 0), KH, KW, Cin, Cout, first tile}; a tile is 32 ci x
+// 32 co of one tap, as in weights_to_h16_kernel.  The images are refreshed once per optimiser step; layer by layer that was
+// 77 launches of ~5 us at the head of the ResNet-101 step (knock-out: 0.6 ms of the 19 ms 512 x 512 step).
+struct H16ImageEntry { long long off; unsigned long long wf, wd; int KH, KW, Cin, Cout, first_tile, pad; };
+
+template <typename T>
+__global__ void weights_to_h16_batched_kernel(const float* __restrict__ params, const H16ImageEntry* __restrict__ table, int n) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n - 1;                         // last entry with first_tile <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].first_tile <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const H16ImageEntry e = table[lo];
+    int t = blockIdx.x - e.first_tile;
+    const int cot = (e.Cout + 31) / 32, cit = (e.Cin + 31) / 32;
+    const int co0 = (t % cot) * 32; t /= cot;
+    const int ci0 = (t % cit) * 32;
+    const int tap = t / cit;
+    const int kh = tap / e.KW, kw = tap % e.KW;
+    const int tap_t = (e.KH - 1 - kh) * e.KW + (e.KW - 1 - kw);
+    const float* w = params + e.off;
+    T* wt_f = (T*)e.wf;
+    T* wt_d = (T*)e.wd;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const long long Kf = (long long)e.KH * e.KW * e.Cin, Kd = (long long)e.KH * e.KW * e.Cout;
+    for (int r = ty; r < 32; r += 8) {
+        const int ci = ci0 + r, co = co0 + tx;
+        const float v = (ci < e.Cin && co < e.Cout) ? w[((long long)tap * e.Cin + ci) * e.Cout + co] : 0.f;
+        tile[r][tx] = v;
+        if (wt_d && ci < e.Cin && co < e.Cout) wt_d[(long long)ci * Kd + (long long)tap_t * e.Cout + co] = (T)v;
+    }
+    __syncthreads();
+    if (wt_f)
+        for (int r = ty; r < 32; r += 8) {
+            const int co = co0 + r, ci = ci0 + tx;
+            if (co < e.Cout && ci < e.Cin) wt_f[(long long)co * Kf + (long long)tap * e.Cin + ci] = (T)tile[tx][r];
+        }
+}
+
+extern "C" int mrcnn_weights_to_h16_batched(const float* params, const void* table, int n_layers, int total_tiles, int dtype,
+                                            void* stream) {
+    if (!params || !table || n_layers <= 0 || total_tiles <= 0 || !h16_dtype_ok(dtype)) return MRCNN_ERR_ARG;
+    if (dtype == MRCNN_DTYPE_F16)
+        hipLaunchKernelGGL(weights_to_h16_batched_kernel<_Float16>, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                           params, (const H16ImageEntry*)table, n_layers);
+    else
+        hipLaunchKernelGGL(weights_to_h16_batched_kernel<__bf16>, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                           params, (const H16ImageEntry*)table, n_layers);
+    return mrcnn_launch_status();
+}
+
 extern "C" int mrcnn_weights_to_h16(const float* w, void* wt_fwd, void* wt_dgrad, int KH, int KW, int Cin, int Cout, int dtype,
                                     void* stream) {
     if (!w || (!wt_fwd && !wt_dgrad) || KH <= 0 || KW <= 0 || Cin <= 0 || Cout <= 0 || !h16_dtype_ok(dtype)) return MRCNN_ERR_ARG;

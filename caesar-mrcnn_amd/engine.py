@@ -227,6 +227,7 @@ class MaskRCNNEngine(object):
         self.h16_fused_bwd = os.environ.get("MRCNN_H16_FUSED_BWD", "1") != "0"     # 16-bit data gradients carry the lower layer's epilogue backward
         self._h16 = {}
         self._h16_store = {}            # dtype -> {layer: (W^T image, data-gradient image)}, stable addresses
+        self._h16_tables = {}           # (dtype, layer names) -> table of the one-launch refresh (ops.h16_image_table)
         self._h16_valid = False
         self.fused_mask_out_bwd = True  # single-pass backward of the mask-head output stage
         # the persistent 256 x 256 16-bit kernel for the mask head's DATA gradients too (they run beside the weight gradients
@@ -316,6 +317,18 @@ class MaskRCNNEngine(object):
                 for blk in stage:
                     if self._h16_block(blk):
                         names += [blk.c2a.name, blk.c2b.name, blk.c2c.name] + ([blk.c1.name] if blk.c1 is not None else [])
+        # steady state: every image exists (addresses stable) -> ONE table-driven launch refreshes them all; only the
+        # class-head FC layers' second image (a plain cast of the HWIO kernel) keeps its own launch
+        tkey = (self.head_dtype, tuple(names))
+        tab = self._h16_tables.get(tkey)
+        if tab is not None:
+            ops.weights_to_h16_batched(self.params, tab[0], self.head_dtype)
+            for op, wn in tab[1]:
+                kh, kw, cin, cout = op.wshape
+                ops.cast_to_h16(op.w.view(kh * kw * cin, cout), self.head_dtype, out=wn)
+            self._h16 = dict(imgs, dtype=self.head_dtype)
+            self._h16_valid = True
+            return
         for name in names:
             op = self.op(name)
             if op.padding == "valid" and op.wshape[0] > 1:
@@ -329,6 +342,18 @@ class MaskRCNNEngine(object):
                 imgs[name] = (wf, wn)
             else:
                 imgs[name] = ops.weights_to_h16(op.w, self.head_dtype, out=imgs.get(name))
+        entries, casts = [], []
+        for name in names:
+            op = self.op(name)
+            if op.padding == "valid" and op.wshape[0] > 1:
+                entries.append((op.w, imgs[name][0], None))
+                casts.append((op, imgs[name][1]))
+            else:
+                entries.append((op.w, imgs[name][0], imgs[name][1]))
+        try:
+            self._h16_tables[tkey] = (ops.h16_image_table(self.params, entries, self.dev), casts)
+        except AssertionError:
+            pass                                            # a kernel that is not a view into the flat buffer: stay layer by layer
         self._h16 = dict(imgs, dtype=self.head_dtype)
         self._h16_valid = True
 

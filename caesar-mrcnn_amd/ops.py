@@ -663,6 +663,29 @@ def weights_to_h16(w, dtype=torch.float16, want_dgrad=True, out=None):
     return wf, wd
 
 
+def h16_image_table(params, entries, device):
+    """entries: [(w (a view into the flat float32 `params`), wf, wd or None)] -> (device table, n_layers, total_tiles) for
+    weights_to_h16_batched.  The images' addresses are baked in: build it once the images exist and never move."""
+    import numpy as np
+    rec = np.zeros(len(entries), dtype=[("off", "<i8"), ("wf", "<u8"), ("wd", "<u8"), ("KH", "<i4"), ("KW", "<i4"), ("Cin", "<i4"),
+                                        ("Cout", "<i4"), ("first", "<i4"), ("pad", "<i4")])
+    tiles = 0
+    for i, (w, wf, wd) in enumerate(entries):
+        kh, kw, cin, cout = w.shape
+        off = (w.data_ptr() - params.data_ptr()) // 4
+        assert 0 <= off and off + w.numel() <= params.numel() and w.is_contiguous()
+        rec[i] = (off, wf.data_ptr() if wf is not None else 0, wd.data_ptr() if wd is not None else 0, kh, kw, cin, cout, tiles, 0)
+        tiles += kh * kw * ((cin + 31) // 32) * ((cout + 31) // 32)
+    t = torch.from_numpy(rec.view(np.uint8).copy()).to(device)
+    return t, len(entries), tiles
+
+
+def weights_to_h16_batched(params, table, dtype):
+    _need_cuda(params, table[0])
+    check(_hip.lib().mrcnn_weights_to_h16_batched(ptr(params), ptr(table[0]), table[1], table[2], _H16[dtype], current_stream()),
+          "mrcnn_weights_to_h16_batched")
+
+
 def conv2d_h16(x, w_t, kshape, bias=None, scale=None, shift=None, stride=1, padding="same", act=ACT_NONE, z_out=None,
                out=None, res=None, out_strides=None):
     """16-bit convolution: x [N,H,W,Cin] half/bfloat16, w_t = W^T [Cout, KH*KW*Cin]; kshape = (KH, KW, Cin, Cout).

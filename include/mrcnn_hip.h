@@ -287,6 +287,10 @@ int mrcnn_conv2d_dgrad_ep_h16(const mrcnn_conv_desc* d, int dtype, const void* d
                               void* dz_below, const mrcnn_bwd_epilogue_h16* ep, void* stream);
 int mrcnn_weights_to_h16(const float* w_hwio, void* wt_fwd, void* wt_dgrad, int KH, int KW, int Cin, int Cout,
                          int dtype, void* stream);
+/* All 16-bit weight images of a model in one launch.  table: n_layers records {int64 offset of the float32 HWIO kernel in
+ * `params` (floats); uint64 W^T image pointer; uint64 data-gradient image pointer or 0; int32 KH, KW, Cin, Cout, first_tile,
+ * pad} (48 bytes each), first_tile = running sum of KH*KW*ceil(Cin/32)*ceil(Cout/32); total_tiles = the sum over all layers. */
+int mrcnn_weights_to_h16_batched(const float* params, const void* table, int n_layers, int total_tiles, int dtype, void* stream);
 /* Weight gradient with 16-bit operands x [N,H,W,Cin], dy [N,OH,OW,Cout]: dw (float32, HWIO) = multiplier * sum
  * (or dw += ... with beta_acc); float32 accumulation, slabs per pixel split summed in a fixed order.
  * Cin % 256 == 0, Cout % 128 == 0.  The workspace also holds a per-pixel offset / tap-mask table.           */

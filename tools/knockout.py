@@ -13,7 +13,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "dense-f32"
 what = sys.argv[2] if len(sys.argv) > 2 else "none"
 nimg = 4
 dev = torch.device("cuda", 0)
-cfg = run_py_config(num_classes=4, imgsize=256, backbone="resnet101", images_per_gpu=nimg, gpu_count=1)
+cfg = run_py_config(num_classes=4, imgsize=int(os.environ.get("MRCNN_IMGSIZE", "256")), backbone="resnet101", images_per_gpu=nimg, gpu_count=1)
 model = MaskRCNN("training", cfg, "/tmp/mrcnn_bench_logs", device=dev, seed=0)
 model.compile(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM)
 inp = model._to_device(bench.synthetic_batch(cfg, nimg, seed=1234))
