@@ -21,6 +21,8 @@ struct ConvArgs {
     FastDiv d_ohw, d_ow;               // exact division of output-pixel indices (non-dense stores: deconv, concat, UP2)
     FastDiv d_c4;                      // Cout / 4 (vector split-K epilogue)
     float* slab; int ksplit, ksteps;   // split-K: partial sums [ksplit][M][Cout], K-steps per split
+    int bat_rows;                      // LDS-DMA kernel as a batched GEMM (Winograd domain): rows [b * bat_rows, (b + 1) * bat_rows) use the
+                                       // weight matrix w + b * Ktot * Cout; 0 = one weight matrix (every convolution)
     int mtile0;                        // LDS-DMA split-K kernel as the TAIL launch of a large layer: first 128-row tile it owns; slab rows
                                        // are relative to it ([ksplit][M - 128 mtile0][Cout])
     // fused backward epilogue (mrcnn_conv2d_dgrad_ep, LDS-DMA kernel only): the result y is the gradient w.r.t. the
@@ -495,8 +497,9 @@ __device__ __forceinline__ void conv_fwd_blds_body(const ConvArgs& p, const unsi
 
     const __amdgpu_buffer_rsrc_t rsrc_a =
         __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - x_shift), 0, x_records, 0x00020000);
+    const long long wbat = (!SPLIT && p.bat_rows) ? (long long)(m0 / p.bat_rows) * p.Ktot * p.Cout : 0;   // batched GEMM: the tile's weight matrix
     const __amdgpu_buffer_rsrc_t rsrc_b =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + n0), 0, (unsigned)(((long long)p.Ktot * p.Cout - n0) * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + wbat + n0), 0, (unsigned)(((long long)p.Ktot * p.Cout - n0) * 4), 0x00020000);
 
     unsigned a_voff[2];
     unsigned long long a_mask[2];
@@ -1235,7 +1238,7 @@ static int conv_fill_args(const mrcnn_conv_desc* d, const float* x, const float*
     a.vecB = (d->Cout % 4 == 0) && ((reinterpret_cast<uintptr_t>(w) & 15) == 0);
     a.dense = d->out_mode == MRCNN_OUT_NHWC && d->out_w_stride == d->Cout &&
               d->out_h_stride == (int64_t)d->OW * d->Cout && d->out_n_stride == (int64_t)d->OH * d->OW * d->Cout;
-    a.ksplit = 1; a.ksteps = a.nk; a.slab = nullptr; a.mtile0 = 0;
+    a.ksplit = 1; a.ksteps = a.nk; a.slab = nullptr; a.mtile0 = 0; a.bat_rows = 0;
     a.fb_act = -1;
     a.fb_out = a.fb_z = a.fb_scale = a.fb_mean = a.fb_rstd = nullptr;
     a.fb_dgamma = a.fb_dbeta = a.fb_dbias = nullptr;
@@ -1347,6 +1350,27 @@ static int conv_fwd_impl(const mrcnn_conv_desc* d, const float* x, const float* 
     if (pl.bn == 32) return pl.bm == 128 ? launch_conv<128, 32, 4, 1>(a, s) : launch_conv<64, 32, 2, 1>(a, s);
     if (pl.bn == 64) return pl.bm == 128 ? launch_conv<128, 64, 2, 2>(a, s) : launch_conv<64, 64, 2, 2>(a, s);
     return pl.bm == 128 ? launch_conv<128, 128, 2, 2>(a, s) : launch_conv<64, 128, 2, 2>(a, s);
+}
+
+// The 16 GEMMs of a Winograd F(2x2, 3x3) layer in one launch of the LDS-DMA kernel: V [nb][rows][K] . U [nb][K][Cout] ->
+// Mt [nb][rows][Cout], rows a multiple of 128 (a tile never straddles two weight matrices), K % 16 == 0, Cout % 128 == 0.
+// To the kernel it is a 1 x 1 convolution over nb * rows pixels whose weight matrix is chosen by the tile's row block.
+extern "C" int mrcnn_gemm_batched_f32(const float* V, const float* U, float* Mt, int nb, int rows, int K, int Cout, void* stream) {
+    if (!V || !U || !Mt || nb <= 0 || rows <= 0 || rows % 128 || K <= 0 || K % 16 || Cout <= 0 || Cout % 128) return MRCNN_ERR_ARG;
+    const long long M = (long long)nb * rows;
+    if (M >= (1LL << 31) || M * K * 4 >= 0x7FFFFFF0LL || (long long)K * Cout * 4 >= 0x7FFFFFF0LL) return MRCNN_ERR_UNSUPPORTED;
+    mrcnn_conv_desc d = {};
+    d.N = (int)M; d.H = 1; d.W = 1; d.Cin = K; d.Cout = Cout; d.KH = 1; d.KW = 1; d.stride = 1; d.pad_t = 0; d.pad_l = 0; d.OH = 1; d.OW = 1;
+    d.act = MRCNN_ACT_NONE; d.res_mode = MRCNN_RES_NONE; d.out_mode = MRCNN_OUT_NHWC; d.cmod = Cout;
+    d.out_n_stride = Cout; d.out_h_stride = Cout; d.out_w_stride = Cout;
+    ConvArgs a;
+    const int rc = conv_fill_args(&d, V, U, nullptr, nullptr, nullptr, nullptr, Mt, nullptr, a);
+    if (rc != MRCNN_OK) return rc;
+    if (!a.fastA || !a.vecB || !a.dense) return MRCNN_ERR_UNSUPPORTED;
+    a.bat_rows = rows;
+    const int mt = (int)(M / 128), nt = Cout / 128;
+    hipLaunchKernelGGL(conv_fwd_blds_kernel, dim3((unsigned)(mt * nt)), dim3(256), 0, (hipStream_t)stream, a, 0u, (unsigned)(M * K * 4));
+    return mrcnn_launch_status();
 }
 
 extern "C" int mrcnn_conv2d_fwd_ws(const mrcnn_conv_desc* d, const float* x, const float* w,

@@ -1,0 +1,280 @@
+// Winograd F(2x2, 3x3) for the stride-1 "same" 3x3 convolutions of the mask head (float32): Y = A^T [(G g G^T) . (B^T d B)] A per
+// 4 x 4 input tile / 2 x 2 output tile, summed over input channels -- 16 multiplications per 4 outputs and channel pair instead
+// of 36, i.e. 16 batched GEMMs [tiles x Cin] . [Cin x Cout] in the transform domain (2.25 x fewer MFMA flops than the direct
+// form).  Three passes per layer:
+//   winograd_input_kernel    x [N, H, W, C]            -> V [16][T][C],   T = N (H/2)(W/2) tiles   (reads x once through L2, writes 4 x its size)
+//   16 GEMMs                 V[xi] [T, C] . U[xi] [C, Cout] -> Mt [16][T][Cout]                     (conv_fwd_blds_kernel, batched over xi)
+//   winograd_output_kernel   Mt -> out [N, H, W, Cout] with the convolution's epilogue (bias, frozen-BN affine, activation, z)
+// plus winograd_weight_kernel U = G g G^T once per weight update.  The transforms are exact additions / halvings in float32
+// (B^T, A^T have entries 0, +-1; G has 0, 1, +-1/2), so the result differs from the direct kernel by summation order only.
+// H and W even (mask head: 14 x 14).
+#include "common.h"
+
+// B^T d B for one 4 x 4 tile held as d[r][c] (float4 = 4 channels per thread)
+__device__ __forceinline__ void wino_bt_d_b(const f32x4 d[4][4], f32x4 v[4][4]) {
+    f32x4 t[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {                // rows: B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
+        t[0][c] = d[0][c] - d[2][c];
+        t[1][c] = d[1][c] + d[2][c];
+        t[2][c] = d[2][c] - d[1][c];
+        t[3][c] = d[1][c] - d[3][c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                // columns: the same with B
+        v[r][0] = t[r][0] - t[r][2];
+        v[r][1] = t[r][1] + t[r][2];
+        v[r][2] = t[r][2] - t[r][1];
+        v[r][3] = t[r][1] - t[r][3];
+    }
+}
+
+// one thread: one tile x 4 channels.  Tiles are numbered (n, th, tw) row-major: tile t covers outputs (2 th .. 2 th + 1, 2 tw .. + 1)
+__global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W,
+                                                             int C, long long T, long long Tp) {
+    const int c4n = C >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * c4n) return;
+    const long long t = i / c4n;
+    const int c = (int)(i - t * c4n) * 4;
+    const int tw_n = W >> 1, th_n = H >> 1;
+    const int tw = (int)(t % tw_n);
+    const long long q = t / tw_n;
+    const int th = (int)(q % th_n);
+    const int n = (int)(q / th_n);
+    const int ih0 = 2 * th - 1, iw0 = 2 * tw - 1;
+    f32x4 d[4][4], v[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int ih = ih0 + r, iw = iw0 + s;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+                val = *(const f32x4*)(x + (((long long)n * H + ih) * W + iw) * C + c);
+            d[r][s] = val;
+        }
+    wino_bt_d_b(d, v);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) *(f32x4*)(V + ((long long)(r * 4 + s) * Tp + t) * C + c) = v[r][s];
+}
+
+// U[xi][ci][co] = (G g G^T)[xi] from the HWIO kernel g[3][3][ci][co]; one thread per (ci, co)
+__global__ __launch_bounds__(256) void winograd_weight_kernel(const float* __restrict__ g, float* __restrict__ U, int Cin, int Cout) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)Cin * Cout;
+    if (i >= n) return;
+    float w[3][3], t[4][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) w[a][b] = g[(long long)(a * 3 + b) * n + i];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {                // G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
+        t[0][b] = w[0][b];
+        t[1][b] = 0.5f * (w[0][b] + w[1][b] + w[2][b]);
+        t[2][b] = 0.5f * (w[0][b] - w[1][b] + w[2][b]);
+        t[3][b] = w[2][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        U[(long long)(a * 4 + 0) * n + i] = t[a][0];
+        U[(long long)(a * 4 + 1) * n + i] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+        U[(long long)(a * 4 + 2) * n + i] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+        U[(long long)(a * 4 + 3) * n + i] = t[a][2];
+    }
+}
+
+// A^T m A (2 x 2 outputs of one tile) + epilogue: z = y + bias (stored when asked), out = act(scale z + shift)
+__global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ Mt, float* __restrict__ out, float* __restrict__ z,
+                                                              const float* __restrict__ bias, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int N, int H, int W, int C, long long T,
+                                                              long long Tp, int act) {
+    const int c4n = C >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * c4n) return;
+    const long long t = i / c4n;
+    const int c = (int)(i - t * c4n) * 4;
+    const int tw_n = W >> 1, th_n = H >> 1;
+    const int tw = (int)(t % tw_n);
+    const long long q = t / tw_n;
+    const int th = (int)(q % th_n);
+    const int n = (int)(q / th_n);
+    f32x4 m[4][4], s[2][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[r][k] = *(const f32x4*)(Mt + ((long long)(r * 4 + k) * Tp + t) * C + c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                // A^T = [1 1 1 0; 0 1 -1 -1]
+        s[0][k] = m[0][k] + m[1][k] + m[2][k];
+        s[1][k] = m[1][k] - m[2][k] - m[3][k];
+    }
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
+    const f32x4 bi = bias ? *(const f32x4*)(bias + c) : zero4;
+    const f32x4 sc = scale ? *(const f32x4*)(scale + c) : one4, sh = scale ? *(const f32x4*)(shift + c) : zero4;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        f32x4 y[2];
+        y[0] = s[a][0] + s[a][1] + s[a][2];
+        y[1] = s[a][1] - s[a][2] - s[a][3];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const long long addr = (((long long)n * H + 2 * th + a) * W + 2 * tw + b) * C + c;
+            f32x4 zv, o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                zv[e] = y[b][e] + bi[e];
+                float v = sc[e] * zv[e] + sh[e];
+                if (act == MRCNN_ACT_RELU) v = fmaxf(v, 0.f);
+                o[e] = v;
+            }
+            if (z) *(f32x4*)(z + addr) = zv;
+            *(f32x4*)(out + addr) = o;
+        }
+    }
+}
+
+// The output transform of a DATA gradient fused with the epilogue backward of the layer below (what mrcnn_conv2d_dgrad_ep does
+// for the direct kernel): y = A^T m A is d(loss)/d(activated output of the layer below);
+//   g = y * act'(out_below);  dz = g * scale_below -> stored;  dbeta += sum g, dgamma += sum g (z_below - mean) rstd, dbias += sum dz.
+// A workgroup walks a range of tiles: lane = 4-channel group (C / 4 of them, a power of two <= 256), 256 / (C / 4) tiles in flight;
+// channel sums stay in registers, meet in LDS and leave as one atomic per channel and workgroup.
+__global__ __launch_bounds__(256) void winograd_output_bwd_kernel(const float* __restrict__ Mt, float* __restrict__ dz_out,
+                                                                  const float* __restrict__ below_out, const float* __restrict__ below_z,
+                                                                  const float* __restrict__ scale, const float* __restrict__ mean,
+                                                                  const float* __restrict__ rstd, float* dgamma, float* dbeta, float* dbias,
+                                                                  int N, int H, int W, int C, long long T, long long Tp, int act,
+                                                                  long long tiles_per_block, int lg) {
+    __shared__ float sacc[3 * 4 * 256];
+    const int L = 1 << lg, R = 256 >> lg;                       // L = C / 4 lanes, R tiles in flight
+    for (int c = threadIdx.x; c < 12 * L; c += 256) sacc[c] = 0.f;
+    __syncthreads();
+    const int rsub = threadIdx.x >> lg, lane = threadIdx.x & (L - 1);
+    const int c = lane * 4;
+    const long long t0 = (long long)blockIdx.x * tiles_per_block;
+    long long t1 = t0 + tiles_per_block;
+    if (t1 > T) t1 = T;
+    const int tw_n = W >> 1, th_n = H >> 1;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, mu = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
+    if (scale) sc = *(const f32x4*)(scale + c);
+    if (dgamma) { mu = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c); }
+    f32x4 a_db = {0.f, 0.f, 0.f, 0.f}, a_dg = a_db, a_bias = a_db;
+    for (long long t = t0 + rsub; t < t1; t += R) {
+        const int tw = (int)(t % tw_n);
+        const long long q = t / tw_n;
+        const int th = (int)(q % th_n);
+        const int n = (int)(q / th_n);
+        f32x4 m[4][4], s[2][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m[r][k] = *(const f32x4*)(Mt + ((long long)(r * 4 + k) * Tp + t) * C + c);
+        f32x4 oo[2][2], zz[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const long long addr = (((long long)n * H + 2 * th + a) * W + 2 * tw + b) * C + c;
+                if (act == MRCNN_ACT_RELU) oo[a][b] = *(const f32x4*)(below_out + addr);
+                if (dgamma) zz[a][b] = *(const f32x4*)(below_z + addr);
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            s[0][k] = m[0][k] + m[1][k] + m[2][k];
+            s[1][k] = m[1][k] - m[2][k] - m[3][k];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            f32x4 y[2];
+            y[0] = s[a][0] + s[a][1] + s[a][2];
+            y[1] = s[a][1] - s[a][2] - s[a][3];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const long long addr = (((long long)n * H + 2 * th + a) * W + 2 * tw + b) * C + c;
+                f32x4 g = y[b], dz;
+                if (act == MRCNN_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = oo[a][b][e] > 0.f ? g[e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dz[e] = g[e] * sc[e];
+                *(f32x4*)(dz_out + addr) = dz;
+                if (dgamma) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a_dg[e] += g[e] * (zz[a][b][e] - mu[e]) * rs[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { a_db[e] += g[e]; a_bias[e] += dz[e]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (dbeta || dgamma) atomicAdd(&sacc[lane * 4 + k], a_db[k]);
+        if (dgamma) atomicAdd(&sacc[4 * L + lane * 4 + k], a_dg[k]);
+        if (dbias) atomicAdd(&sacc[8 * L + lane * 4 + k], a_bias[k]);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 4 * L; j += 256) {
+        if (dbeta) atomicAdd(&dbeta[j], sacc[j]);
+        if (dgamma) atomicAdd(&dgamma[j], sacc[4 * L + j]);
+        if (dbias) atomicAdd(&dbias[j], sacc[8 * L + j]);
+    }
+}
+
+static inline long long wino_tiles(int N, int H, int W) { return (long long)N * (H >> 1) * (W >> 1); }
+static inline long long wino_rows(long long T) { return (T + 127) / 128 * 128; }      // rows per transform-domain matrix: whole 128-row tiles
+
+static int wino_shape_ok(int N, int H, int W, int C) { return N > 0 && H > 0 && W > 0 && !(H & 1) && !(W & 1) && C > 0 && !(C & 3); }
+
+/* floats of V (input transform) or Mt (transform-domain product) for a layer: 16 x rows x C */
+extern "C" size_t mrcnn_winograd_buffer_floats(int N, int H, int W, int C) {
+    if (!wino_shape_ok(N, H, W, C)) return 0;
+    return (size_t)16 * (size_t)wino_rows(wino_tiles(N, H, W)) * (size_t)C;
+}
+
+extern "C" int mrcnn_winograd_input(const float* x, float* V, int N, int H, int W, int C, void* stream) {
+    if (!x || !V || !wino_shape_ok(N, H, W, C)) return MRCNN_ERR_ARG;
+    const long long T = wino_tiles(N, H, W);
+    hipLaunchKernelGGL(winograd_input_kernel, dim3((unsigned)cdiv64(T * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W, C, T,
+                       wino_rows(T));
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_winograd_weights(const float* g, float* U, int Cin, int Cout, void* stream) {
+    if (!g || !U || Cin <= 0 || Cout <= 0) return MRCNN_ERR_ARG;
+    hipLaunchKernelGGL(winograd_weight_kernel, dim3((unsigned)cdiv64((long long)Cin * Cout, 256)), dim3(256), 0, (hipStream_t)stream, g, U, Cin, Cout);
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_winograd_output(const float* Mt, float* out, float* z, const float* bias, const float* scale, const float* shift,
+                                     int N, int H, int W, int C, int act, void* stream) {
+    if (!Mt || !out || !wino_shape_ok(N, H, W, C) || (scale && !shift)) return MRCNN_ERR_ARG;
+    if (act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) return MRCNN_ERR_UNSUPPORTED;
+    const long long T = wino_tiles(N, H, W);
+    hipLaunchKernelGGL(winograd_output_kernel, dim3((unsigned)cdiv64(T * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, Mt, out, z, bias,
+                       scale, shift, N, H, W, C, T, wino_rows(T), act);
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_winograd_output_bwd(const float* Mt, float* dz_below, const float* below_out, const float* below_z, const float* scale,
+                                         const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H, int W,
+                                         int C, int act, void* stream) {
+    if (!Mt || !dz_below || !wino_shape_ok(N, H, W, C)) return MRCNN_ERR_ARG;
+    if ((act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) || (act == MRCNN_ACT_RELU && !below_out)) return MRCNN_ERR_ARG;
+    if (dgamma && (!below_z || !mean || !rstd)) return MRCNN_ERR_ARG;
+    const int c4n = C >> 2;
+    if (c4n > 256 || (c4n & (c4n - 1))) return MRCNN_ERR_UNSUPPORTED;
+    int lg = 0;
+    while ((1 << lg) < c4n) ++lg;
+    const long long T = wino_tiles(N, H, W);
+    const long long R = 256 >> lg;
+    long long per = (T + 2047) / 2048;                          // ~2048 workgroups; every one a whole number of passes
+    per = (per + R - 1) / R * R;
+    hipLaunchKernelGGL(winograd_output_bwd_kernel, dim3((unsigned)cdiv64(T, per)), dim3(256), 0, (hipStream_t)stream, Mt, dz_below, below_out,
+                       below_z, scale, mean, rstd, dgamma, dbeta, dbias, N, H, W, C, T, wino_rows(T), act, per, lg);
+    return mrcnn_launch_status();
+}

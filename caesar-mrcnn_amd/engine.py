@@ -226,6 +226,11 @@ class MaskRCNNEngine(object):
         self.h16_all_blocks = os.environ.get("MRCNN_H16_ALL_BLOCKS", "1") != "0"   # 0: only the identity blocks of res4 / res5
         self.h16_fused_bwd = os.environ.get("MRCNN_H16_FUSED_BWD", "1") != "0"     # 16-bit data gradients carry the lower layer's epilogue backward
         self._h16 = {}
+        # Winograd F(2x2, 3x3) for the float32 3x3 convolutions of the mask head (forward and data gradients): 2.25 x fewer
+        # matrix-core flops through three launches per layer; MRCNN_WINOGRAD=0 keeps the direct kernels
+        self.winograd = os.environ.get("MRCNN_WINOGRAD", "1") != "0"
+        self._wino = {}                 # layer -> [U forward, U data gradient] (allocated once, refreshed after weight updates)
+        self._wino_valid = {}           # layer -> [forward valid, data-gradient valid]
         self._h16_store = {}            # dtype -> {layer: (W^T image, data-gradient image)}, stable addresses
         self._h16_tables = {}           # (dtype, layer names) -> table of the one-launch refresh (ops.h16_image_table)
         self._h16_valid = False
@@ -302,6 +307,33 @@ class MaskRCNNEngine(object):
             ops.conv2d_wgrad_h16(x, dz, wshape, 1, padding, dw=dw, accumulate=accumulate, multiplier=multiplier)
         dz.record_stream(ws)
         x.record_stream(ws)
+
+    # every site that invalidates the 16-bit weight images (optimiser step, set_weights, graph / tape replay, warm-up roll
+    # back) changes the weights: the Winograd-domain kernels go stale with them
+    @property
+    def _h16_valid(self):
+        return self._h16_valid_flag
+
+    @_h16_valid.setter
+    def _h16_valid(self, v):
+        self._h16_valid_flag = bool(v)
+        if not v:
+            self._wino_valid = {}
+
+    def _wino_U(self, op, which):
+        """Winograd-domain kernel of layer `op`: which = 0 forward (from op.w), 1 data gradient (from the flipped / transposed
+        op.wt, which must be current).  Refreshed lazily after every weight update, in place."""
+        ent = self._wino.setdefault(op.name, [None, None])
+        ok = self._wino_valid.setdefault(op.name, [False, False])
+        if not ok[which]:
+            src = op.w if which == 0 else op.wt
+            ent[which] = ops.winograd_weights(src, out=ent[which])
+            ok[which] = True
+        return ent[which]
+
+    def _wino_ok(self, op, xshape):
+        return (self.winograd and self.head_dtype is None and
+                ops.winograd_ok(tuple(xshape), op.wshape, op.stride, op.padding))
 
     def _ensure_h16(self):
         """16-bit operand images (W^T and the rotated data-gradient image) of the mask-head convolutions."""
@@ -789,7 +821,14 @@ class MaskRCNNEngine(object):
         ctxs = []
         if self.head_dtype is None:
             for i in range(1, 5):
-                x, c = self.op("mrcnn_mask_conv%d" % i).forward(x, ACT_RELU, train=train)
+                op = self.op("mrcnn_mask_conv%d" % i)
+                if self._wino_ok(op, x.shape):
+                    out = ops.empty(tuple(x.shape[:3]) + (op.wshape[3],), torch.float32, self.dev)
+                    z = ops.empty_like(out) if (train and op.bn) else None
+                    ops.conv2d_winograd(x, self._wino_U(op, 0), op.b, op.scale, op.shift, ACT_RELU, out=out, z_out=z)
+                    x, c = out, ((x, z, out, ACT_RELU) if train else None)
+                else:
+                    x, c = op.forward(x, ACT_RELU, train=train)
                 ctxs.append(c)
         else:                                   # 16-bit matrix cores; float32 again from the deconvolution on
             self._ensure_h16()
@@ -1071,11 +1110,24 @@ class MaskRCNNEngine(object):
             dz = self._dgrad_ep(dzg, dc.wt, "valid", chain[0][0], chain[0][1])
             for k, (op, c) in enumerate(chain):
                 self._mask_wgrad("f32", *op.wgrad_item(dz, c))
+                kh, kw, cin, cout = op.wshape
+                wino = self._wino_ok(op, c[0].shape)
+                if wino and not self.wt_valid:
+                    ops.weight_flip_transpose(op.w, op.wt)
                 if k + 1 < len(chain):
-                    kh, kw = op.wshape[0], op.wshape[1]
-                    if not self.wt_valid:
+                    below, bctx = chain[k + 1]
+                    if not self.wt_valid and not wino:
                         ops.weight_flip_transpose(op.w, op.wt)
-                    dz = self._dgrad_ep(dz, op.wt, ((kh - 1) // 2, (kw - 1) // 2), chain[k + 1][0], chain[k + 1][1])
+                    if wino and self.fused_dgrad_epilogue and below.bn is not None:
+                        _, bz, bout, bact = bctx
+                        dz = ops.conv2d_dgrad_ep_winograd(dz, self._wino_U(op, 1), bout if bact != ACT_NONE else None, bz, below.scale,
+                                                          below.mean, below.rstd, below.dgamma, below.dbeta, below.db, bact)
+                    elif wino:
+                        dz = below.epilogue_bwd(ops.conv2d_winograd(dz, self._wino_U(op, 1)), bctx)[0]
+                    else:
+                        dz = self._dgrad_ep(dz, op.wt, ((kh - 1) // 2, (kw - 1) // 2), below, bctx)
+                elif wino:
+                    d = ops.conv2d_winograd(dz, self._wino_U(op, 1))
                 else:
                     d = op.dgrad(dz, c)
         else:

@@ -663,6 +663,67 @@ def weights_to_h16(w, dtype=torch.float16, want_dgrad=True, out=None):
     return wf, wd
 
 
+# ---- Winograd F(2x2, 3x3), float32 (mask-head 3x3 convolutions) --------------------------------------------------------
+def winograd_ok(xshape, wshape, stride=1, padding="same", min_rows=32768):
+    """Shapes the Winograd path takes: 3 x 3, stride 1, 'same' (or explicit 1, 1), even H and W, channels that fit the batched
+    GEMM (Cin % 16, Cout % 128) and the transforms (multiples of 4), enough rows to fill the chip."""
+    N, H, W, Cin = xshape
+    kh, kw, cin, cout = wshape
+    return (kh == 3 and kw == 3 and stride == 1 and padding in ("same", (1, 1)) and H % 2 == 0 and W % 2 == 0 and cin == Cin and
+            Cin % 16 == 0 and cout % 128 == 0 and N * H * W >= min_rows and N * (H // 2) * (W // 2) * 16 * max(Cin, cout) < 2 ** 31)
+
+
+def winograd_weights(w, out=None):
+    """HWIO 3 x 3 kernel -> U [16, Cin, Cout] = G g G^T."""
+    _need_cuda(w, out)
+    kh, kw, cin, cout = w.shape
+    assert kh == 3 and kw == 3 and w.is_contiguous()
+    if out is None:
+        out = torch.empty((16, cin, cout), dtype=torch.float32, device=w.device)
+    check(_hip.lib().mrcnn_winograd_weights(ptr(w), ptr(out), cin, cout, current_stream()), "mrcnn_winograd_weights")
+    return out
+
+
+def _winograd_product(x, U):
+    """Input transform + the 16 transform-domain GEMMs; returns Mt (a per-stream scratch buffer, valid until the next call)."""
+    N, H, W, Cin = x.shape
+    cout = U.shape[2]
+    lib = _hip.lib()
+    nv, nm = lib.mrcnn_winograd_buffer_floats(N, H, W, Cin), lib.mrcnn_winograd_buffer_floats(N, H, W, cout)
+    V = workspace(nv * 4, x.device, "winograd_v")
+    Mt = workspace(nm * 4, x.device, "winograd_m")
+    check(lib.mrcnn_winograd_input(ptr(x), ptr(V), N, H, W, Cin, current_stream()), "mrcnn_winograd_input")
+    check(lib.mrcnn_gemm_batched_f32(ptr(V), ptr(U), ptr(Mt), 16, nv // (16 * Cin), Cin, cout, current_stream()), "mrcnn_gemm_batched_f32")
+    return Mt
+
+
+def conv2d_winograd(x, U, bias=None, scale=None, shift=None, act=ACT_NONE, out=None, z_out=None):
+    """3 x 3 'same' stride-1 convolution with its epilogue through the Winograd domain (U = winograd_weights(w))."""
+    _need_cuda(x, U, bias, scale, shift, out, z_out)
+    N, H, W, _ = x.shape
+    cout = U.shape[2]
+    if out is None:
+        out = empty((N, H, W, cout), torch.float32, x.device)
+    Mt = _winograd_product(x, U)
+    check(_hip.lib().mrcnn_winograd_output(ptr(Mt), ptr(out), ptr(z_out), ptr(bias), ptr(scale), ptr(shift), N, H, W, cout, act,
+                                           current_stream()), "mrcnn_winograd_output")
+    return out
+
+
+def conv2d_dgrad_ep_winograd(dz, Ut, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, act):
+    """Data gradient of a 3 x 3 'same' convolution (Ut = winograd_weights of the flipped / transposed kernel) fused with the
+    epilogue backward of the layer below: returns dz_below, channel sums are added to dgamma / dbeta / dbias."""
+    _need_cuda(dz, Ut, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias)
+    N, H, W, _ = dz.shape
+    cout = Ut.shape[2]
+    out = empty((N, H, W, cout), torch.float32, dz.device)
+    Mt = _winograd_product(dz, Ut)
+    check(_hip.lib().mrcnn_winograd_output_bwd(ptr(Mt), ptr(out), ptr(below_out), ptr(below_z), ptr(scale), ptr(mean), ptr(rstd),
+                                               ptr(dgamma), ptr(dbeta), ptr(dbias), N, H, W, cout, act, current_stream()),
+          "mrcnn_winograd_output_bwd")
+    return out
+
+
 def h16_image_table(params, entries, device):
     """entries: [(w (a view into the flat float32 `params`), wf, wd or None)] -> (device table, n_layers, total_tiles) for
     weights_to_h16_batched.  The images' addresses are baked in: build it once the images exist and never move."""

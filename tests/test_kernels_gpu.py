@@ -100,6 +100,53 @@ def test_conv_fwd(dev, case, tail_split_env):
     torch.testing.assert_close(z.cpu(), z_ref, **F32)
 
 
+@pytest.mark.parametrize("case", [(37, 14, 14, 64, 128), (5, 8, 12, 32, 256), (130, 14, 14, 256, 256)])
+def test_conv_winograd(dev, case):
+    """Winograd F(2x2, 3x3) path of the 3x3 'same' convolutions (input transform, 16 batched GEMMs in one launch, output
+    transform with bias / frozen BN / ReLU / pre-BN z): against the oracle at the float32 tolerance of the direct kernels
+    (the transforms use +-1 and 1/2 only).  Tile counts that are not multiples of 128 exercise the padded GEMM rows.  Then the
+    data-gradient form fused with the epilogue backward of the layer below, against the direct kernels of the package."""
+    ops = _ops()
+    N, H, W, Cin, Cout = case
+    rng = np.random.default_rng(300 + sum(case))
+    x = _rand(rng, N, H, W, Cin)
+    w = _rand(rng, 3, 3, Cin, Cout, scale=1.0 / np.sqrt(9 * Cin))
+    b = _rand(rng, Cout, scale=0.1)
+    sc = rng.uniform(.5, 1.5, Cout).astype(np.float32); sh = rng.uniform(-.2, .2, Cout).astype(np.float32)
+    z_ref = orc.conv2d_nhwc(torch.tensor(x), torch.tensor(w), torch.tensor(b), 1, "same")
+    y_ref = torch.relu(z_ref * torch.tensor(sc) + torch.tensor(sh))
+    xt, wt, bt, sct, sht = (torch.tensor(a, device=dev) for a in (x, w, b, sc, sh))
+    U = ops.winograd_weights(wt)
+    assert tuple(U.shape) == (16, Cin, Cout)
+    z = torch.empty((N, H, W, Cout), device=dev)
+    y = ops.conv2d_winograd(xt, U, bt, sct, sht, 1, z_out=z)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y.cpu(), y_ref, **F32)
+    torch.testing.assert_close(z.cpu(), z_ref, **F32)
+    y0 = ops.conv2d_winograd(xt, U)                              # no epilogue at all (the last data gradient of the chain)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(y0.cpu(), z_ref - torch.tensor(b), **F32)
+    if Cin % 128:
+        return
+    # data gradient of a Cout -> Cin layer + epilogue backward of the layer below (Cin channels, frozen BN, ReLU)
+    dz = torch.tensor(_rand(rng, N, H, W, Cout), device=dev)
+    wflip = torch.empty((3, 3, Cout, Cin), device=dev)
+    ops.weight_flip_transpose(wt, wflip)
+    below_out = torch.relu(torch.tensor(_rand(rng, N, H, W, Cin), device=dev))
+    below_z = torch.tensor(_rand(rng, N, H, W, Cin), device=dev)
+    scale, mean, rstd = (torch.tensor(rng.uniform(0.5, 1.5, Cin).astype(np.float32), device=dev) for _ in range(3))
+    sums = [torch.zeros(Cin, device=dev) for _ in range(3)]
+    got = ops.conv2d_dgrad_ep_winograd(dz, ops.winograd_weights(wflip), below_out, below_z, scale, mean, rstd, sums[0], sums[1], sums[2], 1)
+    yd = ops.conv2d(dz, wflip, stride=1, padding=(1, 1))
+    ref = torch.empty_like(yd)
+    rs = [torch.zeros(Cin, device=dev) for _ in range(3)]
+    ops.epilogue_bwd(yd, below_out, below_z, scale, mean, rstd, None, ref, rs[0], rs[1], rs[2], 1)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(got, ref, **F32)
+    for a, r in zip(sums, rs):
+        torch.testing.assert_close(a, r, rtol=2e-4, atol=2e-4 * float(r.abs().max()))
+
+
 def test_conv_multi_launch_matches_oracle(dev):
     """mrcnn_conv2d_fwd_multi: the RPN model over five pyramid levels in three launches (model.py:2040-2055) --
     shared 3x3 + ReLU, then the two 1x1 heads written straight into the concatenated [B, A, *] buffers -- and four
