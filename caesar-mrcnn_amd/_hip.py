@@ -142,6 +142,8 @@ _SIGNATURES = {
     "mrcnn_winograd_input": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_gemm_batched_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_winograd_output": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mrcnn_winograd_dy": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mrcnn_winograd_dw": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_winograd_output_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_allreduce_load": (C.c_int, [C.c_char_p]),
     "mrcnn_allreduce_unique_id": (C.c_int, [_P]),

@@ -225,6 +225,69 @@ __global__ __launch_bounds__(256) void winograd_output_bwd_kernel(const float* _
     }
 }
 
+// Weight gradient through the same domain: dU[xi] = V[xi]^T . dM[xi] (16 GEMMs contracting over the tiles: 1 x 1 weight
+// gradients for the float32 weight-gradient kernel), with V = B^T d B the forward's input transform (kept from the forward
+// pass) and dM = A dy A^T the ADJOINT of the output transform, A = [1 0; 1 1; 1 -1; 0 -1]; then dW = G^T dU G.
+__global__ __launch_bounds__(256) void winograd_dy_kernel(const float* __restrict__ dy, float* __restrict__ dM, int N, int H, int W, int C,
+                                                          long long T, long long Tp) {
+    const int c4n = C >> 2;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * c4n) return;
+    const long long t = i / c4n;
+    const int c = (int)(i - t * c4n) * 4;
+    const int tw_n = W >> 1, th_n = H >> 1;
+    const int tw = (int)(t % tw_n);
+    const long long q = t / tw_n;
+    const int th = (int)(q % th_n);
+    const int n = (int)(q / th_n);
+    f32x4 d[2][2], u[4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) d[a][b] = *(const f32x4*)(dy + (((long long)n * H + 2 * th + a) * W + 2 * tw + b) * C + c);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {                // rows: A d
+        u[0][b] = d[0][b];
+        u[1][b] = d[0][b] + d[1][b];
+        u[2][b] = d[0][b] - d[1][b];
+        u[3][b] = -d[1][b];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                // columns: (A d) A^T
+        const f32x4 m0 = u[r][0], m1 = u[r][0] + u[r][1], m2 = u[r][0] - u[r][1], m3 = -u[r][1];
+        *(f32x4*)(dM + ((long long)(r * 4 + 0) * Tp + t) * C + c) = m0;
+        *(f32x4*)(dM + ((long long)(r * 4 + 1) * Tp + t) * C + c) = m1;
+        *(f32x4*)(dM + ((long long)(r * 4 + 2) * Tp + t) * C + c) = m2;
+        *(f32x4*)(dM + ((long long)(r * 4 + 3) * Tp + t) * C + c) = m3;
+    }
+}
+
+// dW [3][3][ci][co] (= or +=) G^T dU G, dU [16][ci][co]; one thread per (ci, co)
+__global__ __launch_bounds__(256) void winograd_dw_kernel(const float* __restrict__ dU, float* dW, int Cin, int Cout, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n = (long long)Cin * Cout;
+    if (i >= n) return;
+    float u[4][4], t[3][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) u[a][b] = dU[(long long)(a * 4 + b) * n + i];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {                // G^T = [1 1/2 1/2 0; 0 1/2 -1/2 0; 0 1/2 1/2 1]
+        t[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
+        t[1][b] = 0.5f * (u[1][b] - u[2][b]);
+        t[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float w0 = t[a][0] + 0.5f * (t[a][1] + t[a][2]), w1 = 0.5f * (t[a][1] - t[a][2]), w2 = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+        float* o = dW + (long long)(a * 3) * n + i;
+        o[0] = accumulate ? o[0] + w0 : w0;
+        o[n] = accumulate ? o[n] + w1 : w1;
+        o[2 * n] = accumulate ? o[2 * n] + w2 : w2;
+    }
+}
+
 static inline long long wino_tiles(int N, int H, int W) { return (long long)N * (H >> 1) * (W >> 1); }
 static inline long long wino_rows(long long T) { return (T + 127) / 128 * 128; }      // rows per transform-domain matrix: whole 128-row tiles
 
@@ -276,5 +339,20 @@ extern "C" int mrcnn_winograd_output_bwd(const float* Mt, float* dz_below, const
     per = (per + R - 1) / R * R;
     hipLaunchKernelGGL(winograd_output_bwd_kernel, dim3((unsigned)cdiv64(T, per)), dim3(256), 0, (hipStream_t)stream, Mt, dz_below, below_out,
                        below_z, scale, mean, rstd, dgamma, dbeta, dbias, N, H, W, C, T, wino_rows(T), act, per, lg);
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_winograd_dy(const float* dy, float* dM, int N, int H, int W, int C, void* stream) {
+    if (!dy || !dM || !wino_shape_ok(N, H, W, C)) return MRCNN_ERR_ARG;
+    const long long T = wino_tiles(N, H, W);
+    hipLaunchKernelGGL(winograd_dy_kernel, dim3((unsigned)cdiv64(T * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, dy, dM, N, H, W, C, T,
+                       wino_rows(T));
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_winograd_dw(const float* dU, float* dw_hwio, int Cin, int Cout, int accumulate, void* stream) {
+    if (!dU || !dw_hwio || Cin <= 0 || Cout <= 0) return MRCNN_ERR_ARG;
+    hipLaunchKernelGGL(winograd_dw_kernel, dim3((unsigned)cdiv64((long long)Cin * Cout, 256)), dim3(256), 0, (hipStream_t)stream, dU, dw_hwio,
+                       Cin, Cout, accumulate);
     return mrcnn_launch_status();
 }

@@ -229,6 +229,8 @@ class MaskRCNNEngine(object):
         # Winograd F(2x2, 3x3) for the float32 3x3 convolutions of the mask head (forward and data gradients): 2.25 x fewer
         # matrix-core flops through three launches per layer; MRCNN_WINOGRAD=0 keeps the direct kernels
         self.winograd = os.environ.get("MRCNN_WINOGRAD", "1") != "0"
+        self.winograd_wgrad = os.environ.get("MRCNN_WINOGRAD_WGRAD", "1") != "0"    # weight gradients through the same domain
+        self._wino_V = {}               # layer -> input transform V of this step's forward pass
         self._wino = {}                 # layer -> [U forward, U data gradient] (allocated once, refreshed after weight updates)
         self._wino_valid = {}           # layer -> [forward valid, data-gradient valid]
         self._h16_store = {}            # dtype -> {layer: (W^T image, data-gradient image)}, stable addresses
@@ -578,6 +580,18 @@ class MaskRCNNEngine(object):
             self._deferred.append((kind, args))
         elif kind == "f32":
             self.wgrad_async(*args)
+        elif kind == "wino":
+            V, xshape, dz, dw = args
+            ws = self.wgrad_stream
+            if ws is None:
+                ops.conv2d_wgrad_winograd(V, xshape, dz, dw)
+                return
+            ev = _hip_mod.ev_record(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(ws):
+                _hip_mod.ev_wait(ws, ev)
+                ops.conv2d_wgrad_winograd(V, xshape, dz, dw)
+            dz.record_stream(ws)
+            V.record_stream(ws)
         else:
             self.wgrad_h16_async(*args)
 
@@ -596,6 +610,9 @@ class MaskRCNNEngine(object):
                     if kind == "f32":
                         x, dz, wshape, stride, padding, dw, acc = a
                         ops.conv2d_wgrad(x, dz, wshape, stride, padding, dw=dw, accumulate=acc)
+                    elif kind == "wino":
+                        x, xshape, dz, dw = a
+                        ops.conv2d_wgrad_winograd(x, xshape, dz, dw)
                     else:
                         x, dz, wshape, dw, mult = a
                         ops.conv2d_wgrad_h16(x, dz, wshape, 1, "same", dw=dw, multiplier=mult)
@@ -825,7 +842,11 @@ class MaskRCNNEngine(object):
                 if self._wino_ok(op, x.shape):
                     out = ops.empty(tuple(x.shape[:3]) + (op.wshape[3],), torch.float32, self.dev)
                     z = ops.empty_like(out) if (train and op.bn) else None
-                    ops.conv2d_winograd(x, self._wino_U(op, 0), op.b, op.scale, op.shift, ACT_RELU, out=out, z_out=z)
+                    # training keeps the input transform: the layer's weight gradient contracts it with the transformed dz
+                    V = ops.empty((ops.winograd_v_floats(tuple(x.shape)),), torch.float32, self.dev) if (train and self.winograd_wgrad) else None
+                    if V is not None:
+                        self._wino_V[op.name] = V
+                    ops.conv2d_winograd(x, self._wino_U(op, 0), op.b, op.scale, op.shift, ACT_RELU, out=out, z_out=z, keep_v=V)
                     x, c = out, ((x, z, out, ACT_RELU) if train else None)
                 else:
                     x, c = op.forward(x, ACT_RELU, train=train)
@@ -1109,7 +1130,11 @@ class MaskRCNNEngine(object):
             chain = [(self.op("mrcnn_mask_conv%d" % i), c) for i, c in ((4, c4), (3, c3), (2, c2), (1, c1))]
             dz = self._dgrad_ep(dzg, dc.wt, "valid", chain[0][0], chain[0][1])
             for k, (op, c) in enumerate(chain):
-                self._mask_wgrad("f32", *op.wgrad_item(dz, c))
+                V = self._wino_V.pop(op.name, None)
+                if V is not None and self.winograd_wgrad and self._wino_ok(op, c[0].shape):
+                    self._mask_wgrad("wino", V, tuple(c[0].shape), dz, op.dw)
+                else:
+                    self._mask_wgrad("f32", *op.wgrad_item(dz, c))
                 kh, kw, cin, cout = op.wshape
                 wino = self._wino_ok(op, c[0].shape)
                 if wino and not self.wt_valid:

@@ -684,27 +684,34 @@ def winograd_weights(w, out=None):
     return out
 
 
-def _winograd_product(x, U):
-    """Input transform + the 16 transform-domain GEMMs; returns Mt (a per-stream scratch buffer, valid until the next call)."""
+def _winograd_product(x, U, keep_v=None):
+    """Input transform + the 16 transform-domain GEMMs; returns Mt (a per-stream scratch buffer, valid until the next call).
+    keep_v: a float32 tensor of mrcnn_winograd_buffer_floats elements that receives V (the weight gradient reuses it)."""
     N, H, W, Cin = x.shape
     cout = U.shape[2]
     lib = _hip.lib()
     nv, nm = lib.mrcnn_winograd_buffer_floats(N, H, W, Cin), lib.mrcnn_winograd_buffer_floats(N, H, W, cout)
-    V = workspace(nv * 4, x.device, "winograd_v")
+    V = keep_v if keep_v is not None else workspace(nv * 4, x.device, "winograd_v")
+    assert keep_v is None or (keep_v.numel() == nv and keep_v.dtype == torch.float32)
     Mt = workspace(nm * 4, x.device, "winograd_m")
     check(lib.mrcnn_winograd_input(ptr(x), ptr(V), N, H, W, Cin, current_stream()), "mrcnn_winograd_input")
     check(lib.mrcnn_gemm_batched_f32(ptr(V), ptr(U), ptr(Mt), 16, nv // (16 * Cin), Cin, cout, current_stream()), "mrcnn_gemm_batched_f32")
     return Mt
 
 
-def conv2d_winograd(x, U, bias=None, scale=None, shift=None, act=ACT_NONE, out=None, z_out=None):
+def winograd_v_floats(xshape):
+    N, H, W, Cin = xshape
+    return _hip.lib().mrcnn_winograd_buffer_floats(N, H, W, Cin)
+
+
+def conv2d_winograd(x, U, bias=None, scale=None, shift=None, act=ACT_NONE, out=None, z_out=None, keep_v=None):
     """3 x 3 'same' stride-1 convolution with its epilogue through the Winograd domain (U = winograd_weights(w))."""
-    _need_cuda(x, U, bias, scale, shift, out, z_out)
+    _need_cuda(x, U, bias, scale, shift, out, z_out, keep_v)
     N, H, W, _ = x.shape
     cout = U.shape[2]
     if out is None:
         out = empty((N, H, W, cout), torch.float32, x.device)
-    Mt = _winograd_product(x, U)
+    Mt = _winograd_product(x, U, keep_v)
     check(_hip.lib().mrcnn_winograd_output(ptr(Mt), ptr(out), ptr(z_out), ptr(bias), ptr(scale), ptr(shift), N, H, W, cout, act,
                                            current_stream()), "mrcnn_winograd_output")
     return out
@@ -722,6 +729,27 @@ def conv2d_dgrad_ep_winograd(dz, Ut, below_out, below_z, scale, mean, rstd, dgam
                                                ptr(dgamma), ptr(dbeta), ptr(dbias), N, H, W, cout, act, current_stream()),
           "mrcnn_winograd_output_bwd")
     return out
+
+
+def conv2d_wgrad_winograd(V, xshape, dz, dw, accumulate=False):
+    """Weight gradient of a 3 x 3 'same' convolution through the Winograd domain: V = the forward's input transform of x
+    (conv2d_winograd(..., keep_v=V)), dz [N, H, W, Cout] -> dw [3, 3, Cin, Cout] float32."""
+    _need_cuda(V, dz, dw)
+    N, H, W, Cin = xshape
+    cout = dz.shape[3]
+    lib = _hip.lib()
+    nm = lib.mrcnn_winograd_buffer_floats(N, H, W, cout)
+    rows = nm // (16 * cout)
+    T = N * (H // 2) * (W // 2)
+    dM = workspace(nm * 4, dz.device, "winograd_dm")[:nm * 4].view(torch.float32).view(16, rows, cout)
+    dU = workspace(16 * Cin * cout * 4, dz.device, "winograd_du")[:16 * Cin * cout * 4].view(torch.float32).view(16, Cin, cout)
+    check(lib.mrcnn_winograd_dy(ptr(dz), ptr(dM), N, H, W, cout, current_stream()), "mrcnn_winograd_dy")
+    Vv = V.view(16, rows, Cin)
+    for k in range(16):
+        conv2d_wgrad(Vv[k, :T].view(T, 1, 1, Cin), dM[k, :T].view(T, 1, 1, cout), (1, 1, Cin, cout), 1, "valid",
+                     dw=dU[k].view(1, 1, Cin, cout))
+    check(lib.mrcnn_winograd_dw(ptr(dU), ptr(dw), Cin, cout, 1 if accumulate else 0, current_stream()), "mrcnn_winograd_dw")
+    return dw
 
 
 def h16_image_table(params, entries, device):

@@ -402,6 +402,10 @@ int mrcnn_winograd_input(const float* x, float* V, int N, int H, int W, int C, v
 int mrcnn_gemm_batched_f32(const float* V, const float* U, float* Mt, int nb, int rows, int K, int Cout, void* stream);
 int mrcnn_winograd_output(const float* Mt, float* out, float* z_out, const float* bias, const float* scale, const float* shift,
                           int N, int H, int W, int C, int act, void* stream);
+/* weight gradient: dM = A dy A^T (adjoint of the output transform) [16][rows][C]; dU[xi] = V[xi]^T . dM[xi] are 16 1 x 1 weight
+ * gradients (mrcnn_conv2d_wgrad on the first `tiles` rows of each matrix); dW = G^T dU G (accumulate != 0: added to dW).       */
+int mrcnn_winograd_dy(const float* dy, float* dM, int N, int H, int W, int C, void* stream);
+int mrcnn_winograd_dw(const float* dU, float* dw_hwio, int Cin, int Cout, int accumulate, void* stream);
 int mrcnn_winograd_output_bwd(const float* Mt, float* dz_below, const float* below_out, const float* below_z, const float* scale,
                               const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H, int W,
                               int C, int act, void* stream);

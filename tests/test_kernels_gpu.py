@@ -123,9 +123,22 @@ def test_conv_winograd(dev, case):
     torch.cuda.synchronize()
     torch.testing.assert_close(y.cpu(), y_ref, **F32)
     torch.testing.assert_close(z.cpu(), z_ref, **F32)
-    y0 = ops.conv2d_winograd(xt, U)                              # no epilogue at all (the last data gradient of the chain)
+    V = torch.empty(ops.winograd_v_floats((N, H, W, Cin)), device=dev)
+    y0 = ops.conv2d_winograd(xt, U, keep_v=V)                    # no epilogue at all (the last data gradient of the chain)
     torch.cuda.synchronize()
     torch.testing.assert_close(y0.cpu(), z_ref - torch.tensor(b), **F32)
+    # weight gradient through the same domain: V kept from the forward pass, dz transformed by the output transform's adjoint
+    xg = torch.tensor(x); wg = torch.tensor(w, requires_grad=True)
+    yy = orc.conv2d_nhwc(xg, wg, None, 1, "same")
+    dy = _rand(rng, N, H, W, Cout)
+    yy.backward(torch.tensor(dy))
+    dw = torch.full((3, 3, Cin, Cout), 7.0, device=dev)
+    ops.conv2d_wgrad_winograd(V, (N, H, W, Cin), torch.tensor(dy, device=dev), dw)
+    torch.cuda.synchronize()
+    assert float((dw.cpu() - wg.grad).abs().max()) <= 5e-4 * float(wg.grad.abs().max())
+    ops.conv2d_wgrad_winograd(V, (N, H, W, Cin), torch.tensor(dy, device=dev), dw, accumulate=True)
+    torch.cuda.synchronize()
+    assert float((dw.cpu() - 2 * wg.grad).abs().max()) <= 1e-3 * float(wg.grad.abs().max())
     if Cin % 128:
         return
     # data gradient of a Cout -> Cin layer + epilogue backward of the layer below (Cin channels, frozen BN, ReLU)
