@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_blds_kernel(const WgradArgs
 
 // Up to WGRAD_MULTI_MAX weight gradients in one launch (mrcnn_conv2d_wgrad_multi): the three convolutions of a
 // bottleneck block.  Workgroups first[g] .. first[g+1]-1 belong to problem g; the slab reductions share a launch too.
-#define WGRAD_MULTI_MAX 4
+#define WGRAD_MULTI_MAX 16      // 4 covers a bottleneck block; 16 = the transform-domain weight gradients of a Winograd layer
 struct WgradMultiArgs {
     WgradArgs a[WGRAD_MULTI_MAX];
     unsigned x_shift[WGRAD_MULTI_MAX], x_records[WGRAD_MULTI_MAX];
@@ -633,7 +633,8 @@ static bool plan_wgrad_multi(const mrcnn_wgrad_problem* pr, int n, WgradMultiPla
             return false;
         const long long M = (long long)d.N * d.OH * d.OW;
         const long long Ktot = (long long)d.KH * d.KW * d.Cin;
-        if (d.Cin % 128 || d.Cout % 128 || d.KH * d.KW > 64 || M >= WGRAD_TABLE_MIN_PIXELS) return false;
+        const bool gemm = d.KH == 1 && d.KW == 1 && d.H == 1 && d.W == 1 && d.stride == 1;     // pure GEMM rows: no pixel decomposition to pay for
+        if (d.Cin % 128 || d.Cout % 128 || d.KH * d.KW > 64 || (M >= WGRAD_TABLE_MIN_PIXELS && !gemm)) return false;
         const long long xbytes = (long long)d.N * d.H * d.W * d.Cin * 4;
         const long long shift = ((long long)d.pad_t * d.W + d.pad_l) * d.Cin * 4;
         if (xbytes + shift + 16LL * d.H * d.W * d.Cin * 4 >= 0x7FFFFFF0LL || M * d.Cout * 4 >= 0x7FFFFFF0LL) return false;

@@ -745,9 +745,11 @@ def conv2d_wgrad_winograd(V, xshape, dz, dw, accumulate=False):
     dU = workspace(16 * Cin * cout * 4, dz.device, "winograd_du")[:16 * Cin * cout * 4].view(torch.float32).view(16, Cin, cout)
     check(lib.mrcnn_winograd_dy(ptr(dz), ptr(dM), N, H, W, cout, current_stream()), "mrcnn_winograd_dy")
     Vv = V.view(16, rows, Cin)
-    for k in range(16):
-        conv2d_wgrad(Vv[k, :T].view(T, 1, 1, Cin), dM[k, :T].view(T, 1, 1, cout), (1, 1, Cin, cout), 1, "valid",
-                     dw=dU[k].view(1, 1, Cin, cout))
+    items = [(Vv[k, :T].view(T, 1, 1, Cin), dM[k, :T].view(T, 1, 1, cout), (1, 1, Cin, cout), 1, "valid", dU[k].view(1, 1, Cin, cout), False)
+             for k in range(16)]
+    if not conv2d_wgrad_multi(items):                          # one launch for the 16 GEMMs (+ one for their slab reductions)
+        for x_, dy_, wshape, stride, padding, dw_, acc in items:
+            conv2d_wgrad(x_, dy_, wshape, stride, padding, dw=dw_, accumulate=acc)
     check(lib.mrcnn_winograd_dw(ptr(dU), ptr(dw), Cin, cout, 1 if accumulate else 0, current_stream()), "mrcnn_winograd_dw")
     return dw
 
