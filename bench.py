@@ -196,6 +196,7 @@ def _train_loop_leg(args, res, model, cfg, nimg, world, rank):
 
 TRAFFIC_PER_LAUNCH = {1024: None, 2048: 1.810e9}   # mask-head conv, PMC passes: profiles/r01_pmc_conv_traffic.md
 TRAFFIC_WGRAD_PER_LAUNCH = {1024: None, 2048: 4.55e9}   # its weight gradient (same file)
+TRAFFIC_WINOGRAD_GEMM = {2048: None}   # batched transform-domain GEMM (profiles/r02_pmc_winograd.txt once measured)
 
 
 def measure(args, backbone, nimg, rank, local_rank, world, full):
@@ -376,14 +377,20 @@ def _detect_leg(args, res, eng, dev_inputs, dev, backbone, run_py_config, torch)
 
 
 def _roofline_leg(res, ops, torch, dev, nimg, cfg):
-    # ---- roofline of the dominant kernel: the mask-head 3x3 convolution (fwd instance) --------------
+    """Rooflines of the kernels that dominate the headline step, timed live with HIP events on the launch stream.
+    Since the Winograd F(2x2,3x3) path the mask head's eight 3x3 forward / data-gradient convolutions and its
+    four 3x3 weight gradients run as transform-domain GEMMs: `roofline` = the batched GEMM launch of the LDS-DMA kernel
+    (9 launches per step incl. the transposed convolution, ~20 of the ~47 ms), `roofline_wgrad` = the 16 weight-gradient GEMMs
+    of a layer in one multi-problem launch.  The direct 3x3 kernels (detect, small ROI counts, MRCNN_WINOGRAD=0) keep their
+    objects as `roofline_direct_conv` / `roofline_direct_wgrad`."""
     M_rois = nimg * cfg.TRAIN_ROIS_PER_IMAGE
-    xm = torch.randn((M_rois, 14, 14, 256), device=dev)
-    wm = torch.randn((3, 3, 256, 256), device=dev) * 0.02
-    bm = torch.zeros(256, device=dev)
-    sc = torch.ones(256, device=dev)
-    om = torch.empty((M_rois, 14, 14, 256), device=dev)
-    zm = torch.empty((M_rois, 14, 14, 256), device=dev)
+    C_ = 256
+    xm = torch.randn((M_rois, 14, 14, C_), device=dev)
+    wm = torch.randn((3, 3, C_, C_), device=dev) * 0.02
+    bm = torch.zeros(C_, device=dev)
+    sc = torch.ones(C_, device=dev)
+    om = torch.empty((M_rois, 14, 14, C_), device=dev)
+    zm = torch.empty((M_rois, 14, 14, C_), device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     reps = 20
 
@@ -396,29 +403,70 @@ def _roofline_leg(res, ops, torch, dev, nimg, cfg):
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / reps
-    # the variant the training step's forward pass launches: the pre-BatchNorm output z is stored too (the backward pass needs
-    # it); and the bare variant (no second store: what the data gradients and detect launch), reported beside it
+    peak = 157.3
+    flops_direct = 2.0 * (M_rois * 196) * C_ * 9 * C_          # the layer as a direct convolution
+    T = M_rois * 49                                            # 2 x 2 output tiles
+    flops_gemm = 2.0 * 16 * T * C_ * C_                        # what the transform-domain GEMMs multiply (2.25 x fewer)
+    lib = ops._hip.lib()
+    nv = lib.mrcnn_winograd_buffer_floats(M_rois, 14, 14, C_)
+    rows = nv // (16 * C_)
+    V = torch.empty(nv, device=dev); Mt = torch.empty(nv, device=dev)
+    U = ops.winograd_weights(wm)
+    st = ops.current_stream
+    P = ops.ptr
+    t_in = timed_ms(lambda: lib.mrcnn_winograd_input(P(xm), P(V), M_rois, 14, 14, C_, st()))
+    t_gemm = timed_ms(lambda: lib.mrcnn_gemm_batched_f32(P(V), P(U), P(Mt), 16, rows, C_, C_, st()))
+    t_out = timed_ms(lambda: lib.mrcnn_winograd_output(P(Mt), P(om), P(zm), P(bm), P(sc), P(bm), M_rois, 14, 14, C_, 1, st()))
+    t_layer = timed_ms(lambda: ops.conv2d_winograd(xm, U, bm, sc, bm, 1, out=om, z_out=zm))
+    ach = flops_gemm / (t_gemm * 1e-3) / 1e12
+    res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                       "traffic": TRAFFIC_WINOGRAD_GEMM.get(M_rois),
+                       "kernel": "conv_fwd_blds_kernel as mrcnn_gemm_batched_f32: the 16 transform-domain GEMMs [%d x 256] . [256 x 256] of "
+                                 "a Winograd F(2x2,3x3) mask-head layer in one launch (128x128 tiles, K = 256: %.1f GFLOP/launch, "
+                                 "%.3f ms/launch)" % (T, flops_gemm / 1e9, t_gemm),
+                       "layer_ms": {"input_transform": round(t_in, 3), "gemm": round(t_gemm, 3), "output_transform_with_epilogue": round(t_out, 3),
+                                    "whole_layer": round(t_layer, 3)},
+                       "layer_equivalent_direct_tflops": round(flops_direct / (t_layer * 1e-3) / 1e12, 2),
+                       "note": "the layer computes what a direct 3x3 convolution of %.1f GFLOP computes (2.3e-6 of its result) with "
+                               "%.1f GFLOP of MFMA work plus two memory-bound transform passes; layer_equivalent_direct_tflops = the "
+                               "direct convolution's flops over the whole layer's time (a rate the direct kernel would need, not one "
+                               "the matrix cores run at)" %
+                               (flops_direct / 1e9, flops_gemm / 1e9)}
+    # the direct kernel (detect, small ROI counts): the variant with the pre-BN z store and the bare one
     k_ms = timed_ms(lambda: ops.conv2d(xm, wm, bm, sc, bm, act=1, out=om, z_out=zm))
     k_ms_bare = timed_ms(lambda: ops.conv2d(xm, wm, bm, sc, bm, act=1, out=om))
-    flops = 2.0 * (M_rois * 196) * 256 * 2304
-    achieved = flops / (k_ms * 1e-3) / 1e12
-    peak = 157.3
-    res["roofline"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                       "frac": round(achieved / peak, 4),
-                       # HBM-side bytes per launch from rocprofv3 PMC passes on this shape:
-                       # 2*FETCH_SIZE + WRITE_SIZE, profiles/r01_pmc_conv_traffic.md (not re-measured per run)
-                       "traffic": TRAFFIC_PER_LAUNCH.get(M_rois),
-                       "achieved_without_z_store": round(flops / (k_ms_bare * 1e-3) / 1e12, 2),
-                       "kernel": "conv_fwd_blds_kernel, 128x128 tile (mask-head 3x3 conv as the training forward launches it: "
-                                 "activated output + pre-BN z stored; M=%d N=256 K=2304, %.1f GFLOP/launch, %.3f ms/launch; "
-                                 "%.3f ms without the z store)" % (M_rois * 196, flops / 1e9, k_ms, k_ms_bare)}
-    # the second dominant kernel: the weight gradient of the same layer (5 launches per step), same accounting
-    dym = torch.randn((M_rois, 14, 14, 256), device=dev)
-    dwm = torch.empty((3, 3, 256, 256), device=dev)
-    w_ms = timed_ms(lambda: ops.conv2d_wgrad(xm, dym, (3, 3, 256, 256), 1, "same", dw=dwm))
-    w_ach = flops / (w_ms * 1e-3) / 1e12
-    # what the step gets: in the backward pass a layer's data gradient (main stream) and weight gradient (side stream) run
-    # side by side; the pair's sustained rate is the in-step figure for both kernels
+    achieved = flops_direct / (k_ms * 1e-3) / 1e12
+    res["roofline_direct_conv"] = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                                   "frac": round(achieved / peak, 4), "traffic": TRAFFIC_PER_LAUNCH.get(M_rois),
+                                   "achieved_without_z_store": round(flops_direct / (k_ms_bare * 1e-3) / 1e12, 2),
+                                   "kernel": "conv_fwd_blds_kernel, 128x128 tile, direct 3x3 (M=%d N=256 K=2304, %.1f GFLOP/launch, %.3f "
+                                             "ms/launch with the z store, %.3f without)" % (M_rois * 196, flops_direct / 1e9, k_ms, k_ms_bare)}
+    # weight gradient of the same layer: Winograd form (dy transform + 16 GEMMs in one multi-problem launch + slab reduction +
+    # dW transform), and the direct kernel
+    dym = torch.randn((M_rois, 14, 14, C_), device=dev)
+    dwm = torch.empty((3, 3, C_, C_), device=dev)
+    ops.conv2d_winograd(xm, U, keep_v=V)
+    wl_ms = timed_ms(lambda: ops.conv2d_wgrad_winograd(V, (M_rois, 14, 14, C_), dym, dwm))
+    dM = torch.randn((16, rows, C_), device=dev); dU = torch.empty((16, C_, C_), device=dev)
+    Vv = V.view(16, rows, C_)
+    items = [(Vv[k, :T].view(T, 1, 1, C_), dM[k, :T].view(T, 1, 1, C_), (1, 1, C_, C_), 1, "valid", dU[k].view(1, 1, C_, C_), False)
+             for k in range(16)]
+    wg_ms = timed_ms(lambda: ops.conv2d_wgrad_multi(items))
+    w_ach = flops_gemm / (wg_ms * 1e-3) / 1e12
+    res["roofline_wgrad"] = {"bound": "mfma", "achieved": round(w_ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(w_ach / peak, 4),
+                             "traffic": None,
+                             "kernel": "conv_wgrad_blds_multi_kernel<16>: the 16 transform-domain weight-gradient GEMMs [256 x %d] . [%d x 256] "
+                                       "of a Winograd layer in one launch + their slab reduction (%.1f GFLOP, %.3f ms)" %
+                                       (T, T, flops_gemm / 1e9, wg_ms),
+                             "layer_ms": round(wl_ms, 3),
+                             "layer_equivalent_direct_tflops": round(flops_direct / (wl_ms * 1e-3) / 1e12, 2)}
+    w_ms = timed_ms(lambda: ops.conv2d_wgrad(xm, dym, (3, 3, C_, C_), 1, "same", dw=dwm))
+    res["roofline_direct_wgrad"] = {"bound": "mfma", "achieved": round(flops_direct / (w_ms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                                    "frac": round(flops_direct / (w_ms * 1e-3) / 1e12 / peak, 4),
+                                    "traffic": TRAFFIC_WGRAD_PER_LAUNCH.get(M_rois),
+                                    "kernel": "conv_wgrad_blds_kernel<16,true> + pixel table + slab reduction, direct 3x3 (%.1f "
+                                              "GFLOP/launch, %.3f ms/launch)" % (flops_direct / 1e9, w_ms)}
+    # what the step gets: a layer's data gradient (main stream) and weight gradient (side stream) run side by side
     from caesar_mrcnn_amd.engine import _side_streams
     side = _side_streams(dev)[0]                        # the engines' weight-gradient stream (one per process)
     main = torch.cuda.current_stream(dev)
@@ -426,19 +474,13 @@ def _roofline_leg(res, ops, torch, dev, nimg, cfg):
     def pair():
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            ops.conv2d_wgrad(xm, dym, (3, 3, 256, 256), 1, "same", dw=dwm)
-        ops.conv2d(xm, wm, bm, sc, bm, act=1, out=om)
+            ops.conv2d_wgrad_winograd(V, (M_rois, 14, 14, C_), dym, dwm)
+        ops.conv2d_winograd(xm, U, bm, sc, bm, 1, out=om)
         main.wait_stream(side)
     p_ms = timed_ms(pair)
-    res["roofline"]["achieved_beside_wgrad_stream"] = round(2 * flops / (p_ms * 1e-3) / 1e12, 2)
-    res["roofline"]["note_in_step"] = ("achieved = the forward variant with the z store, alone on the chip; "
-                                       "achieved_beside_wgrad_stream = data gradient + weight gradient of the layer on two streams "
-                                       "(2 x %.1f GFLOP in %.3f ms), the rate both kernels sustain inside the step" % (flops / 1e9, p_ms))
-    res["roofline_wgrad"] = {"bound": "mfma", "achieved": round(w_ach, 2), "peak": peak, "unit": "TFLOP/s",
-                             "frac": round(w_ach / peak, 4), "traffic": TRAFFIC_WGRAD_PER_LAUNCH.get(M_rois),
-                             "kernel": "conv_wgrad_blds_kernel<16,true> + pixel table + slab reduction (same layer, "
-                                       "%.1f GFLOP/launch, %.3f ms/launch)" % (flops / 1e9, w_ms)}
-    del xm, om, dym
+    res["roofline"]["pair_beside_wgrad_stream_ms"] = round(p_ms, 3)
+    res["roofline"]["pair_equivalent_direct_tflops"] = round(2 * flops_direct / (p_ms * 1e-3) / 1e12, 2)
+    del xm, om, dym, V, Mt, dM
 
 
 def measure_config4(args, rank, local_rank, world):
@@ -612,8 +654,9 @@ def main():
             "losses_last_step": [round(v, 5) for v in r["losses"]],
             "roofline": r["roofline"],
         }
-        if "roofline_wgrad" in r:
-            out["roofline_wgrad"] = r["roofline_wgrad"]
+        for k in ("roofline_wgrad", "roofline_direct_conv", "roofline_direct_wgrad"):
+            if k in r:
+                out[k] = r[k]
         if "train_loop" in r:
             out["train_loop"] = r["train_loop"]
         if "allreduce" in r:
