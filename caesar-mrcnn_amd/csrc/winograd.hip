@@ -9,6 +9,7 @@
 // (B^T, A^T have entries 0, +-1; G has 0, 1, +-1/2), so the result differs from the direct kernel by summation order only.
 // H and W even (mask head: 14 x 14).
 #include "common.h"
+#include <type_traits>
 
 // B^T d B for one 4 x 4 tile held as d[r][c] (float4 = 4 channels per thread)
 __device__ __forceinline__ void wino_bt_d_b(const f32x4 d[4][4], f32x4 v[4][4]) {
@@ -288,6 +289,124 @@ __global__ __launch_bounds__(256) void winograd_dw_kernel(const float* __restric
     }
 }
 
+// ---- the 16 transform-domain GEMMs, persistent form ----------------------------------------------------------------------------
+// V [nb][rows][K] . U [nb][K][N] -> Mt [nb][rows][N] with the tile, LDS image and MFMA loop of conv_fwd_blds_kernel (128 x 128
+// tile, K-step 16, both operands by buffer-addressed LDS-DMA, A chunks XOR-swizzled on the source side), but workgroups that
+// walk tiles blockIdx.x, + gridDim.x, ...: K is only 256 here (16 K-steps per tile), so the one-tile-per-workgroup kernel spends
+// ~26 % of a launch in phases where every resident workgroup of a CU is storing its tile or waiting for its first stage at the
+// same time (tools/gemm_k_probe.py: 0.15 ms fixed + 1.5 us per unit of K over 4.9 rounds).  Here the first stage of the NEXT
+// tile is on its way before the stores of the current tile are issued, and the workgroups of a CU drift apart.
+typedef __attribute__((address_space(3))) void* wino_lds_ptr;
+#define WINO_OOB 0xFFFFFFF0u
+
+__global__ __launch_bounds__(256, 2) void winograd_gemm_kernel(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ Mt,
+                                                               int rows, int K, int N, int total_tiles, unsigned v_records) {
+    constexpr int BM = 128, BN = 128, BK = 16, TM = 2, TN = 2;
+    constexpr int AF = BM * BK, BF = BK * BN;
+    __shared__ __attribute__((aligned(16))) float lds[2 * (AF + BF)];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = N / BN;
+    const int nk = K / BK;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)V, 0, v_records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)U, 0, 0x7FFFFFF0u, 0x00020000);
+
+    // per tile: lane offsets of the two A pieces (16 rows x 64 bytes each) and the B pieces (2 k-rows x 512 bytes each)
+    unsigned a_voff[2], b_voff[2];
+    int m0 = 0, n0 = 0;
+    auto setup = [&](int tile) {
+        const int mtile = tile / ntiles, ntile = tile - mtile * ntiles;
+        m0 = mtile * BM; n0 = ntile * BN;
+        const unsigned wbase = (unsigned)(((long long)(m0 / rows) * K * N + n0) * 4);      // the tile's weight matrix (U [nb][K][N], < 2 GiB)
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const int r = (wave + jj * 4) * 16 + (lane >> 2);
+            const int cl = (lane & 3) ^ ((r >> 2) & 3);
+            a_voff[jj] = (unsigned)(((long long)(m0 + r) * K + cl * 4) * 4);
+            b_voff[jj] = wbase + (unsigned)((((wave + jj * 4) * 2 + (lane >> 5)) * N + (lane & 31) * 4) * 4);
+        }
+    };
+    int k0 = 0;
+    auto stage = [&](float* ab) {
+        float* bb = ab + AF;
+        const unsigned soff_a = (unsigned)(k0 * 4), soff_b = (unsigned)(k0 * N * 4);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (wino_lds_ptr)(ab + (wave + jj * 4) * 256), 16, a_voff[jj], soff_a, 0, 0);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (wino_lds_ptr)(bb + (wave + jj * 4) * 256), 16, b_voff[jj], soff_b, 0, 0);
+        k0 += BK;
+    };
+    f32x16 acc[TM][TN];
+    const int li = lane & 31, lh = lane >> 5;
+    const int row0 = wm * 64 + li;
+    const float* a_rd0 = lds + row0 * BK + (((2 * lh + 0) ^ ((row0 >> 2) & 3)) << 2);
+    const float* a_rd1 = lds + row0 * BK + (((2 * lh + 1) ^ ((row0 >> 2) & 3)) << 2);
+    const float* b_rd = lds + AF + lh * 8 * BN + wn * 64 + li;
+    auto compute = [&](auto curc) {
+        constexpr int BO = decltype(curc)::value * (AF + BF);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 av[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) av[a] = *(const f32x4*)((q ? a_rd1 : a_rd0) + BO + a * 32 * BK);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float bv[TN];
+#pragma unroll
+                for (int b = 0; b < TN; ++b) bv[b] = b_rd[BO + (q * 4 + e) * BN + b * 32];
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][e], bv[b], acc[a][b], 0, 0, 0);
+            }
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+
+    int tile = blockIdx.x;
+    setup(tile);
+    stage(lds);
+    for (;;) {
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        __syncthreads();
+        for (int ks = 0; ks < nk; ks += 2) {
+            if (ks + 1 < nk) stage(lds + (AF + BF));
+            compute(I0{});
+            __syncthreads();
+            if (ks + 1 < nk) {
+                if (ks + 2 < nk) stage(lds);
+                compute(I1{});
+                __syncthreads();
+            }
+        }
+        const int mw0 = m0 + wm * 64 + 4 * lh, nw0 = n0 + wn * 64 + li;       // the tile the accumulators belong to
+        const int next = tile + (int)gridDim.x;
+        const bool more = next < total_tiles;
+        if (more) { k0 = 0; setup(next); stage(lds); }                         // its first stage travels under this tile's stores
+        const int Mtot = (int)(v_records / (unsigned)(K * 4));
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mw0 + a * 32 + (r & 3) + 8 * (r >> 2);
+                    if (m < Mtot) Mt[(long long)m * N + nw0 + b * 32] = acc[a][b][r];
+                }
+        if (!more) break;
+        tile = next;
+    }
+}
+
 static inline long long wino_tiles(int N, int H, int W) { return (long long)N * (H >> 1) * (W >> 1); }
 static inline long long wino_rows(long long T) { return (T + 127) / 128 * 128; }      // rows per transform-domain matrix: whole 128-row tiles
 
@@ -354,5 +473,18 @@ extern "C" int mrcnn_winograd_dw(const float* dU, float* dw_hwio, int Cin, int C
     if (!dU || !dw_hwio || Cin <= 0 || Cout <= 0) return MRCNN_ERR_ARG;
     hipLaunchKernelGGL(winograd_dw_kernel, dim3((unsigned)cdiv64((long long)Cin * Cout, 256)), dim3(256), 0, (hipStream_t)stream, dU, dw_hwio,
                        Cin, Cout, accumulate);
+    return mrcnn_launch_status();
+}
+
+/* the persistent form of mrcnn_gemm_batched_f32 (same arguments and result; K % 16 == 0, N % 128 == 0, rows % 128 == 0) */
+extern "C" int mrcnn_winograd_gemm(const float* V, const float* U, float* Mt, int nb, int rows, int K, int N, void* stream) {
+    if (!V || !U || !Mt || nb <= 0 || rows <= 0 || rows % 128 || K <= 0 || K % 16 || N <= 0 || N % 128) return MRCNN_ERR_ARG;
+    const long long M = (long long)nb * rows;
+    if (M * K * 4 >= 0x7FFFFFF0LL || (long long)nb * K * N * 4 >= 0x7FFFFFF0LL || M * N >= (1LL << 40)) return MRCNN_ERR_UNSUPPORTED;
+    const long long tiles = (M / 128) * (N / 128);
+    const long long slots = 5LL * mrcnn_num_cus();
+    const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+    hipLaunchKernelGGL(winograd_gemm_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, V, U, Mt, rows, K, N, (int)tiles,
+                       (unsigned)(M * K * 4));
     return mrcnn_launch_status();
 }

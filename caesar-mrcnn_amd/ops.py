@@ -5,6 +5,7 @@ arithmetic happens in libmrcnn_hip.so.  Shapes follow the reference graph (NHWC 
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -664,6 +665,7 @@ def weights_to_h16(w, dtype=torch.float16, want_dgrad=True, out=None):
 
 
 # ---- Winograd F(2x2, 3x3), float32 (mask-head 3x3 convolutions) --------------------------------------------------------
+_WINO_PERSISTENT_GEMM = os.environ.get("MRCNN_WINOGRAD_GEMM", "persistent") != "blds"     # A/B: the one-tile-per-workgroup LDS-DMA kernel
 def winograd_ok(xshape, wshape, stride=1, padding="same", min_rows=32768):
     """Shapes the Winograd path takes: 3 x 3, stride 1, 'same' (or explicit 1, 1), even H and W, channels that fit the batched
     GEMM (Cin % 16, Cout % 128) and the transforms (multiples of 4), enough rows to fill the chip."""
@@ -695,7 +697,8 @@ def _winograd_product(x, U, keep_v=None):
     assert keep_v is None or (keep_v.numel() == nv and keep_v.dtype == torch.float32)
     Mt = workspace(nm * 4, x.device, "winograd_m")
     check(lib.mrcnn_winograd_input(ptr(x), ptr(V), N, H, W, Cin, current_stream()), "mrcnn_winograd_input")
-    check(lib.mrcnn_gemm_batched_f32(ptr(V), ptr(U), ptr(Mt), 16, nv // (16 * Cin), Cin, cout, current_stream()), "mrcnn_gemm_batched_f32")
+    gemm = lib.mrcnn_winograd_gemm if _WINO_PERSISTENT_GEMM else lib.mrcnn_gemm_batched_f32
+    check(gemm(ptr(V), ptr(U), ptr(Mt), 16, nv // (16 * Cin), Cin, cout, current_stream()), "mrcnn_winograd_gemm")
     return Mt
 
 

@@ -400,6 +400,8 @@ size_t mrcnn_winograd_buffer_floats(int N, int H, int W, int C);
 int mrcnn_winograd_weights(const float* w_hwio, float* U, int Cin, int Cout, void* stream);          /* U [16][Cin][Cout] */
 int mrcnn_winograd_input(const float* x, float* V, int N, int H, int W, int C, void* stream);
 int mrcnn_gemm_batched_f32(const float* V, const float* U, float* Mt, int nb, int rows, int K, int Cout, void* stream);
+/* the same product by persistent workgroups (next tile's first stage in flight under the current tile's stores): the default */
+int mrcnn_winograd_gemm(const float* V, const float* U, float* Mt, int nb, int rows, int K, int Cout, void* stream);
 int mrcnn_winograd_output(const float* Mt, float* out, float* z_out, const float* bias, const float* scale, const float* shift,
                           int N, int H, int W, int C, int act, void* stream);
 /* weight gradient: dM = A dy A^T (adjoint of the output transform) [16][rows][C]; dU[xi] = V[xi]^T . dM[xi] are 16 1 x 1 weight
