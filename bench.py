@@ -379,8 +379,8 @@ def _detect_leg(args, res, eng, dev_inputs, dev, backbone, run_py_config, torch)
 def _roofline_leg(res, ops, torch, dev, nimg, cfg):
     """Rooflines of the kernels that dominate the headline step, timed live with HIP events on the launch stream.
     Since the Winograd F(2x2,3x3) path the mask head's eight 3x3 forward / data-gradient convolutions and its
-    four 3x3 weight gradients run as transform-domain GEMMs: `roofline` = the batched GEMM launch of the LDS-DMA kernel
-    (9 launches per step incl. the transposed convolution, ~20 of the ~47 ms), `roofline_wgrad` = the 16 weight-gradient GEMMs
+    four 3x3 weight gradients run as transform-domain GEMMs: `roofline` = the persistent batched GEMM kernel (8 launches per
+    step, ~14 of the ~45 ms: the largest single item), `roofline_wgrad` = the 16 weight-gradient GEMMs
     of a layer in one multi-problem launch.  The direct 3x3 kernels (detect, small ROI counts, MRCNN_WINOGRAD=0) keep their
     objects as `roofline_direct_conv` / `roofline_direct_wgrad`."""
     M_rois = nimg * cfg.TRAIN_ROIS_PER_IMAGE
@@ -415,15 +415,18 @@ def _roofline_leg(res, ops, torch, dev, nimg, cfg):
     st = ops.current_stream
     P = ops.ptr
     t_in = timed_ms(lambda: lib.mrcnn_winograd_input(P(xm), P(V), M_rois, 14, 14, C_, st()))
-    t_gemm = timed_ms(lambda: lib.mrcnn_gemm_batched_f32(P(V), P(U), P(Mt), 16, rows, C_, C_, st()))
+    t_gemm = timed_ms(lambda: lib.mrcnn_winograd_gemm(P(V), P(U), P(Mt), 16, rows, C_, C_, st()))
+    t_gemm_blds = timed_ms(lambda: lib.mrcnn_gemm_batched_f32(P(V), P(U), P(Mt), 16, rows, C_, C_, st()))
     t_out = timed_ms(lambda: lib.mrcnn_winograd_output(P(Mt), P(om), P(zm), P(bm), P(sc), P(bm), M_rois, 14, 14, C_, 1, st()))
     t_layer = timed_ms(lambda: ops.conv2d_winograd(xm, U, bm, sc, bm, 1, out=om, z_out=zm))
     ach = flops_gemm / (t_gemm * 1e-3) / 1e12
     res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                        "traffic": TRAFFIC_WINOGRAD_GEMM.get(M_rois),
-                       "kernel": "conv_fwd_blds_kernel as mrcnn_gemm_batched_f32: the 16 transform-domain GEMMs [%d x 256] . [256 x 256] of "
-                                 "a Winograd F(2x2,3x3) mask-head layer in one launch (128x128 tiles, K = 256: %.1f GFLOP/launch, "
-                                 "%.3f ms/launch)" % (T, flops_gemm / 1e9, t_gemm),
+                       "kernel": "winograd_gemm_kernel (mrcnn_winograd_gemm): the 16 transform-domain GEMMs [%d x 256] . [256 x 256] of a "
+                                 "Winograd F(2x2,3x3) mask-head layer in one launch of persistent workgroups (128x128 tiles, K = 256, "
+                                 "LDS-DMA operands, next tile's first stage in flight under the current tile's stores: %.1f "
+                                 "GFLOP/launch, %.3f ms/launch; the one-tile-per-workgroup LDS-DMA kernel on the same product: %.3f ms)"
+                                 % (T, flops_gemm / 1e9, t_gemm, t_gemm_blds),
                        "layer_ms": {"input_transform": round(t_in, 3), "gemm": round(t_gemm, 3), "output_transform_with_epilogue": round(t_out, 3),
                                     "whole_layer": round(t_layer, 3)},
                        "layer_equivalent_direct_tflops": round(flops_direct / (t_layer * 1e-3) / 1e12, 2),
