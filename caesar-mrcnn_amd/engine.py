@@ -230,6 +230,7 @@ class MaskRCNNEngine(object):
         # matrix-core flops through three launches per layer; MRCNN_WINOGRAD=0 keeps the direct kernels
         self.winograd = os.environ.get("MRCNN_WINOGRAD", "1") != "0"
         self.winograd_wgrad = os.environ.get("MRCNN_WINOGRAD_WGRAD", "1") != "0"    # weight gradients through the same domain
+        self.winograd_split = os.environ.get("MRCNN_WINOGRAD_SPLIT", "1") != "0"    # forward: two half-batch chains on two streams
         self._wino_V = {}               # layer -> input transform V of this step's forward pass
         self._wino = {}                 # layer -> [U forward, U data gradient] (allocated once, refreshed after weight updates)
         self._wino_valid = {}           # layer -> [forward valid, data-gradient valid]
@@ -581,15 +582,15 @@ class MaskRCNNEngine(object):
         elif kind == "f32":
             self.wgrad_async(*args)
         elif kind == "wino":
-            V, xshape, dz, dw = args
+            V, xshape, dz, dw, acc = args
             ws = self.wgrad_stream
             if ws is None:
-                ops.conv2d_wgrad_winograd(V, xshape, dz, dw)
+                ops.conv2d_wgrad_winograd(V, xshape, dz, dw, accumulate=acc)
                 return
             ev = _hip_mod.ev_record(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(ws):
                 _hip_mod.ev_wait(ws, ev)
-                ops.conv2d_wgrad_winograd(V, xshape, dz, dw)
+                ops.conv2d_wgrad_winograd(V, xshape, dz, dw, accumulate=acc)
             dz.record_stream(ws)
             V.record_stream(ws)
         else:
@@ -611,8 +612,8 @@ class MaskRCNNEngine(object):
                         x, dz, wshape, stride, padding, dw, acc = a
                         ops.conv2d_wgrad(x, dz, wshape, stride, padding, dw=dw, accumulate=acc)
                     elif kind == "wino":
-                        x, xshape, dz, dw = a
-                        ops.conv2d_wgrad_winograd(x, xshape, dz, dw)
+                        x, xshape, dz, dw, acc = a
+                        ops.conv2d_wgrad_winograd(x, xshape, dz, dw, accumulate=acc)
                     else:
                         x, dz, wshape, dw, mult = a
                         ops.conv2d_wgrad_h16(x, dz, wshape, 1, "same", dw=dw, multiplier=mult)
@@ -836,7 +837,11 @@ class MaskRCNNEngine(object):
         pooled = ops.roialign(rois, fms, cfg.MASK_POOL_SIZE, image_area)
         x = pooled.view(B * R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1)
         ctxs = []
-        if self.head_dtype is None:
+        if self.head_dtype is None and self.winograd_split and self.wgrad_stream is not None and x.shape[0] >= 512 and \
+                all(self._wino_ok(self.op("mrcnn_mask_conv%d" % i), (x.shape[0] // 2,) + tuple(x.shape[1:3]) + (self.op("mrcnn_mask_conv%d" % i).wshape[2],))
+                    for i in range(1, 5)):
+            x, ctxs = self._mask_convs_fwd_split(x, train)
+        elif self.head_dtype is None:
             for i in range(1, 5):
                 op = self.op("mrcnn_mask_conv%d" % i)
                 if self._wino_ok(op, x.shape):
@@ -845,7 +850,7 @@ class MaskRCNNEngine(object):
                     # training keeps the input transform: the layer's weight gradient contracts it with the transformed dz
                     V = ops.empty((ops.winograd_v_floats(tuple(x.shape)),), torch.float32, self.dev) if (train and self.winograd_wgrad) else None
                     if V is not None:
-                        self._wino_V[op.name] = V
+                        self._wino_V[op.name] = [(V, 0, x.shape[0])]
                     ops.conv2d_winograd(x, self._wino_U(op, 0), op.b, op.scale, op.shift, ACT_RELU, out=out, z_out=z, keep_v=V)
                     x, c = out, ((x, z, out, ACT_RELU) if train else None)
                 else:
@@ -876,6 +881,46 @@ class MaskRCNNEngine(object):
         ctxs.append((x, None, up, ACT_RELU) if train else None)
         ctxs.append(cm)
         return m.view(B, R, m.shape[1], m.shape[2], m.shape[3]), ctxs
+
+    def _mask_convs_fwd_split(self, x, train):
+        """The four Winograd layers of the mask head on the two halves of the ROI rows, one half per stream (main and the
+        weight-gradient stream, idle during the forward pass) and the second half one transform behind the first: a layer is
+        a memory pass, a matrix-core pass and a memory pass in a row, so two chains that are out of phase keep both busy.
+        Activations / z are whole tensors (the backward pass and the transposed convolution see one batch); the input transforms
+        kept for the weight gradients are per half."""
+        main, side = torch.cuda.current_stream(self.dev), self.wgrad_stream
+        N = x.shape[0]
+        cut = (N // 2 + 3) // 4 * 4
+        halves = ((0, cut, main), (cut, N, side))
+        ops_ = [self.op("mrcnn_mask_conv%d" % i) for i in range(1, 5)]
+        Us = [self._wino_U(op, 0) for op in ops_]                      # weight transforms on the main stream, before the fork
+        outs, zs, ctxs = [], [], []
+        cur = x
+        for op in ops_:
+            out = ops.empty(tuple(x.shape[:3]) + (op.wshape[3],), torch.float32, self.dev)
+            z = ops.empty_like(out) if (train and op.bn) else None
+            outs.append(out); zs.append(z)
+            ctxs.append((cur, z, out, ACT_RELU) if train else None)
+            cur = out
+            if train and self.winograd_wgrad:
+                self._wino_V[op.name] = [(ops.empty((ops.winograd_v_floats((b - a,) + tuple(x.shape[1:3]) + (op.wshape[2],)),), torch.float32,
+                                                    self.dev), a, b) for a, b, _ in halves]
+        ev0 = _hip_mod.ev_record(main)                                   # x and the U's are ready
+        lag = []
+        for hi, (a, b, st) in enumerate(halves):
+            with torch.cuda.stream(st):
+                if st is not main:
+                    _hip_mod.ev_wait(st, ev0)
+                    _hip_mod.ev_wait(st, lag[0])                         # one input transform behind the first half
+                inp = x[a:b]
+                for li, op in enumerate(ops_):
+                    V = self._wino_V[op.name][hi][0] if (train and self.winograd_wgrad) else None
+                    mark = (lambda: lag.append(_hip_mod.ev_record(main))) if (st is main and li == 0) else None
+                    ops.conv2d_winograd(inp, Us[li], op.b, op.scale, op.shift, ACT_RELU, out=outs[li][a:b],
+                                        z_out=None if zs[li] is None else zs[li][a:b], keep_v=V, after_input=mark)
+                    inp = outs[li][a:b]
+        _hip_mod.stream_wait(main, side)
+        return outs[-1], ctxs
 
     def infer(self, images, windows_norm):
         """Inference graph (model.py:2133-2159).  images [B,H,W,3] float32 device tensor (molded);
@@ -1130,9 +1175,10 @@ class MaskRCNNEngine(object):
             chain = [(self.op("mrcnn_mask_conv%d" % i), c) for i, c in ((4, c4), (3, c3), (2, c2), (1, c1))]
             dz = self._dgrad_ep(dzg, dc.wt, "valid", chain[0][0], chain[0][1])
             for k, (op, c) in enumerate(chain):
-                V = self._wino_V.pop(op.name, None)
-                if V is not None and self.winograd_wgrad and self._wino_ok(op, c[0].shape):
-                    self._mask_wgrad("wino", V, tuple(c[0].shape), dz, op.dw)
+                Vs = self._wino_V.pop(op.name, None)
+                if Vs is not None and self.winograd_wgrad:
+                    for vi, (V, a, b) in enumerate(Vs):                  # one call per forward chain (whole batch, or two halves)
+                        self._mask_wgrad("wino", V, (b - a,) + tuple(c[0].shape[1:]), dz[a:b], op.dw, vi > 0)
                 else:
                     self._mask_wgrad("f32", *op.wgrad_item(dz, c))
                 kh, kw, cin, cout = op.wshape

@@ -686,7 +686,7 @@ def winograd_weights(w, out=None):
     return out
 
 
-def _winograd_product(x, U, keep_v=None):
+def _winograd_product(x, U, keep_v=None, after_input=None):
     """Input transform + the 16 transform-domain GEMMs; returns Mt (a per-stream scratch buffer, valid until the next call).
     keep_v: a float32 tensor of mrcnn_winograd_buffer_floats elements that receives V (the weight gradient reuses it)."""
     N, H, W, Cin = x.shape
@@ -697,6 +697,8 @@ def _winograd_product(x, U, keep_v=None):
     assert keep_v is None or (keep_v.numel() == nv and keep_v.dtype == torch.float32)
     Mt = workspace(nm * 4, x.device, "winograd_m")
     check(lib.mrcnn_winograd_input(ptr(x), ptr(V), N, H, W, Cin, current_stream()), "mrcnn_winograd_input")
+    if after_input is not None:
+        after_input()                    # e.g. an event: a second chain on another stream starts one transform behind this one
     gemm = lib.mrcnn_winograd_gemm if _WINO_PERSISTENT_GEMM else lib.mrcnn_gemm_batched_f32
     check(gemm(ptr(V), ptr(U), ptr(Mt), 16, nv // (16 * Cin), Cin, cout, current_stream()), "mrcnn_winograd_gemm")
     return Mt
@@ -707,14 +709,14 @@ def winograd_v_floats(xshape):
     return _hip.lib().mrcnn_winograd_buffer_floats(N, H, W, Cin)
 
 
-def conv2d_winograd(x, U, bias=None, scale=None, shift=None, act=ACT_NONE, out=None, z_out=None, keep_v=None):
+def conv2d_winograd(x, U, bias=None, scale=None, shift=None, act=ACT_NONE, out=None, z_out=None, keep_v=None, after_input=None):
     """3 x 3 'same' stride-1 convolution with its epilogue through the Winograd domain (U = winograd_weights(w))."""
     _need_cuda(x, U, bias, scale, shift, out, z_out, keep_v)
     N, H, W, _ = x.shape
     cout = U.shape[2]
     if out is None:
         out = empty((N, H, W, cout), torch.float32, x.device)
-    Mt = _winograd_product(x, U, keep_v)
+    Mt = _winograd_product(x, U, keep_v, after_input)
     check(_hip.lib().mrcnn_winograd_output(ptr(Mt), ptr(out), ptr(z_out), ptr(bias), ptr(scale), ptr(shift), N, H, W, cout, act,
                                            current_stream()), "mrcnn_winograd_output")
     return out

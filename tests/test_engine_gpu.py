@@ -567,7 +567,8 @@ def test_fused_dgrad_epilogue_equals_unfused(dev):
         losses = model.train_on_batch(inputs, rand_keys=keys, apply=False)
         torch.cuda.synchronize()
         res.append((losses.cpu().numpy(), model.engine.grads.cpu().numpy().copy()))
-    np.testing.assert_allclose(res[0][0], res[1][0], rtol=1e-6)       # the loss reductions use float atomics
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=5e-6)       # the loss reductions use float atomics: their order moves the
+                                                                      # class loss by up to ~16 ulp between two runs (seen: 1.5e-6)
     scale = np.abs(res[1][1]).max()
     assert np.abs(res[0][1] - res[1][1]).max() <= 2e-5 * scale and scale > 0
 
