@@ -288,7 +288,18 @@ def measure(args, backbone, nimg, rank, local_rank, world, full):
         step()
         dt_h16, _ = timed(args.steps)
         eng.sparse_mask_bwd, eng.head_dtype = True, None
+    # for transparency: the headline step with the DIRECT 3x3 kernels in the mask head (the Winograd path switched off)
+    dt_direct = float("nan")
+    if not args.dense_only and getattr(eng, "winograd", False):
+        eng.sparse_mask_bwd, eng.winograd = False, False
+        step()
+        step()
+        nd = max(4, args.steps // 2)
+        dt_direct, _ = timed(nd)
+        dt_direct = dt_direct / nd * args.steps
+        eng.sparse_mask_bwd, eng.winograd = True, True
     res = {"backbone": backbone, "nimg": nimg, "ms_per_step": dt / args.steps * 1e3,
+           "images_per_s_direct": None if dt_direct != dt_direct else nimg * world * args.steps / dt_direct,
            "images_per_s_f16_mask_head": None if args.dense_only else nimg * world * args.steps / dt_h16,
            "images_per_s": nimg * world * args.steps / dt,
            "images_per_s_sparse": None if args.dense_only else nimg * world * args.steps / dt_sparse,
@@ -643,6 +654,10 @@ def main():
             "detect_ms_per_image": rnd(r["detect_ms"]), "detect_ms_per_image_eager": rnd(r["detect_eager_ms"]),
             "detect_ms_per_image_batch8": rnd(r["detect_ms_b8"]),
             "detect_ms_per_image_f16_stages": rnd(r.get("detect_ms_f16")),
+            "value_direct_conv_kernels": None if r.get("images_per_s_direct") is None else round(r["images_per_s_direct"], 3),
+            "note_direct_conv_kernels": "the same step with the Winograd F(2x2,3x3) path of the mask head switched off (direct 3x3 implicit-GEMM "
+                                        "kernels, MRCNN_WINOGRAD=0): `value` computes the same layers in float32 with 2.25x fewer matrix "
+                                        "multiplications (2.3e-6 of the direct result, DESIGN.md 4.1d)",
             "value_exact_zero_skip": None if args.dense_only else round(r["images_per_s_sparse"], 3),
             "note_exact_zero_skip": "same step with the mask head (forward and backward) run on the <=168 positive-quota ROI "
                                     "rows per image only: the other rows are never read by the loss and carry exactly-zero "
