@@ -137,15 +137,15 @@ _SIGNATURES = {
     "mrcnn_sumsq": (C.c_int, [_P, C.c_int64, _P, _P]),
     "mrcnn_sgd_momentum": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, C.c_int64, _P]),
     "mrcnn_sgd_momentum_guarded": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, C.c_float, _P, C.c_int64, _P, _P]),
-    "mrcnn_winograd_buffer_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "mrcnn_winograd_weights": (C.c_int, [_P, _P, C.c_int, C.c_int, _P]),
-    "mrcnn_winograd_input": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mrcnn_winograd_buffer_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "mrcnn_winograd_weights": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "mrcnn_winograd_input": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_gemm_batched_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_winograd_gemm": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
-    "mrcnn_winograd_output": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
-    "mrcnn_winograd_dy": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
-    "mrcnn_winograd_dw": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, _P]),
-    "mrcnn_winograd_output_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mrcnn_winograd_output": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mrcnn_winograd_dy": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mrcnn_winograd_dw": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mrcnn_winograd_output_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_allreduce_load": (C.c_int, [C.c_char_p]),
     "mrcnn_allreduce_unique_id": (C.c_int, [_P]),
     "mrcnn_allreduce_init": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int]),

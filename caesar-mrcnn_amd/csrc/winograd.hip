@@ -1,139 +1,228 @@
-// Winograd F(2x2, 3x3) for the stride-1 "same" 3x3 convolutions of the mask head (float32): Y = A^T [(G g G^T) . (B^T d B)] A per
-// 4 x 4 input tile / 2 x 2 output tile, summed over input channels -- 16 multiplications per 4 outputs and channel pair instead
-// of 36, i.e. 16 batched GEMMs [tiles x Cin] . [Cin x Cout] in the transform domain (2.25 x fewer MFMA flops than the direct
-// form).  Three passes per layer:
+// Winograd F(2x2, 3x3) / F(4x4, 3x3) for the stride-1 "same" 3x3 convolutions of the mask head (float32):
+// Y = A^T [(G g G^T) . (B^T d B)] A per 4 x 4 input tile / 2 x 2 output tile, summed over input channels -- 16 multiplications per 4
+// outputs and channel pair instead of 36, i.e. 16 batched GEMMs [tiles x Cin] . [Cin x Cout] in the transform domain (2.25 x fewer
+// MFMA flops than the direct form); with 6 x 6 / 4 x 4 tiles 36 GEMMs over a quarter of the tiles (4 x fewer).  Three passes per layer:
 //   winograd_input_kernel    x [N, H, W, C]            -> V [16][T][C],   T = N (H/2)(W/2) tiles   (reads x once through L2, writes 4 x its size)
 //   16 GEMMs                 V[xi] [T, C] . U[xi] [C, Cout] -> Mt [16][T][Cout]                     (conv_fwd_blds_kernel, batched over xi)
 //   winograd_output_kernel   Mt -> out [N, H, W, Cout] with the convolution's epilogue (bias, frozen-BN affine, activation, z)
-// plus winograd_weight_kernel U = G g G^T once per weight update.  The transforms are exact additions / halvings in float32
-// (B^T, A^T have entries 0, +-1; G has 0, 1, +-1/2), so the result differs from the direct kernel by summation order only.
-// H and W even (mask head: 14 x 14).
+// plus winograd_weight_kernel U = G g G^T once per weight update.  For the 2 x 2 tile the transforms are exact additions / halvings
+// in float32 (B^T, A^T have entries 0, +-1; G has 0, 1, +-1/2), so the result differs from the direct kernel by summation order
+// only, and H and W must be even (mask head: 14 x 14); the 4 x 4 tile takes any extent (its last tiles hang over the edge).
 #include "common.h"
 #include <type_traits>
 
-// B^T d B for one 4 x 4 tile held as d[r][c] (float4 = 4 channels per thread)
-__device__ __forceinline__ void wino_bt_d_b(const f32x4 d[4][4], f32x4 v[4][4]) {
-    f32x4 t[4][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {                // rows: B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]
-        t[0][c] = d[0][c] - d[2][c];
-        t[1][c] = d[1][c] + d[2][c];
-        t[2][c] = d[2][c] - d[1][c];
-        t[3][c] = d[1][c] - d[3][c];
+// ---- the 1-D transforms, m = OT outputs per tile and dimension (IT = OT + 2 inputs) -------------------------------------------
+// OT = 2: B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1], A^T = [1 1 1 0; 0 1 -1 -1].
+// OT = 4 (F(4x4, 3x3), interpolation points 0, +-1, +-2, inf): 36 multiplications per 16 outputs (4 x fewer than direct, 1.78 x
+// fewer than OT = 2 -- 1.36 x on 14 x 14 maps, which it covers with 4 x 4 tiles of which the last row / column is half used);
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// its constants up to 8 cost about a decimal digit: ~7e-6 of the output range against ~5e-7 for OT = 2 (float32, K = 256).
+template <int CV> struct WinoVec;
+template <> struct WinoVec<4> { typedef f32x4 type; };
+template <> struct WinoVec<2> { typedef float type __attribute__((ext_vector_type(2))); };
+
+template <int OT, typename V> __device__ __forceinline__ void wino_bt(const V (&d)[OT + 2], V (&t)[OT + 2]) {
+    if constexpr (OT == 2) {
+        t[0] = d[0] - d[2];
+        t[1] = d[1] + d[2];
+        t[2] = d[2] - d[1];
+        t[3] = d[1] - d[3];
+    } else {
+        const V a = d[4] - 4.f * d[2], b = d[3] - 4.f * d[1], c = d[4] - d[2], e = 2.f * (d[3] - d[1]);
+        t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+        t[1] = a + b;
+        t[2] = a - b;
+        t[3] = c + e;
+        t[4] = c - e;
+        t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {                // columns: the same with B
-        v[r][0] = t[r][0] - t[r][2];
-        v[r][1] = t[r][1] + t[r][2];
-        v[r][2] = t[r][2] - t[r][1];
-        v[r][3] = t[r][1] - t[r][3];
+}
+template <int OT, typename V> __device__ __forceinline__ void wino_at(const V (&m)[OT + 2], V (&y)[OT]) {
+    if constexpr (OT == 2) {
+        y[0] = m[0] + m[1] + m[2];
+        y[1] = m[1] - m[2] - m[3];
+    } else {
+        const V p = m[1] + m[2], q = m[1] - m[2], r = m[3] + m[4], s = m[3] - m[4];
+        y[0] = m[0] + p + r;
+        y[1] = q + 2.f * s;
+        y[2] = p + 4.f * r;
+        y[3] = q + 8.f * s + m[5];
+    }
+}
+// the adjoint of wino_at: A y
+template <int OT, typename V> __device__ __forceinline__ void wino_a(const V (&y)[OT], V (&m)[OT + 2]) {
+    if constexpr (OT == 2) {
+        m[0] = y[0];
+        m[1] = y[0] + y[1];
+        m[2] = y[0] - y[1];
+        m[3] = -y[1];
+    } else {
+        const V e = y[0] + y[2], o = y[1] + y[3], e4 = y[0] + 4.f * y[2], o4 = 2.f * y[1] + 8.f * y[3];
+        m[0] = y[0];
+        m[1] = e + o;
+        m[2] = e - o;
+        m[3] = e4 + o4;
+        m[4] = e4 - o4;
+        m[5] = y[3];
+    }
+}
+template <int OT> __device__ __forceinline__ void wino_g(const float (&g)[3], float (&u)[OT + 2]) {
+    if constexpr (OT == 2) {
+        u[0] = g[0];
+        u[1] = 0.5f * (g[0] + g[1] + g[2]);
+        u[2] = 0.5f * (g[0] - g[1] + g[2]);
+        u[3] = g[2];
+    } else {
+        const float e = g[0] + g[2];
+        u[0] = 0.25f * g[0];
+        u[1] = (-1.f / 6.f) * (e + g[1]);
+        u[2] = (-1.f / 6.f) * (e - g[1]);
+        const float f = (1.f / 24.f) * g[0] + (1.f / 6.f) * g[2], h = (1.f / 12.f) * g[1];
+        u[3] = f + h;
+        u[4] = f - h;
+        u[5] = g[2];
+    }
+}
+// the adjoint of wino_g: G^T u
+template <int OT> __device__ __forceinline__ void wino_gt(const float (&u)[OT + 2], float (&w)[3]) {
+    if constexpr (OT == 2) {
+        w[0] = u[0] + 0.5f * (u[1] + u[2]);
+        w[1] = 0.5f * (u[1] - u[2]);
+        w[2] = 0.5f * (u[1] + u[2]) + u[3];
+    } else {
+        const float p = u[1] + u[2], q = u[3] + u[4];
+        w[0] = 0.25f * u[0] - (1.f / 6.f) * p + (1.f / 24.f) * q;
+        w[1] = (1.f / 6.f) * (u[2] - u[1]) + (1.f / 12.f) * (u[3] - u[4]);
+        w[2] = (1.f / 6.f) * (q - p) + u[5];
     }
 }
 
-// one thread: one tile x 4 channels.  Tiles are numbered (n, th, tw) row-major: tile t covers outputs (2 th .. 2 th + 1, 2 tw .. + 1)
-__global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W,
-                                                             int C, long long T, long long Tp) {
-    const int c4n = C >> 2;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= T * c4n) return;
-    const long long t = i / c4n;
-    const int c = (int)(i - t * c4n) * 4;
-    const int tw_n = W >> 1, th_n = H >> 1;
-    const int tw = (int)(t % tw_n);
+// tile t of [0, N * th_n * tw_n) -> (n, th, tw), row-major: tile (th, tw) covers outputs (OT th .. OT th + OT - 1, OT tw .. )
+struct WinoTile { int n, th, tw; };
+__device__ __forceinline__ WinoTile wino_tile(long long t, int th_n, int tw_n) {
+    WinoTile r;
+    r.tw = (int)(t % tw_n);
     const long long q = t / tw_n;
-    const int th = (int)(q % th_n);
-    const int n = (int)(q / th_n);
-    const int ih0 = 2 * th - 1, iw0 = 2 * tw - 1;
-    f32x4 d[4][4], v[4][4];
+    r.th = (int)(q % th_n);
+    r.n = (int)(q / th_n);
+    return r;
+}
+
+// B^T d B: one thread = one tile x CV channels.  V [IT * IT][Tp][C]
+template <int OT, int CV>
+__global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W,
+                                                             int C, long long T, long long Tp, int th_n, int tw_n) {
+    typedef typename WinoVec<CV>::type vec;
+    constexpr int IT = OT + 2;
+    const int cn = C / CV;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * cn) return;
+    const long long t = i / cn;
+    const int c = (int)(i - t * cn) * CV;
+    const WinoTile q = wino_tile(t, th_n, tw_n);
+    const int ih0 = OT * q.th - 1, iw0 = OT * q.tw - 1;
+    vec tt[IT][IT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int s = 0; s < IT; ++s) {               // columns of the tile: B^T applied down the rows
+        vec col[IT], o[IT];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int r = 0; r < IT; ++r) {
             const int ih = ih0 + r, iw = iw0 + s;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
-                val = *(const f32x4*)(x + (((long long)n * H + ih) * W + iw) * C + c);
-            d[r][s] = val;
+            vec val = {};
+            if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) val = *(const vec*)(x + (((long long)q.n * H + ih) * W + iw) * C + c);
+            col[r] = val;
         }
-    wino_bt_d_b(d, v);
+        wino_bt<OT>(col, o);
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < IT; ++r) tt[r][s] = o[r];
+    }
 #pragma unroll
-        for (int s = 0; s < 4; ++s) *(f32x4*)(V + ((long long)(r * 4 + s) * Tp + t) * C + c) = v[r][s];
+    for (int r = 0; r < IT; ++r) {               // then along each row
+        vec v[IT];
+        wino_bt<OT>(tt[r], v);
+#pragma unroll
+        for (int s = 0; s < IT; ++s) *(vec*)(V + ((long long)(r * IT + s) * Tp + t) * C + c) = v[s];
+    }
 }
 
 // U[xi][ci][co] = (G g G^T)[xi] from the HWIO kernel g[3][3][ci][co]; one thread per (ci, co)
+template <int OT>
 __global__ __launch_bounds__(256) void winograd_weight_kernel(const float* __restrict__ g, float* __restrict__ U, int Cin, int Cout) {
+    constexpr int IT = OT + 2;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long n = (long long)Cin * Cout;
     if (i >= n) return;
-    float w[3][3], t[4][3];
+    float t[IT][3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+        float col[3], o[IT];
 #pragma unroll
-        for (int b = 0; b < 3; ++b) w[a][b] = g[(long long)(a * 3 + b) * n + i];
+        for (int a = 0; a < 3; ++a) col[a] = g[(long long)(a * 3 + b) * n + i];
+        wino_g<OT>(col, o);
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {                // G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]
-        t[0][b] = w[0][b];
-        t[1][b] = 0.5f * (w[0][b] + w[1][b] + w[2][b]);
-        t[2][b] = 0.5f * (w[0][b] - w[1][b] + w[2][b]);
-        t[3][b] = w[2][b];
+        for (int a = 0; a < IT; ++a) t[a][b] = o[a];
     }
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        U[(long long)(a * 4 + 0) * n + i] = t[a][0];
-        U[(long long)(a * 4 + 1) * n + i] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
-        U[(long long)(a * 4 + 2) * n + i] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
-        U[(long long)(a * 4 + 3) * n + i] = t[a][2];
+    for (int a = 0; a < IT; ++a) {
+        float u[IT];
+        wino_g<OT>(t[a], u);
+#pragma unroll
+        for (int b = 0; b < IT; ++b) U[(long long)(a * IT + b) * n + i] = u[b];
     }
 }
 
-// A^T m A (2 x 2 outputs of one tile) + epilogue: z = y + bias (stored when asked), out = act(scale z + shift)
+// A^T m A (OT x OT outputs of one tile) + epilogue: z = y + bias (stored when asked), out = act(scale z + shift)
+template <int OT, int CV>
 __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ Mt, float* __restrict__ out, float* __restrict__ z,
                                                               const float* __restrict__ bias, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, int N, int H, int W, int C, long long T,
-                                                              long long Tp, int act) {
-    const int c4n = C >> 2;
+                                                              long long Tp, int act, int th_n, int tw_n) {
+    typedef typename WinoVec<CV>::type vec;
+    constexpr int IT = OT + 2;
+    const int cn = C / CV;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= T * c4n) return;
-    const long long t = i / c4n;
-    const int c = (int)(i - t * c4n) * 4;
-    const int tw_n = W >> 1, th_n = H >> 1;
-    const int tw = (int)(t % tw_n);
-    const long long q = t / tw_n;
-    const int th = (int)(q % th_n);
-    const int n = (int)(q / th_n);
-    f32x4 m[4][4], s[2][4];
+    if (i >= T * cn) return;
+    const long long t = i / cn;
+    const int c = (int)(i - t * cn) * CV;
+    const WinoTile q = wino_tile(t, th_n, tw_n);
+    vec s[OT][IT];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int k = 0; k < IT; ++k) {               // A^T down the rows of every column k
+        vec col[IT], o[OT];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) m[r][k] = *(const f32x4*)(Mt + ((long long)(r * 4 + k) * Tp + t) * C + c);
+        for (int r = 0; r < IT; ++r) col[r] = *(const vec*)(Mt + ((long long)(r * IT + k) * Tp + t) * C + c);
+        wino_at<OT>(col, o);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                // A^T = [1 1 1 0; 0 1 -1 -1]
-        s[0][k] = m[0][k] + m[1][k] + m[2][k];
-        s[1][k] = m[1][k] - m[2][k] - m[3][k];
+        for (int a = 0; a < OT; ++a) s[a][k] = o[a];
     }
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f}, one4 = {1.f, 1.f, 1.f, 1.f};
-    const f32x4 bi = bias ? *(const f32x4*)(bias + c) : zero4;
-    const f32x4 sc = scale ? *(const f32x4*)(scale + c) : one4, sh = scale ? *(const f32x4*)(shift + c) : zero4;
+    vec bi = {}, sc, sh = {};
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        f32x4 y[2];
-        y[0] = s[a][0] + s[a][1] + s[a][2];
-        y[1] = s[a][1] - s[a][2] - s[a][3];
+    for (int e = 0; e < CV; ++e) sc[e] = 1.f;
+    if (bias) bi = *(const vec*)(bias + c);
+    if (scale) { sc = *(const vec*)(scale + c); sh = *(const vec*)(shift + c); }
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const long long addr = (((long long)n * H + 2 * th + a) * W + 2 * tw + b) * C + c;
-            f32x4 zv, o;
+    for (int a = 0; a < OT; ++a) {
+        vec y[OT];
+        wino_at<OT>(s[a], y);
+        const int oh = OT * q.th + a;
+        if (oh >= H) continue;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+        for (int b = 0; b < OT; ++b) {
+            const int ow = OT * q.tw + b;
+            if (ow >= W) continue;
+            const long long addr = (((long long)q.n * H + oh) * W + ow) * C + c;
+            vec zv, o;
+#pragma unroll
+            for (int e = 0; e < CV; ++e) {
                 zv[e] = y[b][e] + bi[e];
                 float v = sc[e] * zv[e] + sh[e];
                 if (act == MRCNN_ACT_RELU) v = fmaxf(v, 0.f);
                 o[e] = v;
             }
-            if (z) *(f32x4*)(z + addr) = zv;
-            *(f32x4*)(out + addr) = o;
+            if (z) *(vec*)(z + addr) = zv;
+            *(vec*)(out + addr) = o;
         }
     }
 }
@@ -141,151 +230,150 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
 // The output transform of a DATA gradient fused with the epilogue backward of the layer below (what mrcnn_conv2d_dgrad_ep does
 // for the direct kernel): y = A^T m A is d(loss)/d(activated output of the layer below);
 //   g = y * act'(out_below);  dz = g * scale_below -> stored;  dbeta += sum g, dgamma += sum g (z_below - mean) rstd, dbias += sum dz.
-// A workgroup walks a range of tiles: lane = 4-channel group (C / 4 of them, a power of two <= 256), 256 / (C / 4) tiles in flight;
-// channel sums stay in registers, meet in LDS and leave as one atomic per channel and workgroup.
+// A workgroup walks a range of tiles: lane = CV-channel group (C / CV of them, a power of two <= 256), 256 / (C / CV) tiles in
+// flight; channel sums stay in registers, meet in LDS and leave as one atomic per channel and workgroup.
+template <int OT, int CV>
 __global__ __launch_bounds__(256) void winograd_output_bwd_kernel(const float* __restrict__ Mt, float* __restrict__ dz_out,
                                                                   const float* __restrict__ below_out, const float* __restrict__ below_z,
                                                                   const float* __restrict__ scale, const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, float* dgamma, float* dbeta, float* dbias,
                                                                   int N, int H, int W, int C, long long T, long long Tp, int act,
-                                                                  long long tiles_per_block, int lg) {
+                                                                  long long tiles_per_block, int lg, int th_n, int tw_n) {
+    typedef typename WinoVec<CV>::type vec;
+    constexpr int IT = OT + 2;
     __shared__ float sacc[3 * 4 * 256];
-    const int L = 1 << lg, R = 256 >> lg;                       // L = C / 4 lanes, R tiles in flight
-    for (int c = threadIdx.x; c < 12 * L; c += 256) sacc[c] = 0.f;
+    const int L = 1 << lg, R = 256 >> lg;                       // L = C / CV lanes, R tiles in flight
+    for (int c = threadIdx.x; c < 3 * CV * L; c += 256) sacc[c] = 0.f;
     __syncthreads();
     const int rsub = threadIdx.x >> lg, lane = threadIdx.x & (L - 1);
-    const int c = lane * 4;
+    const int c = lane * CV;
     const long long t0 = (long long)blockIdx.x * tiles_per_block;
     long long t1 = t0 + tiles_per_block;
     if (t1 > T) t1 = T;
-    const int tw_n = W >> 1, th_n = H >> 1;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, mu = {0.f, 0.f, 0.f, 0.f}, rs = {0.f, 0.f, 0.f, 0.f};
-    if (scale) sc = *(const f32x4*)(scale + c);
-    if (dgamma) { mu = *(const f32x4*)(mean + c); rs = *(const f32x4*)(rstd + c); }
-    f32x4 a_db = {0.f, 0.f, 0.f, 0.f}, a_dg = a_db, a_bias = a_db;
+    vec sc, mu = {}, rs = {};
+#pragma unroll
+    for (int e = 0; e < CV; ++e) sc[e] = 1.f;
+    if (scale) sc = *(const vec*)(scale + c);
+    if (dgamma) { mu = *(const vec*)(mean + c); rs = *(const vec*)(rstd + c); }
+    vec a_db = {}, a_dg = {}, a_bias = {};
     for (long long t = t0 + rsub; t < t1; t += R) {
-        const int tw = (int)(t % tw_n);
-        const long long q = t / tw_n;
-        const int th = (int)(q % th_n);
-        const int n = (int)(q / th_n);
-        f32x4 m[4][4], s[2][4];
+        const WinoTile q = wino_tile(t, th_n, tw_n);
+        vec s[OT][IT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int k = 0; k < IT; ++k) {
+            vec col[IT], o[OT];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) m[r][k] = *(const f32x4*)(Mt + ((long long)(r * 4 + k) * Tp + t) * C + c);
-        f32x4 oo[2][2], zz[2][2];
+            for (int r = 0; r < IT; ++r) col[r] = *(const vec*)(Mt + ((long long)(r * IT + k) * Tp + t) * C + c);
+            wino_at<OT>(col, o);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const long long addr = (((long long)n * H + 2 * th + a) * W + 2 * tw + b) * C + c;
-                if (act == MRCNN_ACT_RELU) oo[a][b] = *(const f32x4*)(below_out + addr);
-                if (dgamma) zz[a][b] = *(const f32x4*)(below_z + addr);
-            }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            s[0][k] = m[0][k] + m[1][k] + m[2][k];
-            s[1][k] = m[1][k] - m[2][k] - m[3][k];
+            for (int a = 0; a < OT; ++a) s[a][k] = o[a];
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            f32x4 y[2];
-            y[0] = s[a][0] + s[a][1] + s[a][2];
-            y[1] = s[a][1] - s[a][2] - s[a][3];
+        for (int a = 0; a < OT; ++a) {
+            vec y[OT];
+            wino_at<OT>(s[a], y);
+            const int oh = OT * q.th + a;
+            if (oh >= H) continue;
 #pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const long long addr = (((long long)n * H + 2 * th + a) * W + 2 * tw + b) * C + c;
-                f32x4 g = y[b], dz;
+            for (int b = 0; b < OT; ++b) {
+                const int ow = OT * q.tw + b;
+                if (ow >= W) continue;
+                const long long addr = (((long long)q.n * H + oh) * W + ow) * C + c;
+                vec g = y[b], dz;
                 if (act == MRCNN_ACT_RELU) {
+                    const vec oo = *(const vec*)(below_out + addr);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) g[e] = oo[a][b][e] > 0.f ? g[e] : 0.f;
+                    for (int e = 0; e < CV; ++e) g[e] = oo[e] > 0.f ? g[e] : 0.f;
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) dz[e] = g[e] * sc[e];
-                *(f32x4*)(dz_out + addr) = dz;
+                for (int e = 0; e < CV; ++e) dz[e] = g[e] * sc[e];
+                *(vec*)(dz_out + addr) = dz;
                 if (dgamma) {
+                    const vec zz = *(const vec*)(below_z + addr);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) a_dg[e] += g[e] * (zz[a][b][e] - mu[e]) * rs[e];
+                    for (int e = 0; e < CV; ++e) a_dg[e] += g[e] * (zz[e] - mu[e]) * rs[e];
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { a_db[e] += g[e]; a_bias[e] += dz[e]; }
+                for (int e = 0; e < CV; ++e) { a_db[e] += g[e]; a_bias[e] += dz[e]; }
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (dbeta || dgamma) atomicAdd(&sacc[lane * 4 + k], a_db[k]);
-        if (dgamma) atomicAdd(&sacc[4 * L + lane * 4 + k], a_dg[k]);
-        if (dbias) atomicAdd(&sacc[8 * L + lane * 4 + k], a_bias[k]);
+    for (int k = 0; k < CV; ++k) {
+        if (dbeta || dgamma) atomicAdd(&sacc[lane * CV + k], a_db[k]);
+        if (dgamma) atomicAdd(&sacc[CV * L + lane * CV + k], a_dg[k]);
+        if (dbias) atomicAdd(&sacc[2 * CV * L + lane * CV + k], a_bias[k]);
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < 4 * L; j += 256) {
+    for (int j = threadIdx.x; j < CV * L; j += 256) {
         if (dbeta) atomicAdd(&dbeta[j], sacc[j]);
-        if (dgamma) atomicAdd(&dgamma[j], sacc[4 * L + j]);
-        if (dbias) atomicAdd(&dbias[j], sacc[8 * L + j]);
+        if (dgamma) atomicAdd(&dgamma[j], sacc[CV * L + j]);
+        if (dbias) atomicAdd(&dbias[j], sacc[2 * CV * L + j]);
     }
 }
 
-// Weight gradient through the same domain: dU[xi] = V[xi]^T . dM[xi] (16 GEMMs contracting over the tiles: 1 x 1 weight
+// Weight gradient through the same domain: dU[xi] = V[xi]^T . dM[xi] (IT * IT GEMMs contracting over the tiles: 1 x 1 weight
 // gradients for the float32 weight-gradient kernel), with V = B^T d B the forward's input transform (kept from the forward
-// pass) and dM = A dy A^T the ADJOINT of the output transform, A = [1 0; 1 1; 1 -1; 0 -1]; then dW = G^T dU G.
+// pass) and dM = A dy A^T the ADJOINT of the output transform (outputs past the map's edge count as zero); then dW = G^T dU G.
+template <int OT, int CV>
 __global__ __launch_bounds__(256) void winograd_dy_kernel(const float* __restrict__ dy, float* __restrict__ dM, int N, int H, int W, int C,
-                                                          long long T, long long Tp) {
-    const int c4n = C >> 2;
+                                                          long long T, long long Tp, int th_n, int tw_n) {
+    typedef typename WinoVec<CV>::type vec;
+    constexpr int IT = OT + 2;
+    const int cn = C / CV;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= T * c4n) return;
-    const long long t = i / c4n;
-    const int c = (int)(i - t * c4n) * 4;
-    const int tw_n = W >> 1, th_n = H >> 1;
-    const int tw = (int)(t % tw_n);
-    const long long q = t / tw_n;
-    const int th = (int)(q % th_n);
-    const int n = (int)(q / th_n);
-    f32x4 d[2][2], u[4][2];
+    if (i >= T * cn) return;
+    const long long t = i / cn;
+    const int c = (int)(i - t * cn) * CV;
+    const WinoTile q = wino_tile(t, th_n, tw_n);
+    vec u[IT][OT];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int b = 0; b < OT; ++b) {               // A down the rows of every output column b
+        vec col[OT], o[IT];
 #pragma unroll
-        for (int b = 0; b < 2; ++b) d[a][b] = *(const f32x4*)(dy + (((long long)n * H + 2 * th + a) * W + 2 * tw + b) * C + c);
+        for (int a = 0; a < OT; ++a) {
+            const int oh = OT * q.th + a, ow = OT * q.tw + b;
+            vec val = {};
+            if (oh < H && ow < W) val = *(const vec*)(dy + (((long long)q.n * H + oh) * W + ow) * C + c);
+            col[a] = val;
+        }
+        wino_a<OT>(col, o);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {                // rows: A d
-        u[0][b] = d[0][b];
-        u[1][b] = d[0][b] + d[1][b];
-        u[2][b] = d[0][b] - d[1][b];
-        u[3][b] = -d[1][b];
+        for (int r = 0; r < IT; ++r) u[r][b] = o[r];
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {                // columns: (A d) A^T
-        const f32x4 m0 = u[r][0], m1 = u[r][0] + u[r][1], m2 = u[r][0] - u[r][1], m3 = -u[r][1];
-        *(f32x4*)(dM + ((long long)(r * 4 + 0) * Tp + t) * C + c) = m0;
-        *(f32x4*)(dM + ((long long)(r * 4 + 1) * Tp + t) * C + c) = m1;
-        *(f32x4*)(dM + ((long long)(r * 4 + 2) * Tp + t) * C + c) = m2;
-        *(f32x4*)(dM + ((long long)(r * 4 + 3) * Tp + t) * C + c) = m3;
+    for (int r = 0; r < IT; ++r) {               // (A d) A^T
+        vec m[IT];
+        wino_a<OT>(u[r], m);
+#pragma unroll
+        for (int k = 0; k < IT; ++k) *(vec*)(dM + ((long long)(r * IT + k) * Tp + t) * C + c) = m[k];
     }
 }
 
-// dW [3][3][ci][co] (= or +=) G^T dU G, dU [16][ci][co]; one thread per (ci, co)
+// dW [3][3][ci][co] (= or +=) G^T dU G, dU [IT * IT][ci][co]; one thread per (ci, co)
+template <int OT>
 __global__ __launch_bounds__(256) void winograd_dw_kernel(const float* __restrict__ dU, float* dW, int Cin, int Cout, int accumulate) {
+    constexpr int IT = OT + 2;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long n = (long long)Cin * Cout;
     if (i >= n) return;
-    float u[4][4], t[3][4];
+    float t[3][IT];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < IT; ++b) {
+        float col[IT], o[3];
 #pragma unroll
-        for (int b = 0; b < 4; ++b) u[a][b] = dU[(long long)(a * 4 + b) * n + i];
+        for (int a = 0; a < IT; ++a) col[a] = dU[(long long)(a * IT + b) * n + i];
+        wino_gt<OT>(col, o);
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {                // G^T = [1 1/2 1/2 0; 0 1/2 -1/2 0; 0 1/2 1/2 1]
-        t[0][b] = u[0][b] + 0.5f * (u[1][b] + u[2][b]);
-        t[1][b] = 0.5f * (u[1][b] - u[2][b]);
-        t[2][b] = 0.5f * (u[1][b] + u[2][b]) + u[3][b];
+        for (int a = 0; a < 3; ++a) t[a][b] = o[a];
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const float w0 = t[a][0] + 0.5f * (t[a][1] + t[a][2]), w1 = 0.5f * (t[a][1] - t[a][2]), w2 = 0.5f * (t[a][1] + t[a][2]) + t[a][3];
+        float w[3];
+        wino_gt<OT>(t[a], w);
         float* o = dW + (long long)(a * 3) * n + i;
-        o[0] = accumulate ? o[0] + w0 : w0;
-        o[n] = accumulate ? o[n] + w1 : w1;
-        o[2 * n] = accumulate ? o[2 * n] + w2 : w2;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) o[b * n] = accumulate ? o[b * n] + w[b] : w[b];
     }
 }
 
@@ -415,72 +503,96 @@ __global__ __launch_bounds__(256, 2) void winograd_gemm_kernel(const float* __re
     }
 }
 
-static inline long long wino_tiles(int N, int H, int W) { return (long long)N * (H >> 1) * (W >> 1); }
+// tile = outputs per tile and dimension: 2 (F(2x2, 3x3), 16 GEMMs) or 4 (F(4x4, 3x3), 36 GEMMs; edge tiles may hang over the map)
+static inline int wino_tdim(int extent, int tile) { return (extent + tile - 1) / tile; }
+static inline long long wino_tiles(int N, int H, int W, int tile) { return (long long)N * wino_tdim(H, tile) * wino_tdim(W, tile); }
 static inline long long wino_rows(long long T) { return (T + 127) / 128 * 128; }      // rows per transform-domain matrix: whole 128-row tiles
+static inline int wino_nb(int tile) { return (tile + 2) * (tile + 2); }
 
-static int wino_shape_ok(int N, int H, int W, int C) { return N > 0 && H > 0 && W > 0 && !(H & 1) && !(W & 1) && C > 0 && !(C & 3); }
-
-/* floats of V (input transform) or Mt (transform-domain product) for a layer: 16 x rows x C */
-extern "C" size_t mrcnn_winograd_buffer_floats(int N, int H, int W, int C) {
-    if (!wino_shape_ok(N, H, W, C)) return 0;
-    return (size_t)16 * (size_t)wino_rows(wino_tiles(N, H, W)) * (size_t)C;
+static int wino_shape_ok(int N, int H, int W, int C, int tile) {
+    if (tile != 2 && tile != 4) return 0;
+    if (tile == 2 && ((H & 1) || (W & 1))) return 0;
+    return N > 0 && H > 0 && W > 0 && C > 0 && !(C & 3);
 }
 
-extern "C" int mrcnn_winograd_input(const float* x, float* V, int N, int H, int W, int C, void* stream) {
-    if (!x || !V || !wino_shape_ok(N, H, W, C)) return MRCNN_ERR_ARG;
-    const long long T = wino_tiles(N, H, W);
-    hipLaunchKernelGGL(winograd_input_kernel, dim3((unsigned)cdiv64(T * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, x, V, N, H, W, C, T,
-                       wino_rows(T));
+// launch one of the two instantiations of a transform kernel: <2, 4> (one thread = a tile x 4 channels) or <4, 2> (36 + 36 values of
+// 2 channels: 4 would not fit the register file without spilling)
+#define WINO_LAUNCH(kernel, tile, cv_count, ...)                                                                                   \
+    do {                                                                                                                           \
+        if ((tile) == 2)                                                                                                           \
+            hipLaunchKernelGGL((kernel<2, 4>), dim3((unsigned)cdiv64((cv_count) / 4, 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        else                                                                                                                       \
+            hipLaunchKernelGGL((kernel<4, 2>), dim3((unsigned)cdiv64((cv_count) / 2, 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+    } while (0)
+
+/* floats of V (input transform) or Mt (transform-domain product) for a layer: (tile + 2)^2 x rows x C */
+extern "C" size_t mrcnn_winograd_buffer_floats(int N, int H, int W, int C, int tile) {
+    if (!wino_shape_ok(N, H, W, C, tile)) return 0;
+    return (size_t)wino_nb(tile) * (size_t)wino_rows(wino_tiles(N, H, W, tile)) * (size_t)C;
+}
+
+extern "C" int mrcnn_winograd_input(const float* x, float* V, int N, int H, int W, int C, int tile, void* stream) {
+    if (!x || !V || !wino_shape_ok(N, H, W, C, tile)) return MRCNN_ERR_ARG;
+    const long long T = wino_tiles(N, H, W, tile);
+    WINO_LAUNCH(winograd_input_kernel, tile, T * C, x, V, N, H, W, C, T, wino_rows(T), wino_tdim(H, tile), wino_tdim(W, tile));
     return mrcnn_launch_status();
 }
 
-extern "C" int mrcnn_winograd_weights(const float* g, float* U, int Cin, int Cout, void* stream) {
-    if (!g || !U || Cin <= 0 || Cout <= 0) return MRCNN_ERR_ARG;
-    hipLaunchKernelGGL(winograd_weight_kernel, dim3((unsigned)cdiv64((long long)Cin * Cout, 256)), dim3(256), 0, (hipStream_t)stream, g, U, Cin, Cout);
+extern "C" int mrcnn_winograd_weights(const float* g, float* U, int Cin, int Cout, int tile, void* stream) {
+    if (!g || !U || Cin <= 0 || Cout <= 0 || (tile != 2 && tile != 4)) return MRCNN_ERR_ARG;
+    const dim3 grid((unsigned)cdiv64((long long)Cin * Cout, 256));
+    if (tile == 2) hipLaunchKernelGGL(winograd_weight_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g, U, Cin, Cout);
+    else hipLaunchKernelGGL(winograd_weight_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, g, U, Cin, Cout);
     return mrcnn_launch_status();
 }
 
 extern "C" int mrcnn_winograd_output(const float* Mt, float* out, float* z, const float* bias, const float* scale, const float* shift,
-                                     int N, int H, int W, int C, int act, void* stream) {
-    if (!Mt || !out || !wino_shape_ok(N, H, W, C) || (scale && !shift)) return MRCNN_ERR_ARG;
+                                     int N, int H, int W, int C, int act, int tile, void* stream) {
+    if (!Mt || !out || !wino_shape_ok(N, H, W, C, tile) || (scale && !shift)) return MRCNN_ERR_ARG;
     if (act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) return MRCNN_ERR_UNSUPPORTED;
-    const long long T = wino_tiles(N, H, W);
-    hipLaunchKernelGGL(winograd_output_kernel, dim3((unsigned)cdiv64(T * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, Mt, out, z, bias,
-                       scale, shift, N, H, W, C, T, wino_rows(T), act);
+    const long long T = wino_tiles(N, H, W, tile);
+    WINO_LAUNCH(winograd_output_kernel, tile, T * C, Mt, out, z, bias, scale, shift, N, H, W, C, T, wino_rows(T), act, wino_tdim(H, tile),
+                wino_tdim(W, tile));
     return mrcnn_launch_status();
 }
 
 extern "C" int mrcnn_winograd_output_bwd(const float* Mt, float* dz_below, const float* below_out, const float* below_z, const float* scale,
                                          const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H, int W,
-                                         int C, int act, void* stream) {
-    if (!Mt || !dz_below || !wino_shape_ok(N, H, W, C)) return MRCNN_ERR_ARG;
+                                         int C, int act, int tile, void* stream) {
+    if (!Mt || !dz_below || !wino_shape_ok(N, H, W, C, tile)) return MRCNN_ERR_ARG;
     if ((act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) || (act == MRCNN_ACT_RELU && !below_out)) return MRCNN_ERR_ARG;
     if (dgamma && (!below_z || !mean || !rstd)) return MRCNN_ERR_ARG;
-    const int c4n = C >> 2;
-    if (c4n > 256 || (c4n & (c4n - 1))) return MRCNN_ERR_UNSUPPORTED;
+    const int cv = tile == 2 ? 4 : 2;
+    const int cn = C / cv;
+    if (cn > 256 || (cn & (cn - 1))) return MRCNN_ERR_UNSUPPORTED;
     int lg = 0;
-    while ((1 << lg) < c4n) ++lg;
-    const long long T = wino_tiles(N, H, W);
+    while ((1 << lg) < cn) ++lg;
+    const long long T = wino_tiles(N, H, W, tile);
     const long long R = 256 >> lg;
     long long per = (T + 2047) / 2048;                          // ~2048 workgroups; every one a whole number of passes
     per = (per + R - 1) / R * R;
-    hipLaunchKernelGGL(winograd_output_bwd_kernel, dim3((unsigned)cdiv64(T, per)), dim3(256), 0, (hipStream_t)stream, Mt, dz_below, below_out,
-                       below_z, scale, mean, rstd, dgamma, dbeta, dbias, N, H, W, C, T, wino_rows(T), act, per, lg);
+    const dim3 grid((unsigned)cdiv64(T, per));
+    if (tile == 2)
+        hipLaunchKernelGGL((winograd_output_bwd_kernel<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, Mt, dz_below, below_out, below_z, scale,
+                           mean, rstd, dgamma, dbeta, dbias, N, H, W, C, T, wino_rows(T), act, per, lg, wino_tdim(H, tile), wino_tdim(W, tile));
+    else
+        hipLaunchKernelGGL((winograd_output_bwd_kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, Mt, dz_below, below_out, below_z, scale,
+                           mean, rstd, dgamma, dbeta, dbias, N, H, W, C, T, wino_rows(T), act, per, lg, wino_tdim(H, tile), wino_tdim(W, tile));
     return mrcnn_launch_status();
 }
 
-extern "C" int mrcnn_winograd_dy(const float* dy, float* dM, int N, int H, int W, int C, void* stream) {
-    if (!dy || !dM || !wino_shape_ok(N, H, W, C)) return MRCNN_ERR_ARG;
-    const long long T = wino_tiles(N, H, W);
-    hipLaunchKernelGGL(winograd_dy_kernel, dim3((unsigned)cdiv64(T * (C >> 2), 256)), dim3(256), 0, (hipStream_t)stream, dy, dM, N, H, W, C, T,
-                       wino_rows(T));
+extern "C" int mrcnn_winograd_dy(const float* dy, float* dM, int N, int H, int W, int C, int tile, void* stream) {
+    if (!dy || !dM || !wino_shape_ok(N, H, W, C, tile)) return MRCNN_ERR_ARG;
+    const long long T = wino_tiles(N, H, W, tile);
+    WINO_LAUNCH(winograd_dy_kernel, tile, T * C, dy, dM, N, H, W, C, T, wino_rows(T), wino_tdim(H, tile), wino_tdim(W, tile));
     return mrcnn_launch_status();
 }
 
-extern "C" int mrcnn_winograd_dw(const float* dU, float* dw_hwio, int Cin, int Cout, int accumulate, void* stream) {
-    if (!dU || !dw_hwio || Cin <= 0 || Cout <= 0) return MRCNN_ERR_ARG;
-    hipLaunchKernelGGL(winograd_dw_kernel, dim3((unsigned)cdiv64((long long)Cin * Cout, 256)), dim3(256), 0, (hipStream_t)stream, dU, dw_hwio,
-                       Cin, Cout, accumulate);
+extern "C" int mrcnn_winograd_dw(const float* dU, float* dw_hwio, int Cin, int Cout, int accumulate, int tile, void* stream) {
+    if (!dU || !dw_hwio || Cin <= 0 || Cout <= 0 || (tile != 2 && tile != 4)) return MRCNN_ERR_ARG;
+    const dim3 grid((unsigned)cdiv64((long long)Cin * Cout, 256));
+    if (tile == 2) hipLaunchKernelGGL(winograd_dw_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dU, dw_hwio, Cin, Cout, accumulate);
+    else hipLaunchKernelGGL(winograd_dw_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dU, dw_hwio, Cin, Cout, accumulate);
     return mrcnn_launch_status();
 }
 

@@ -323,14 +323,17 @@ class MaskRCNNEngine(object):
         if not v:
             self._wino_valid = {}
 
-    def _wino_U(self, op, which):
-        """Winograd-domain kernel of layer `op`: which = 0 forward (from op.w), 1 data gradient (from the flipped / transposed
-        op.wt, which must be current).  Refreshed lazily after every weight update, in place."""
-        ent = self._wino.setdefault(op.name, [None, None])
-        ok = self._wino_valid.setdefault(op.name, [False, False])
+    def _wino_U(self, op, which, xshape):
+        """Winograd-domain kernel of layer `op` for an input of shape xshape (the shape picks the tile size): which = 0 forward
+        (from op.w), 1 data gradient (from the flipped / transposed op.wt, which must be current).  Refreshed lazily after every
+        weight update, in place."""
+        tile = ops.winograd_tile(tuple(xshape))
+        key = (op.name, tile)
+        ent = self._wino.setdefault(key, [None, None])
+        ok = self._wino_valid.setdefault(key, [False, False])
         if not ok[which]:
             src = op.w if which == 0 else op.wt
-            ent[which] = ops.winograd_weights(src, out=ent[which])
+            ent[which] = ops.winograd_weights(src, out=ent[which], tile=tile)
             ok[which] = True
         return ent[which]
 
@@ -851,7 +854,7 @@ class MaskRCNNEngine(object):
                     V = ops.empty((ops.winograd_v_floats(tuple(x.shape)),), torch.float32, self.dev) if (train and self.winograd_wgrad) else None
                     if V is not None:
                         self._wino_V[op.name] = [(V, 0, x.shape[0])]
-                    ops.conv2d_winograd(x, self._wino_U(op, 0), op.b, op.scale, op.shift, ACT_RELU, out=out, z_out=z, keep_v=V)
+                    ops.conv2d_winograd(x, self._wino_U(op, 0, x.shape), op.b, op.scale, op.shift, ACT_RELU, out=out, z_out=z, keep_v=V)
                     x, c = out, ((x, z, out, ACT_RELU) if train else None)
                 else:
                     x, c = op.forward(x, ACT_RELU, train=train)
@@ -893,7 +896,8 @@ class MaskRCNNEngine(object):
         cut = (N // 2 + 3) // 4 * 4
         halves = ((0, cut, main), (cut, N, side))
         ops_ = [self.op("mrcnn_mask_conv%d" % i) for i in range(1, 5)]
-        Us = [self._wino_U(op, 0) for op in ops_]                      # weight transforms on the main stream, before the fork
+        hshape = lambda op, a, b: (b - a,) + tuple(x.shape[1:3]) + (op.wshape[2],)
+        Us = [[self._wino_U(op, 0, hshape(op, a, b)) for a, b, _ in halves] for op in ops_]   # weight transforms on the main stream, before the fork
         outs, zs, ctxs = [], [], []
         cur = x
         for op in ops_:
@@ -903,8 +907,8 @@ class MaskRCNNEngine(object):
             ctxs.append((cur, z, out, ACT_RELU) if train else None)
             cur = out
             if train and self.winograd_wgrad:
-                self._wino_V[op.name] = [(ops.empty((ops.winograd_v_floats((b - a,) + tuple(x.shape[1:3]) + (op.wshape[2],)),), torch.float32,
-                                                    self.dev), a, b) for a, b, _ in halves]
+                self._wino_V[op.name] = [(ops.empty((ops.winograd_v_floats(hshape(op, a, b)),), torch.float32, self.dev), a, b)
+                                         for a, b, _ in halves]
         ev0 = _hip_mod.ev_record(main)                                   # x and the U's are ready
         lag = []
         for hi, (a, b, st) in enumerate(halves):
@@ -916,7 +920,7 @@ class MaskRCNNEngine(object):
                 for li, op in enumerate(ops_):
                     V = self._wino_V[op.name][hi][0] if (train and self.winograd_wgrad) else None
                     mark = (lambda: lag.append(_hip_mod.ev_record(main))) if (st is main and li == 0) else None
-                    ops.conv2d_winograd(inp, Us[li], op.b, op.scale, op.shift, ACT_RELU, out=outs[li][a:b],
+                    ops.conv2d_winograd(inp, Us[li][hi], op.b, op.scale, op.shift, ACT_RELU, out=outs[li][a:b],
                                         z_out=None if zs[li] is None else zs[li][a:b], keep_v=V, after_input=mark)
                     inp = outs[li][a:b]
         _hip_mod.stream_wait(main, side)
@@ -1191,14 +1195,14 @@ class MaskRCNNEngine(object):
                         ops.weight_flip_transpose(op.w, op.wt)
                     if wino and self.fused_dgrad_epilogue and below.bn is not None:
                         _, bz, bout, bact = bctx
-                        dz = ops.conv2d_dgrad_ep_winograd(dz, self._wino_U(op, 1), bout if bact != ACT_NONE else None, bz, below.scale,
+                        dz = ops.conv2d_dgrad_ep_winograd(dz, self._wino_U(op, 1, dz.shape), bout if bact != ACT_NONE else None, bz, below.scale,
                                                           below.mean, below.rstd, below.dgamma, below.dbeta, below.db, bact)
                     elif wino:
-                        dz = below.epilogue_bwd(ops.conv2d_winograd(dz, self._wino_U(op, 1)), bctx)[0]
+                        dz = below.epilogue_bwd(ops.conv2d_winograd(dz, self._wino_U(op, 1, dz.shape)), bctx)[0]
                     else:
                         dz = self._dgrad_ep(dz, op.wt, ((kh - 1) // 2, (kw - 1) // 2), below, bctx)
                 elif wino:
-                    d = ops.conv2d_winograd(dz, self._wino_U(op, 1))
+                    d = ops.conv2d_winograd(dz, self._wino_U(op, 1, dz.shape))
                 else:
                     d = op.dgrad(dz, c)
         else:

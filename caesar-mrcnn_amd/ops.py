@@ -664,9 +664,28 @@ def weights_to_h16(w, dtype=torch.float16, want_dgrad=True, out=None):
     return wf, wd
 
 
-# ---- Winograd F(2x2, 3x3), float32 (mask-head 3x3 convolutions) --------------------------------------------------------
+# ---- Winograd F(2x2, 3x3) / F(4x4, 3x3), float32 (mask-head 3x3 convolutions) ---------------------------------------------
 _WINO_PERSISTENT_GEMM = os.environ.get("MRCNN_WINOGRAD_GEMM", "persistent") != "blds"     # A/B: the one-tile-per-workgroup LDS-DMA kernel
 _WINO_MIN_ROWS = int(os.environ.get("MRCNN_WINOGRAD_MIN_ROWS", "16384"))   # 84 ROIs of 14 x 14: detect's 100 detections take the path (3.48 -> 3.18 ms/image)
+# 4: F(4x4, 3x3) for layers of at least _WINO_TILE4_MIN_ROWS pixels (512 ROIs of 14 x 14: the training step's layers and their
+# halves; detect's 100 ROIs per image stay on F(2x2, 3x3)); headline step 44.5 -> 40.9 ms.  2: F(2x2, 3x3) everywhere
+_WINO_TILE = int(os.environ.get("MRCNN_WINOGRAD_TILE", "4"))
+_WINO_TILE4_MIN_ROWS = int(os.environ.get("MRCNN_WINOGRAD_TILE4_MIN_ROWS", "100352"))
+
+
+def winograd_tile(xshape):
+    """Outputs per tile and dimension for a layer of this input shape: 4 (36 GEMMs over a quarter of the tiles, 1.36 x fewer
+    multiplications on 14 x 14 maps, about one decimal digit less accurate: 1.3e-5 of the result's range against 1.6e-6) for
+    training-sized layers, else 2; MRCNN_WINOGRAD_TILE=2 keeps 2 everywhere.  A pure function of the shape, so the forward pass,
+    the data gradient and the weight gradient of a layer agree on it."""
+    N, H, W, _ = xshape
+    return 4 if (_WINO_TILE == 4 and N * H * W >= _WINO_TILE4_MIN_ROWS) else 2
+
+
+def _wino_tile_of(U):
+    nb = U.shape[0]
+    assert nb in (16, 36), "U is not a Winograd weight transform"
+    return 2 if nb == 16 else 4
 
 
 def winograd_ok(xshape, wshape, stride=1, padding="same", min_rows=None):
@@ -680,42 +699,45 @@ def winograd_ok(xshape, wshape, stride=1, padding="same", min_rows=None):
             Cin % 16 == 0 and cout % 128 == 0 and N * H * W >= min_rows and N * (H // 2) * (W // 2) * 16 * max(Cin, cout) < 2 ** 31)
 
 
-def winograd_weights(w, out=None):
-    """HWIO 3 x 3 kernel -> U [16, Cin, Cout] = G g G^T."""
+def winograd_weights(w, out=None, tile=2):
+    """HWIO 3 x 3 kernel -> U [(tile + 2)^2, Cin, Cout] = G g G^T."""
     _need_cuda(w, out)
     kh, kw, cin, cout = w.shape
     assert kh == 3 and kw == 3 and w.is_contiguous()
+    nb = (tile + 2) ** 2
     if out is None:
-        out = torch.empty((16, cin, cout), dtype=torch.float32, device=w.device)
-    check(_hip.lib().mrcnn_winograd_weights(ptr(w), ptr(out), cin, cout, current_stream()), "mrcnn_winograd_weights")
+        out = torch.empty((nb, cin, cout), dtype=torch.float32, device=w.device)
+    assert out.shape[0] == nb
+    check(_hip.lib().mrcnn_winograd_weights(ptr(w), ptr(out), cin, cout, tile, current_stream()), "mrcnn_winograd_weights")
     return out
 
 
 def _winograd_product(x, U, keep_v=None, after_input=None):
-    """Input transform + the 16 transform-domain GEMMs; returns Mt (a per-stream scratch buffer, valid until the next call).
+    """Input transform + the transform-domain GEMMs; returns Mt (a per-stream scratch buffer, valid until the next call).
     keep_v: a float32 tensor of mrcnn_winograd_buffer_floats elements that receives V (the weight gradient reuses it)."""
     N, H, W, Cin = x.shape
-    cout = U.shape[2]
+    nb, _, cout = U.shape
+    tile = _wino_tile_of(U)
     lib = _hip.lib()
-    nv, nm = lib.mrcnn_winograd_buffer_floats(N, H, W, Cin), lib.mrcnn_winograd_buffer_floats(N, H, W, cout)
+    nv, nm = lib.mrcnn_winograd_buffer_floats(N, H, W, Cin, tile), lib.mrcnn_winograd_buffer_floats(N, H, W, cout, tile)
     V = keep_v if keep_v is not None else workspace(nv * 4, x.device, "winograd_v")
     assert keep_v is None or (keep_v.numel() == nv and keep_v.dtype == torch.float32)
     Mt = workspace(nm * 4, x.device, "winograd_m")
-    check(lib.mrcnn_winograd_input(ptr(x), ptr(V), N, H, W, Cin, current_stream()), "mrcnn_winograd_input")
+    check(lib.mrcnn_winograd_input(ptr(x), ptr(V), N, H, W, Cin, tile, current_stream()), "mrcnn_winograd_input")
     if after_input is not None:
         after_input()                    # e.g. an event: a second chain on another stream starts one transform behind this one
     gemm = lib.mrcnn_winograd_gemm if _WINO_PERSISTENT_GEMM else lib.mrcnn_gemm_batched_f32
-    check(gemm(ptr(V), ptr(U), ptr(Mt), 16, nv // (16 * Cin), Cin, cout, current_stream()), "mrcnn_winograd_gemm")
+    check(gemm(ptr(V), ptr(U), ptr(Mt), nb, nv // (nb * Cin), Cin, cout, current_stream()), "mrcnn_winograd_gemm")
     return Mt
 
 
-def winograd_v_floats(xshape):
+def winograd_v_floats(xshape, tile=None):
     N, H, W, Cin = xshape
-    return _hip.lib().mrcnn_winograd_buffer_floats(N, H, W, Cin)
+    return _hip.lib().mrcnn_winograd_buffer_floats(N, H, W, Cin, winograd_tile(xshape) if tile is None else tile)
 
 
 def conv2d_winograd(x, U, bias=None, scale=None, shift=None, act=ACT_NONE, out=None, z_out=None, keep_v=None, after_input=None):
-    """3 x 3 'same' stride-1 convolution with its epilogue through the Winograd domain (U = winograd_weights(w))."""
+    """3 x 3 'same' stride-1 convolution with its epilogue through the Winograd domain (U = winograd_weights(w, tile=...))."""
     _need_cuda(x, U, bias, scale, shift, out, z_out, keep_v)
     N, H, W, _ = x.shape
     cout = U.shape[2]
@@ -723,7 +745,7 @@ def conv2d_winograd(x, U, bias=None, scale=None, shift=None, act=ACT_NONE, out=N
         out = empty((N, H, W, cout), torch.float32, x.device)
     Mt = _winograd_product(x, U, keep_v, after_input)
     check(_hip.lib().mrcnn_winograd_output(ptr(Mt), ptr(out), ptr(z_out), ptr(bias), ptr(scale), ptr(shift), N, H, W, cout, act,
-                                           current_stream()), "mrcnn_winograd_output")
+                                           _wino_tile_of(U), current_stream()), "mrcnn_winograd_output")
     return out
 
 
@@ -736,31 +758,38 @@ def conv2d_dgrad_ep_winograd(dz, Ut, below_out, below_z, scale, mean, rstd, dgam
     out = empty((N, H, W, cout), torch.float32, dz.device)
     Mt = _winograd_product(dz, Ut)
     check(_hip.lib().mrcnn_winograd_output_bwd(ptr(Mt), ptr(out), ptr(below_out), ptr(below_z), ptr(scale), ptr(mean), ptr(rstd),
-                                               ptr(dgamma), ptr(dbeta), ptr(dbias), N, H, W, cout, act, current_stream()),
-          "mrcnn_winograd_output_bwd")
+                                               ptr(dgamma), ptr(dbeta), ptr(dbias), N, H, W, cout, act, _wino_tile_of(Ut),
+                                               current_stream()), "mrcnn_winograd_output_bwd")
     return out
 
 
-def conv2d_wgrad_winograd(V, xshape, dz, dw, accumulate=False):
+def conv2d_wgrad_winograd(V, xshape, dz, dw, accumulate=False, tile=None):
     """Weight gradient of a 3 x 3 'same' convolution through the Winograd domain: V = the forward's input transform of x
-    (conv2d_winograd(..., keep_v=V)), dz [N, H, W, Cout] -> dw [3, 3, Cin, Cout] float32."""
+    (conv2d_winograd(..., keep_v=V)), dz [N, H, W, Cout] -> dw [3, 3, Cin, Cout] float32.  tile: the forward's (default:
+    winograd_tile(xshape), what the forward chose for this shape)."""
     _need_cuda(V, dz, dw)
     N, H, W, Cin = xshape
     cout = dz.shape[3]
+    if tile is None:
+        tile = winograd_tile(xshape)
+    nb = (tile + 2) ** 2
     lib = _hip.lib()
-    nm = lib.mrcnn_winograd_buffer_floats(N, H, W, cout)
-    rows = nm // (16 * cout)
-    T = N * (H // 2) * (W // 2)
-    dM = workspace(nm * 4, dz.device, "winograd_dm")[:nm * 4].view(torch.float32).view(16, rows, cout)
-    dU = workspace(16 * Cin * cout * 4, dz.device, "winograd_du")[:16 * Cin * cout * 4].view(torch.float32).view(16, Cin, cout)
-    check(lib.mrcnn_winograd_dy(ptr(dz), ptr(dM), N, H, W, cout, current_stream()), "mrcnn_winograd_dy")
-    Vv = V.view(16, rows, Cin)
+    nm = lib.mrcnn_winograd_buffer_floats(N, H, W, cout, tile)
+    assert V.numel() == lib.mrcnn_winograd_buffer_floats(N, H, W, Cin, tile), "V was made with another tile size"
+    rows = nm // (nb * cout)
+    T = N * ((H + tile - 1) // tile) * ((W + tile - 1) // tile)
+    dM = workspace(nm * 4, dz.device, "winograd_dm")[:nm * 4].view(torch.float32).view(nb, rows, cout)
+    dU = workspace(nb * Cin * cout * 4, dz.device, "winograd_du")[:nb * Cin * cout * 4].view(torch.float32).view(nb, Cin, cout)
+    check(lib.mrcnn_winograd_dy(ptr(dz), ptr(dM), N, H, W, cout, tile, current_stream()), "mrcnn_winograd_dy")
+    Vv = V.view(nb, rows, Cin)
     items = [(Vv[k, :T].view(T, 1, 1, Cin), dM[k, :T].view(T, 1, 1, cout), (1, 1, Cin, cout), 1, "valid", dU[k].view(1, 1, Cin, cout), False)
-             for k in range(16)]
-    if not conv2d_wgrad_multi(items):                          # one launch for the 16 GEMMs (+ one for their slab reductions)
-        for x_, dy_, wshape, stride, padding, dw_, acc in items:
-            conv2d_wgrad(x_, dy_, wshape, stride, padding, dw=dw_, accumulate=acc)
-    check(lib.mrcnn_winograd_dw(ptr(dU), ptr(dw), Cin, cout, 1 if accumulate else 0, current_stream()), "mrcnn_winograd_dw")
+             for k in range(nb)]
+    per = 16 if nb == 16 else 12                               # GEMMs per launch (+ one launch for their slab reductions): the argument block holds 16
+    for i in range(0, nb, per):
+        if not conv2d_wgrad_multi(items[i:i + per]):
+            for x_, dy_, wshape, stride, padding, dw_, acc in items[i:i + per]:
+                conv2d_wgrad(x_, dy_, wshape, stride, padding, dw=dw_, accumulate=acc)
+    check(lib.mrcnn_winograd_dw(ptr(dU), ptr(dw), Cin, cout, 1 if accumulate else 0, tile, current_stream()), "mrcnn_winograd_dw")
     return dw
 
 

@@ -389,28 +389,30 @@ int mrcnn_sgd_momentum_guarded(float* params, float* momentum_buf, const float* 
                                float clipnorm, float lr, float momentum, const float* gran_coef, int64_t n,
                                unsigned* skipped_steps, void* stream);
 
-/* ---- Winograd F(2x2, 3x3) for the stride-1 "same" 3x3 convolutions of the mask head (KL.Conv2D(256, (3, 3), padding="same"),
- * mrcnn/model.py:1058-1082), float32: 16 multiplications per 2 x 2 outputs and channel pair instead of 36.  Three launches per
- * layer -- input transform, the 16 transform-domain GEMMs as ONE launch of the LDS-DMA convolution kernel, output transform with
- * the layer's epilogue (or, for a data gradient, the epilogue backward of the layer below) -- and one weight transform per weight
- * update.  H, W even; C % 4 == 0 (GEMM: K % 16 == 0, Cout % 128 == 0).  V / Mt hold mrcnn_winograd_buffer_floats floats each:
- * [16][rows][C] with rows = tiles rounded up to whole 128-row tiles.  The transforms use +-1 and 1/2 only, so the result differs
- * from the direct kernels by float32 summation order (measured 2e-6 of the output maximum).                                    */
-size_t mrcnn_winograd_buffer_floats(int N, int H, int W, int C);
-int mrcnn_winograd_weights(const float* w_hwio, float* U, int Cin, int Cout, void* stream);          /* U [16][Cin][Cout] */
-int mrcnn_winograd_input(const float* x, float* V, int N, int H, int W, int C, void* stream);
+/* ---- Winograd F(m x m, 3x3), m = `tile` = 2 or 4, for the stride-1 "same" 3x3 convolutions of the mask head
+ * (KL.Conv2D(256, (3, 3), padding="same"), mrcnn/model.py:1058-1082), float32: (m + 2)^2 multiplications per m x m outputs and
+ * channel pair instead of 9 m^2 -- 16 per 4 (tile 2) or 36 per 16 (tile 4).  Three launches per layer -- input transform, the
+ * (m + 2)^2 transform-domain GEMMs as ONE launch, output transform with the layer's epilogue (or, for a data gradient, the epilogue
+ * backward of the layer below) -- and one weight transform per weight update.  C % 4 == 0 (GEMM: K % 16 == 0, Cout % 128 == 0);
+ * tile 2 wants H, W even, tile 4 takes any extent (edge tiles hang over the map: their inputs read as zero, their outputs are
+ * dropped).  V / Mt hold mrcnn_winograd_buffer_floats floats each: [(m + 2)^2][rows][C], rows = tiles rounded up to whole 128-row
+ * tiles.  Tile 2 uses +-1 and 1/2 only: the result differs from the direct kernels by float32 summation order (measured 2e-6 of
+ * the output maximum); tile 4 has constants up to 8 and costs about one more decimal digit (measured 1e-5).                       */
+size_t mrcnn_winograd_buffer_floats(int N, int H, int W, int C, int tile);
+int mrcnn_winograd_weights(const float* w_hwio, float* U, int Cin, int Cout, int tile, void* stream);   /* U [(m + 2)^2][Cin][Cout] */
+int mrcnn_winograd_input(const float* x, float* V, int N, int H, int W, int C, int tile, void* stream);
 int mrcnn_gemm_batched_f32(const float* V, const float* U, float* Mt, int nb, int rows, int K, int Cout, void* stream);
 /* the same product by persistent workgroups (next tile's first stage in flight under the current tile's stores): the default */
 int mrcnn_winograd_gemm(const float* V, const float* U, float* Mt, int nb, int rows, int K, int Cout, void* stream);
 int mrcnn_winograd_output(const float* Mt, float* out, float* z_out, const float* bias, const float* scale, const float* shift,
-                          int N, int H, int W, int C, int act, void* stream);
-/* weight gradient: dM = A dy A^T (adjoint of the output transform) [16][rows][C]; dU[xi] = V[xi]^T . dM[xi] are 16 1 x 1 weight
+                          int N, int H, int W, int C, int act, int tile, void* stream);
+/* weight gradient: dM = A dy A^T (adjoint of the output transform) [(m + 2)^2][rows][C]; dU[xi] = V[xi]^T . dM[xi] are 1 x 1 weight
  * gradients (mrcnn_conv2d_wgrad on the first `tiles` rows of each matrix); dW = G^T dU G (accumulate != 0: added to dW).       */
-int mrcnn_winograd_dy(const float* dy, float* dM, int N, int H, int W, int C, void* stream);
-int mrcnn_winograd_dw(const float* dU, float* dw_hwio, int Cin, int Cout, int accumulate, void* stream);
+int mrcnn_winograd_dy(const float* dy, float* dM, int N, int H, int W, int C, int tile, void* stream);
+int mrcnn_winograd_dw(const float* dU, float* dw_hwio, int Cin, int Cout, int accumulate, int tile, void* stream);
 int mrcnn_winograd_output_bwd(const float* Mt, float* dz_below, const float* below_out, const float* below_z, const float* scale,
                               const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H, int W,
-                              int C, int act, void* stream);
+                              int C, int act, int tile, void* stream);
 
 /* ---- data-parallel gradient exchange over RCCL / xGMI ---------------------------------------------------------------
  * Replaces the in-graph tower aggregation of mrcnn/parallel_model.py:54-104 (weights shared between towers, gradients

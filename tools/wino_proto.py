@@ -1,20 +1,16 @@
 #!/usr/bin/env python3
-"""Winograd F(2x2,3x3) prototype on the mask-head layer: correctness against the direct float32 kernel, stage timings (tools only)."""
-import os, sys, ctypes as C
+"""The Winograd path on the mask-head layer, tile 2 (F(2x2,3x3)) and tile 4 (F(4x4,3x3)): forward, data gradient with the fused
+epilogue backward and weight gradient against the direct float32 kernels (error relative to the result's maximum), and the time of
+every stage (tools only).  usage: wino_proto.py [ROIs]"""
+import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from caesar_mrcnn_amd import ops, _hip
 lib = _hip.lib()
-P = C.c_void_p
-lib.mrcnn_winograd_input.argtypes = [P, P, C.c_int, C.c_int, C.c_int, C.c_int, P]
-lib.mrcnn_winograd_weights.argtypes = [P, P, C.c_int, C.c_int, P]
-lib.mrcnn_winograd_output.argtypes = [P, P, P, P, P, P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, P]
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 H = W = 14; Cc = 256
-T = N * 49
-st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
-ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+st, ptr = ops.current_stream, ops.ptr
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 def timed(fn, reps=10):
     for _ in range(2): fn()
@@ -22,44 +18,43 @@ def timed(fn, reps=10):
     for _ in range(reps): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
+rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
 torch.manual_seed(0)
-x = torch.randn(N, H, W, Cc, device=dev)
+x = torch.relu(torch.randn(N, H, W, Cc, device=dev))
 w = torch.randn(3, 3, Cc, Cc, device=dev) * 0.03
 b = torch.randn(Cc, device=dev) * 0.1
 sc = torch.rand(Cc, device=dev) + 0.5; sh = torch.randn(Cc, device=dev) * 0.1
-V = torch.empty(16, T, Cc, device=dev); Mt = torch.empty(16, T, Cc, device=dev)
-U = torch.empty(16, Cc, Cc, device=dev)
-y = torch.empty_like(x); z = torch.empty_like(x)
-f_in = lambda: lib.mrcnn_winograd_input(ptr(x), ptr(V), N, H, W, Cc, st())
-f_w = lambda: lib.mrcnn_winograd_weights(ptr(w), ptr(U), Cc, Cc, st())
-def f_gemm():
-    for k in range(16):
-        ops.conv2d(V[k].view(T, 1, 1, Cc), U[k].view(1, 1, Cc, Cc), None, None, None, out=Mt[k].view(T, 1, 1, Cc), stride=1, padding="valid")
-f_out = lambda: lib.mrcnn_winograd_output(ptr(Mt), ptr(y), ptr(z), ptr(b), ptr(sc), ptr(sh), N, H, W, Cc, 1, st())
-assert f_w() == 0 and f_in() == 0
-f_gemm()
-assert f_out() == 0
+mean = torch.randn(Cc, device=dev) * 0.1; rstd = torch.rand(Cc, device=dev) + 0.5
+dy = torch.randn(N, H, W, Cc, device=dev)
+wt = w.flip(0, 1).permute(0, 1, 3, 2).contiguous()
 yr = torch.empty_like(x); zr = torch.empty_like(x)
 ops.conv2d(x, w, b, sc, sh, act=1, out=yr, z_out=zr)
-torch.cuda.synchronize()
-print("max |y - direct| / max |direct| = %.3g   z: %.3g" % (float((y - yr).abs().max() / yr.abs().max()), float((z - zr).abs().max() / zr.abs().max())))
-t_in, t_g, t_out, t_w = timed(f_in), timed(f_gemm), timed(f_out), timed(f_w)
-Vb = V.view(16 * T, 1, 1, Cc); Mb = Mt.view(16 * T, 1, 1, Cc)
-t_g1 = timed(lambda: ops.conv2d(Vb, U[0].view(1, 1, Cc, Cc), None, None, None, out=Mb, stride=1, padding="valid"))
+dwr = torch.empty_like(w); ops.conv2d_wgrad(x, dy, (3, 3, Cc, Cc), 1, "same", dw=dwr)
+sums_r = [torch.zeros(Cc, device=dev) for _ in range(3)]
+dxr = ops.conv2d_dgrad_ep(dy, wt, "same", yr, zr, sc, mean, rstd, sums_r[0], sums_r[1], sums_r[2], 1)
 t_d = timed(lambda: ops.conv2d(x, w, b, sc, sh, act=1, out=yr, z_out=zr))
-print("input transform %.3f ms, 16 GEMM launches %.3f ms (one launch of the same rows: %.3f), output transform %.3f ms, weights %.3f ms" % (t_in, t_g, t_g1, t_out, t_w))
-print("Winograd total %.3f ms (with a batched GEMM launch: %.3f)  direct %.3f ms" % (t_in + t_g + t_out, t_in + t_g1 + t_out, t_d))
-# beside a weight gradient on another stream (what the step does)
-from caesar_mrcnn_amd.engine import _side_streams
-side = _side_streams(dev)[0]; main = torch.cuda.current_stream(dev)
-dy = torch.randn_like(x); dw = torch.empty(3, 3, Cc, Cc, device=dev)
-def pair(fwd):
-    side.wait_stream(main)
-    with torch.cuda.stream(side):
-        ops.conv2d_wgrad(x, dy, (3, 3, Cc, Cc), 1, "same", dw=dw)
-    fwd()
-    main.wait_stream(side)
-def wino():
-    f_in(); ops.conv2d(Vb, U[0].view(1, 1, Cc, Cc), None, None, None, out=Mb, stride=1, padding="valid"); f_out()
-t_pw = timed(lambda: pair(wino)); t_pd = timed(lambda: pair(lambda: ops.conv2d(x, w, b, sc, sh, act=1, out=yr, z_out=zr)))
-print("beside the layer's weight gradient on the side stream: Winograd (batched proxy) %.3f ms, direct %.3f ms" % (t_pw, t_pd))
+t_dw = timed(lambda: ops.conv2d_wgrad(x, dy, (3, 3, Cc, Cc), 1, "same", dw=dwr))
+print("direct: forward %.3f ms, weight gradient %.3f ms" % (t_d, t_dw))
+for tile in (2, 4):
+    nb = (tile + 2) ** 2
+    nv = lib.mrcnn_winograd_buffer_floats(N, H, W, Cc, tile)
+    rows = nv // (nb * Cc)
+    V = torch.empty(nv, device=dev); Mt = torch.empty(nv, device=dev)
+    U = ops.winograd_weights(w, tile=tile); Ut = ops.winograd_weights(wt, tile=tile)
+    y = torch.empty_like(x); z = torch.empty_like(x)
+    ops.conv2d_winograd(x, U, b, sc, sh, 1, out=y, z_out=z, keep_v=V)
+    dw = torch.empty_like(w); ops.conv2d_wgrad_winograd(V, tuple(x.shape), dy, dw, tile=tile)
+    line = "tile %d: forward %.3g (z %.3g), weight gradient %.3g" % (tile, rel(y, yr), rel(z, zr), rel(dw, dwr))
+    if dxr is not None:
+        sums = [torch.zeros(Cc, device=dev) for _ in range(3)]
+        dx = ops.conv2d_dgrad_ep_winograd(dy, Ut, yr, zr, sc, mean, rstd, sums[0], sums[1], sums[2], 1)
+        line += ", data gradient %.3g, channel sums %.3g %.3g %.3g" % ((rel(dx, dxr),) + tuple(rel(a, c) for a, c in zip(sums, sums_r)))
+    print(line, flush=True)
+    t_in = timed(lambda: lib.mrcnn_winograd_input(ptr(x), ptr(V), N, H, W, Cc, tile, st()))
+    t_g = timed(lambda: lib.mrcnn_winograd_gemm(ptr(V), ptr(U), ptr(Mt), nb, rows, Cc, Cc, st()))
+    t_out = timed(lambda: lib.mrcnn_winograd_output(ptr(Mt), ptr(y), ptr(z), ptr(b), ptr(sc), ptr(sh), N, H, W, Cc, 1, tile, st()))
+    t_l = timed(lambda: ops.conv2d_winograd(x, U, b, sc, sh, 1, out=y, z_out=z))
+    t_w = timed(lambda: ops.conv2d_wgrad_winograd(V, tuple(x.shape), dy, dw, tile=tile))
+    t_dyt = timed(lambda: lib.mrcnn_winograd_dy(ptr(dy), ptr(Mt), N, H, W, Cc, tile, st()))
+    print("        input %.3f ms, %d GEMMs %.3f ms (%.1f TFLOP/s), output %.3f ms, layer %.3f ms; weight gradient %.3f ms (dy transform %.3f)"
+          % (t_in, nb, t_g, 2.0 * nb * rows * Cc * Cc / t_g / 1e9, t_out, t_l, t_w, t_dyt), flush=True)
