@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_blds_kernel(const WgradArgs
 
 // Up to WGRAD_MULTI_MAX weight gradients in one launch (mrcnn_conv2d_wgrad_multi): the three convolutions of a
 // bottleneck block.  Workgroups first[g] .. first[g+1]-1 belong to problem g; the slab reductions share a launch too.
-#define WGRAD_MULTI_MAX 16      // 4 covers a bottleneck block; 16 = the transform-domain weight gradients of a Winograd layer
+#define WGRAD_MULTI_MAX 16      // 4 covers a bottleneck block; 16 = the transform-domain weight gradients of a Winograd F(2x2) layer (F(4x4): 3 x 12; 18 per launch measured no faster)
 struct WgradMultiArgs {
     WgradArgs a[WGRAD_MULTI_MAX];
     unsigned x_shift[WGRAD_MULTI_MAX], x_records[WGRAD_MULTI_MAX];
@@ -467,6 +467,8 @@ struct WgradMultiArgs {
     int rfirst[WGRAD_MULTI_MAX + 1];      // reduction launch: blocks of 256 float4
     int n;
 };
+
+static_assert(sizeof(WgradMultiArgs) <= 4096, "kernel argument block");
 
 template <int BP>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_blds_multi_kernel(const WgradMultiArgs mp) {
