@@ -387,9 +387,18 @@ __global__ __launch_bounds__(256) void winograd_dw_kernel(const float* __restric
 typedef __attribute__((address_space(3))) void* wino_lds_ptr;
 #define WINO_OOB 0xFFFFFFF0u
 
-template <int TN>      // 2: 128 x 128 tile (5 workgroups per CU); 4: 128 x 256 tile -- N = 256 whole: every V row block is fetched once
+// DECONV: the product is a 2 x 2 stride-2 transposed convolution (mrcnn_deconv2x2_gemm): row m = input pixel (img, h, w), column
+// n = (tap a b, channel co) -> out[img][2 h + a][2 w + b][co] = act(acc + bias[co]) -- the pixel-shuffle store of the direct kernel
+struct GemmDeconvEp {
+    const float* bias;
+    int Cd, H, W, act;
+    FastDiv d_hw, d_w;
+};
+
+template <int TN, bool DECONV>      // TN 2: 128 x 128 tile (5 workgroups per CU); 4: 128 x 256 tile -- N = 256 whole: every V row block is fetched once
 __global__ __launch_bounds__(256, 2) void winograd_gemm_kernel(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ Mt,
-                                                               int rows, int K, int N, int total_tiles, unsigned v_records) {
+                                                               int rows, int K, int N, int total_tiles, unsigned v_records,
+                                                               const GemmDeconvEp ep) {
     constexpr int BM = 128, BN = 64 * TN, BK = 16, TM = 2;
     constexpr int AF = BM * BK, BF = BK * BN;
     __shared__ __attribute__((aligned(16))) float lds[2 * (AF + BF)];
@@ -489,15 +498,45 @@ __global__ __launch_bounds__(256, 2) void winograd_gemm_kernel(const float* __re
         const bool more = next < total_tiles;
         if (more) { k0 = 0; setup(next); stage(lds); }                         // its first stage travels under this tile's stores
         const int Mtot = (int)(v_records / (unsigned)(K * 4));
+        if constexpr (!DECONV) {
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+            for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
+                for (int b = 0; b < TN; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mw0 + a * 32 + (r & 3) + 8 * (r >> 2);
+                        if (m < Mtot) Mt[(long long)m * N + nw0 + b * 32] = acc[a][b][r];
+                    }
+        } else {
+            float bi[TN];
+            int coff[TN];                                                      // (a * 2 W + b) * Cd + co of this lane's column in group b
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int n = nw0 + b * 32;
+                const int tap = (n >= ep.Cd) + (n >= 2 * ep.Cd) + (n >= 3 * ep.Cd);
+                const int co = n - tap * ep.Cd;
+                bi[b] = ep.bias ? ep.bias[co] : 0.f;
+                coff[b] = ((tap >> 1) * 2 * ep.W + (tap & 1)) * ep.Cd + co;
+            }
+            const int hw = ep.H * ep.W;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int m = mw0 + a * 32 + (r & 3) + 8 * (r >> 2);
-                    if (m < Mtot) Mt[(long long)m * N + nw0 + b * 32] = acc[a][b][r];
+                    if (m >= Mtot) continue;
+                    const int img = (int)fast_div((unsigned)m, ep.d_hw), rem = m - img * hw;
+                    const int h = (int)fast_div((unsigned)rem, ep.d_w), w = rem - h * ep.W;
+                    const long long base = (((long long)img * 2 * ep.H + 2 * h) * 2 * ep.W + 2 * w) * ep.Cd;
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        float v = acc[a][b][r] + bi[b];
+                        if (ep.act == MRCNN_ACT_RELU) v = fmaxf(v, 0.f);
+                        Mt[base + coff[b]] = v;
+                    }
                 }
+        }
         if (!more) break;
         tile = next;
     }
@@ -605,18 +644,42 @@ extern "C" int mrcnn_winograd_gemm(const float* V, const float* U, float* Mt, in
     // is fetched once), but inside the step it is slower (44.0 -> 44.9 ms): at 166 VGPRs / 48 KiB it leaves less room for the
     // other stream's kernels on a CU
     static const int wide = getenv("MRCNN_WINOGRAD_GEMM_WIDE") ? atoi(getenv("MRCNN_WINOGRAD_GEMM_WIDE")) : 0;
+    const GemmDeconvEp none = {};
     if (wide && N % 256 == 0) {                                 // 128 x 256 tiles: 48 KiB LDS, 3 workgroups per CU
         const long long tiles = (M / 128) * (N / 256);
         const long long slots = 3LL * mrcnn_num_cus();
         const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
-        hipLaunchKernelGGL(winograd_gemm_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, V, U, Mt, rows, K, N, (int)tiles,
-                           (unsigned)(M * K * 4));
+        hipLaunchKernelGGL((winograd_gemm_kernel<4, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, V, U, Mt, rows, K, N, (int)tiles,
+                           (unsigned)(M * K * 4), none);
         return mrcnn_launch_status();
     }
     const long long tiles = (M / 128) * (N / 128);
     const long long slots = 5LL * mrcnn_num_cus();
     const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
-    hipLaunchKernelGGL(winograd_gemm_kernel<2>, dim3(grid), dim3(256), 0, (hipStream_t)stream, V, U, Mt, rows, K, N, (int)tiles,
-                       (unsigned)(M * K * 4));
+    hipLaunchKernelGGL((winograd_gemm_kernel<2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, V, U, Mt, rows, K, N, (int)tiles,
+                       (unsigned)(M * K * 4), none);
+    return mrcnn_launch_status();
+}
+
+/* Conv2DTranspose(2 x 2, stride 2) as ONE product [N H W x Cin] . [Cin x 4 Cd] on the persistent GEMM above with the pixel-shuffle
+ * store in its epilogue (bias, ReLU): K is one filter tap deep (256 in the mask head), the case the persistent form exists for.
+ * w_gemm [Cin][(a, b, co)]; out [N][2 H][2 W][Cd].  Cin % 16 == 0, Cd % 32 == 0, 4 Cd % 128 == 0. */
+extern "C" int mrcnn_deconv2x2_gemm(const float* x, const float* w_gemm, const float* bias, float* out, int N, int H, int W, int Cin, int Cd,
+                                    int act, void* stream) {
+    if (!x || !w_gemm || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cd <= 0) return MRCNN_ERR_ARG;
+    if (act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) return MRCNN_ERR_UNSUPPORTED;
+    const long long M = (long long)N * H * W;
+    const int Nn = 4 * Cd;
+    if (Cin % 16 || Cd % 32 || Nn % 128 || M * Cin * 4 >= 0x7FFFFFF0LL || (long long)Cin * Nn * 4 >= 0x7FFFFFF0LL || M >= (1LL << 31) - 128)
+        return MRCNN_ERR_UNSUPPORTED;
+    GemmDeconvEp ep = {};
+    ep.bias = bias; ep.Cd = Cd; ep.H = H; ep.W = W; ep.act = act;
+    ep.d_hw = make_fastdiv((unsigned)(H * W)); ep.d_w = make_fastdiv((unsigned)W);
+    const long long tiles = ((M + 127) / 128) * (Nn / 128);
+    const long long slots = 5LL * mrcnn_num_cus();
+    const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+    const int rows = (int)((M + 127) / 128 * 128);              // one matrix: every tile uses weight matrix 0
+    hipLaunchKernelGGL((winograd_gemm_kernel<2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w_gemm, out, rows, Cin, Nn, (int)tiles,
+                       (unsigned)(M * Cin * 4), ep);
     return mrcnn_launch_status();
 }

@@ -172,19 +172,29 @@ def conv2d_multi(problems):
     return outs
 
 
+_DECONV_GEMM = os.environ.get("MRCNN_DECONV_GEMM", "1") != "0"          # transposed convolution on the persistent GEMM (A/B switch)
+_DECONV_GEMM_MIN_ROWS = int(os.environ.get("MRCNN_DECONV_GEMM_MIN_ROWS", "16384"))
+
+
 def deconv2x2(x, w_gemm, bias, act=ACT_RELU, out=None):
     """Conv2DTranspose(2x2, stride 2): x [N,H,W,Cin], w_gemm [Cin, 4*Cd] with column (a*2+b)*Cd+co."""
     _need_cuda(x, w_gemm, bias, out)
     N, H, W, Cin = x.shape
     Cd = w_gemm.shape[1] // 4
+    if out is None:
+        out = empty((N, 2 * H, 2 * W, Cd), torch.float32, x.device)
+    if (_DECONV_GEMM and Cin % 16 == 0 and Cd % 32 == 0 and (4 * Cd) % 128 == 0 and act in (ACT_NONE, ACT_RELU) and
+            N * H * W * Cin * 4 < 0x7FFFFFF0 and N * H * W >= _DECONV_GEMM_MIN_ROWS):
+        # one filter tap of K: the persistent GEMM with the pixel-shuffle store in its epilogue
+        check(_hip.lib().mrcnn_deconv2x2_gemm(ptr(x), ptr(w_gemm), ptr(bias), ptr(out), N, H, W, Cin, Cd, act, current_stream()),
+              "mrcnn_deconv2x2_gemm")
+        return out
     d = _hip.ConvDesc()
     d.N, d.H, d.W, d.Cin, d.Cout, d.KH, d.KW, d.stride, d.pad_t, d.pad_l = N, H, W, Cin, 4 * Cd, 1, 1, 1, 0, 0
     d.OH, d.OW, d.act, d.res_mode, d.out_mode, d.cmod = H, W, act, RES_NONE, OUT_DECONV2, Cd
     d.out_w_stride = Cd
     d.out_h_stride = 2 * W * Cd
     d.out_n_stride = 4 * H * W * Cd
-    if out is None:
-        out = empty((N, 2 * H, 2 * W, Cd), torch.float32, x.device)
     check(_hip.lib().mrcnn_conv2d_fwd(C.byref(d), ptr(x), ptr(w_gemm), ptr(bias), None, None, None, ptr(out), None,
                                       current_stream()), "mrcnn_conv2d_fwd(deconv)")
     return out

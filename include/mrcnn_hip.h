@@ -414,6 +414,14 @@ int mrcnn_winograd_output_bwd(const float* Mt, float* dz_below, const float* bel
                               const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H, int W,
                               int C, int act, int tile, void* stream);
 
+/* KL.Conv2DTranspose(256, (2, 2), strides=2, activation="relu") of build_fpn_mask_graph (mrcnn/model.py:1084-1086) as one product
+ * [N H W x Cin] . [Cin x 4 Cd] on the persistent GEMM (mrcnn_winograd_gemm's kernel) with bias, activation and the pixel-shuffle
+ * store in its epilogue: K is a single filter tap deep, where the persistent form beats the one-tile-per-workgroup kernel
+ * (2.15 -> 1.75 ms at 2048 ROIs).  w_gemm [Cin][(a, b, co)] (the layout mrcnn_conv2d_fwd takes for MRCNN_OUT_DECONV2);
+ * out [N][2 H][2 W][Cd].  Cin % 16 == 0, Cd % 32 == 0, 4 Cd % 128 == 0, act NONE or RELU; else MRCNN_ERR_UNSUPPORTED.          */
+int mrcnn_deconv2x2_gemm(const float* x, const float* w_gemm, const float* bias, float* out, int N, int H, int W, int Cin, int Cd,
+                         int act, void* stream);
+
 /* ---- data-parallel gradient exchange over RCCL / xGMI ---------------------------------------------------------------
  * Replaces the in-graph tower aggregation of mrcnn/parallel_model.py:54-104 (weights shared between towers, gradients
  * summed implicitly by TF, scalar losses averaged :97-99): one process per GPU, each rank sums contiguous ranges

@@ -233,18 +233,30 @@ def test_conv_into_concat_buffer(dev):
     torch.testing.assert_close(buf.cpu(), torch.cat(refs, 1), **F32)
 
 
-def test_deconv2x2(dev):
+@pytest.mark.parametrize("case", [(3, 14, 14, 256, 256, "direct"), (3, 14, 14, 256, 256, "gemm"), (101, 14, 14, 256, 256, "gemm"),
+                                  (5, 6, 10, 32, 64, "gemm")])
+def test_deconv2x2(dev, case, monkeypatch):
+    """Conv2DTranspose(2 x 2, stride 2) + bias + ReLU (model.py:1084-1086) against the oracle: the convolution kernel's
+    pixel-shuffle store and the persistent GEMM with the same store in its epilogue (row counts that are not multiples of the
+    128-row tile, a 6 x 10 map, 64 output channels = 32-column groups that change tap inside a 128-column tile)."""
     ops = _ops()
     from caesar_mrcnn_amd.params import deconv_keras_to_gemm
-    rng = np.random.default_rng(6)
-    x = _rand(rng, 3, 14, 14, 256)
-    k = _rand(rng, 2, 2, 256, 256, scale=0.05)      # Keras (2,2,out,in)
-    b = _rand(rng, 256, scale=0.1)
+    N, H, W, Cin, Cd, path = case
+    monkeypatch.setattr(ops, "_DECONV_GEMM", path == "gemm")
+    monkeypatch.setattr(ops, "_DECONV_GEMM_MIN_ROWS", 1)
+    rng = np.random.default_rng(6 + N)
+    x = _rand(rng, N, H, W, Cin)
+    k = _rand(rng, 2, 2, Cd, Cin, scale=0.05)      # Keras (2,2,out,in)
+    b = _rand(rng, Cd, scale=0.1)
     ref = torch.relu(orc.conv2d_transpose_2x2(torch.tensor(x), torch.tensor(k), torch.tensor(b)))
-    wg = torch.tensor(deconv_keras_to_gemm(k).reshape(256, 1024), device=dev)
-    out = ops.deconv2x2(torch.tensor(x, device=dev), wg, torch.tensor(b, device=dev))
+    wg = torch.tensor(deconv_keras_to_gemm(k).reshape(Cin, 4 * Cd), device=dev)
+    out = torch.full((N, 2 * H, 2 * W, Cd), 9.0, device=dev)
+    ops.deconv2x2(torch.tensor(x, device=dev), wg, torch.tensor(b, device=dev), out=out)
     torch.cuda.synchronize()
     torch.testing.assert_close(out.cpu(), ref, **F32)
+    out0 = ops.deconv2x2(torch.tensor(x, device=dev), wg, None, ops.ACT_NONE)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out0.cpu(), orc.conv2d_transpose_2x2(torch.tensor(x), torch.tensor(k), torch.zeros(Cd)), **F32)
 
 
 WGRAD_CASES = [
