@@ -429,6 +429,87 @@ __global__ void mask_out_bwd_kernel(const float* __restrict__ dmask, const float
     }
 }
 
+// The same pass with float4 accesses: a thread owns 4 deconv channels, 256 / (Cd / 4) pixels are in flight per workgroup step
+// (4 for Cd = 256) and four steps are unrolled -- 16 KiB of loads in flight per workgroup instead of 4 (one dword per thread):
+// 1.34 -> ~0.9 ms at 2048 ROIs (3.3 GB moved).  The per-thread partial sums of dWm / dbd meet in LDS (the pixel lanes of a channel
+// group are different waves) before the one atomic per element and workgroup.  Cd % 4 == 0, Cd / 4 a power of two <= 256.
+template <int CP>
+__global__ __launch_bounds__(256) void mask_out_bwd_vec_kernel(const float* __restrict__ dmask, const float* __restrict__ mask,
+                                                               const float* __restrict__ up, const float* __restrict__ wm, float* dzg,
+                                                               float* dWm, float* dbm, float* dbd, int64_t npix, int H, int W, int Cd,
+                                                               int C, int lg) {
+    __shared__ __attribute__((aligned(16))) float sdz[MOB_PPB * CP];
+    __shared__ float sred[256 * 4 * (CP + 1)];                    // [thread][4 channels][CP weights + 1 bias]
+    const int tid = threadIdx.x;
+    const int L = 1 << lg, PP = 256 >> lg;                        // L = Cd / 4 channel groups, PP pixels in flight
+    const int cg = tid & (L - 1), pp = tid >> lg;
+    const int ci = cg * 4;
+    const int64_t p0 = (int64_t)blockIdx.x * MOB_PPB;
+    const int np = (int)((npix - p0) < MOB_PPB ? (npix - p0) : MOB_PPB);
+    for (int i = tid; i < MOB_PPB * CP; i += 256) {
+        const int pl = i / CP, c = i - pl * CP;
+        float v = 0.f;
+        if (pl < np && c < C) {
+            const float g = dmask[(p0 + pl) * C + c], q = mask[(p0 + pl) * C + c];
+            v = g * q * (1.f - q);
+        }
+        sdz[i] = v;
+    }
+    float wrow[4][CP], aw[4][CP], abd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        abd[k] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CP; ++c) { wrow[k][c] = c < C ? wm[(int64_t)(ci + k) * C + c] : 0.f; aw[k][c] = 0.f; }
+    }
+    __syncthreads();
+    const int hw = H * W, W2 = W >> 1, H2 = H >> 1;
+#pragma unroll 4
+    for (int pl = pp; pl < np; pl += PP) {
+        const f32x4 u = *(const f32x4*)(up + (p0 + pl) * Cd + ci);
+        f32x4 dzu;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dzu[k] = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < CP; c4 += 4) {
+            const f32x4 z = *(const f32x4*)&sdz[pl * CP + c4];          // LDS broadcast within a pixel lane
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { dzu[k] += z[e] * wrow[k][c4 + e]; aw[k][c4 + e] += u[k] * z[e]; }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { dzu[k] = u[k] > 0.f ? dzu[k] : 0.f; abd[k] += dzu[k]; }
+        const int64_t pix = p0 + pl;
+        const int64_t n = pix / hw;
+        const int rem = (int)(pix - n * hw);
+        const int y = rem / W, x = rem - y * W;
+        *(f32x4*)(dzg + (((n * H2 + (y >> 1)) * W2 + (x >> 1)) * 4 + ((y & 1) * 2 + (x & 1))) * Cd + ci) = dzu;
+    }
+    // partial sums of the PP pixel lanes -> LDS -> one atomic per element and workgroup
+    float* mine = sred + tid * 4 * (CP + 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int c = 0; c < CP; ++c) mine[k * (CP + 1) + c] = aw[k][c];
+        mine[k * (CP + 1) + CP] = abd[k];
+    }
+    __syncthreads();
+    for (int i = tid; i < L * 4 * (CP + 1); i += 256) {            // element i of channel group i / (4 (CP + 1))
+        const int g = i / (4 * (CP + 1)), e = i - g * 4 * (CP + 1);
+        float s_ = 0.f;
+        for (int q = 0; q < PP; ++q) s_ += sred[(q * L + g) * 4 * (CP + 1) + e];
+        const int k = e / (CP + 1), c = e - k * (CP + 1);
+        if (c == CP) atomicAdd(&dbd[g * 4 + k], s_);
+        else if (c < C) atomicAdd(&dWm[(int64_t)(g * 4 + k) * C + c], s_);
+    }
+    if (tid < C) {
+        float s_ = 0.f;
+        for (int pl = 0; pl < np; ++pl) s_ += sdz[pl * CP + tid];
+        atomicAdd(&dbm[tid], s_);
+    }
+}
+
 extern "C" int mrcnn_mask_out_bwd(const float* d_mask_out, const float* mask_out, const float* up, const float* w_mask,
                                   float* dzg, float* dw_mask, float* db_mask, float* db_deconv, int64_t M, int H, int W,
                                   int Cd, int C, void* stream) {
@@ -438,6 +519,15 @@ extern "C" int mrcnn_mask_out_bwd(const float* d_mask_out, const float* mask_out
     const int64_t npix = M * H * W;
     const dim3 grid((unsigned)cdiv64(npix, MOB_PPB)), block(Cd);
     hipStream_t s = (hipStream_t)stream;
+    static const bool vec = !(getenv("MRCNN_MASK_OUT_BWD_VEC") && getenv("MRCNN_MASK_OUT_BWD_VEC")[0] == '0');
+    const int L = Cd >> 2;
+    if (vec && C <= 4 && !(L & (L - 1)) && L <= 256 && !((reinterpret_cast<uintptr_t>(up) | reinterpret_cast<uintptr_t>(dzg)) & 15)) {
+        int lg = 0;
+        while ((1 << lg) < L) ++lg;
+        hipLaunchKernelGGL(mask_out_bwd_vec_kernel<4>, grid, dim3(256), 0, s, d_mask_out, mask_out, up, w_mask, dzg, dw_mask, db_mask,
+                           db_deconv, npix, H, W, Cd, C, lg);
+        return mrcnn_launch_status();
+    }
     if (C <= 4)
         hipLaunchKernelGGL(mask_out_bwd_kernel<4>, grid, block, 0, s, d_mask_out, mask_out, up, w_mask, dzg, dw_mask,
                            db_mask, db_deconv, npix, H, W, Cd, C);
