@@ -640,12 +640,16 @@ extern "C" int mrcnn_winograd_gemm(const float* V, const float* U, float* Mt, in
     if (!V || !U || !Mt || nb <= 0 || rows <= 0 || rows % 128 || K <= 0 || K % 16 || N <= 0 || N % 128) return MRCNN_ERR_ARG;
     const long long M = (long long)nb * rows;
     if (M * K * 4 >= 0x7FFFFFF0LL || (long long)nb * K * N * 4 >= 0x7FFFFFF0LL || M * N >= (1LL << 40)) return MRCNN_ERR_UNSUPPORTED;
-    // OFF by default: alone the wide tile is 4 % faster (1.69 -> 1.62 ms, 0.79 -> 0.83 of the matrix peak: every V row block
-    // is fetched once), but inside the step it is slower (44.0 -> 44.9 ms): at 166 VGPRs / 48 KiB it leaves less room for the
-    // other stream's kernels on a CU
-    static const int wide = getenv("MRCNN_WINOGRAD_GEMM_WIDE") ? atoi(getenv("MRCNN_WINOGRAD_GEMM_WIDE")) : 0;
+    // The wide tile (N = 256 whole: every V row block is fetched once; 166 VGPRs, 48 KiB LDS, 3 workgroups per CU) is 4-5 % faster
+    // alone (F(4x4) layer: 1.25 -> 1.19 ms, 0.79 -> 0.83 of the matrix peak).  Inside the step it used to lose (F(2x2): 44.0 ->
+    // 44.9 ms, less room for the other stream's kernels on a CU); with the F(4x4) layers it is level or slightly ahead on the
+    // dense step (40.85 / 40.60 -> 40.61 / 40.51 ms) and level on the positive-quota step, so it is taken for products of at least
+    // MRCNN_WINOGRAD_GEMM_WIDE_MIN (4096) wide tiles -- the dense layers and their halves; 0 = always, -1 = never.
+    const char* wenv = getenv("MRCNN_WINOGRAD_GEMM_WIDE_MIN");                  // read per call (tests compare the two tiles)
+    const long long wide_min = wenv ? atoll(wenv) : 4096;
+    const bool wide = wide_min >= 0 && N % 256 == 0 && (M / 128) * (N / 256) >= wide_min;
     const GemmDeconvEp none = {};
-    if (wide && N % 256 == 0) {                                 // 128 x 256 tiles: 48 KiB LDS, 3 workgroups per CU
+    if (wide) {                                                 // 128 x 256 tiles: 48 KiB LDS, 3 workgroups per CU
         const long long tiles = (M / 128) * (N / 256);
         const long long slots = 3LL * mrcnn_num_cus();
         const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);

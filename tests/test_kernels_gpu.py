@@ -164,6 +164,28 @@ def test_conv_winograd(dev, case):
         torch.testing.assert_close(a, r, rtol=2e-4, atol=2e-4 * float(r.abs().max()))
 
 
+def test_winograd_gemm_tiles_agree(dev, monkeypatch):
+    """mrcnn_winograd_gemm: the 128 x 256 tile (taken for large products) and the 128 x 128 tile walk K in the same order, so the
+    36 products of an F(4x4) layer must agree bit for bit; both against a float64 matmul of three of the matrices."""
+    ops = _ops()
+    lib = ops._hip.lib()
+    nb, rows, K, N = 36, 640, 256, 256
+    g = torch.Generator(device="cpu").manual_seed(5)
+    V = torch.randn(nb, rows, K, generator=g).to(dev)
+    U = (torch.randn(nb, K, N, generator=g) * 0.05).to(dev)
+    outs = []
+    for wide_min in ("-1", "0"):
+        monkeypatch.setenv("MRCNN_WINOGRAD_GEMM_WIDE_MIN", wide_min)
+        Mt = torch.full((nb, rows, N), 3.0, device=dev)
+        ops.check(lib.mrcnn_winograd_gemm(ops.ptr(V), ops.ptr(U), ops.ptr(Mt), nb, rows, K, N, ops.current_stream()), "mrcnn_winograd_gemm")
+        torch.cuda.synchronize()
+        outs.append(Mt)
+    assert torch.equal(outs[0], outs[1])
+    for k in (0, 17, 35):
+        ref = V[k].double().cpu() @ U[k].double().cpu()
+        torch.testing.assert_close(outs[1][k].double().cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
 def test_conv_multi_launch_matches_oracle(dev):
     """mrcnn_conv2d_fwd_multi: the RPN model over five pyramid levels in three launches (model.py:2040-2055) --
     shared 3x3 + ReLU, then the two 1x1 heads written straight into the concatenated [B, A, *] buffers -- and four
