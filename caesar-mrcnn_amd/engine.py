@@ -323,11 +323,11 @@ class MaskRCNNEngine(object):
         if not v:
             self._wino_valid = {}
 
-    def _wino_U(self, op, which, xshape):
-        """Winograd-domain kernel of layer `op` for an input of shape xshape (the shape picks the tile size): which = 0 forward
-        (from op.w), 1 data gradient (from the flipped / transposed op.wt, which must be current).  Refreshed lazily after every
-        weight update, in place."""
-        tile = ops.winograd_tile(tuple(xshape))
+    def _wino_U(self, op, which, xshape, train=True):
+        """Winograd-domain kernel of layer `op` for an input of shape xshape (in training the shape picks the tile size; inference
+        always takes F(2x2, 3x3), whatever the batch): which = 0 forward (from op.w), 1 data gradient (from the flipped /
+        transposed op.wt, which must be current).  Refreshed lazily after every weight update, in place."""
+        tile = ops.winograd_tile(tuple(xshape)) if train else 2
         key = (op.name, tile)
         ent = self._wino.setdefault(key, [None, None])
         ok = self._wino_valid.setdefault(key, [False, False])
@@ -854,7 +854,7 @@ class MaskRCNNEngine(object):
                     V = ops.empty((ops.winograd_v_floats(tuple(x.shape)),), torch.float32, self.dev) if (train and self.winograd_wgrad) else None
                     if V is not None:
                         self._wino_V[op.name] = [(V, 0, x.shape[0])]
-                    ops.conv2d_winograd(x, self._wino_U(op, 0, x.shape), op.b, op.scale, op.shift, ACT_RELU, out=out, z_out=z, keep_v=V)
+                    ops.conv2d_winograd(x, self._wino_U(op, 0, x.shape, train), op.b, op.scale, op.shift, ACT_RELU, out=out, z_out=z, keep_v=V)
                     x, c = out, ((x, z, out, ACT_RELU) if train else None)
                 else:
                     x, c = op.forward(x, ACT_RELU, train=train)
@@ -897,7 +897,7 @@ class MaskRCNNEngine(object):
         halves = ((0, cut, main), (cut, N, side))
         ops_ = [self.op("mrcnn_mask_conv%d" % i) for i in range(1, 5)]
         hshape = lambda op, a, b: (b - a,) + tuple(x.shape[1:3]) + (op.wshape[2],)
-        Us = [[self._wino_U(op, 0, hshape(op, a, b)) for a, b, _ in halves] for op in ops_]   # weight transforms on the main stream, before the fork
+        Us = [[self._wino_U(op, 0, hshape(op, a, b), train) for a, b, _ in halves] for op in ops_]   # weight transforms on the main stream, before the fork
         outs, zs, ctxs = [], [], []
         cur = x
         for op in ops_:
