@@ -92,6 +92,31 @@ def test_same_padding_is_tf_asymmetric():
     assert same_padding(64, 1, 2) == (32, 0)
 
 
+def test_winograd_path_selection_and_buffer_sizes():
+    """Host logic of the Winograd path: which shapes take it, which tile a training layer gets (a pure function of the shape:
+    forward, data gradient and weight gradient must agree), and the buffer sizes the C-ABI reports -- (tile + 2)^2 matrices of
+    whole 128-row tiles, tile 4 with tiles that hang over a 14 x 14 map (no GPU call: mrcnn_winograd_buffer_floats is host code)."""
+    from caesar_mrcnn_amd import ops, _hip
+    w = (3, 3, 256, 256)
+    assert ops.winograd_ok((2048, 14, 14, 256), w) and ops.winograd_ok((100, 14, 14, 256), w)
+    assert not ops.winograd_ok((10, 14, 14, 256), w)                      # too few rows to fill the chip
+    assert not ops.winograd_ok((2048, 14, 14, 256), (1, 1, 256, 256))     # 3 x 3 only
+    assert not ops.winograd_ok((2048, 14, 14, 256), w, stride=2)
+    assert not ops.winograd_ok((2048, 15, 14, 256), w)                    # odd extent (the engine's rule; tile 4 alone would take it)
+    assert not ops.winograd_ok((2048, 14, 14, 256), (3, 3, 256, 64))      # Cout % 128
+    if ops._WINO_TILE == 4:
+        assert ops.winograd_tile((2048, 14, 14, 256)) == 4 and ops.winograd_tile((1024, 14, 14, 256)) == 4
+        assert ops.winograd_tile((512, 14, 14, 256)) == 4 and ops.winograd_tile((511, 14, 14, 256)) == 2
+    assert ops.winograd_tile((100, 14, 14, 256)) == 2
+    lib = _hip.lib()
+    assert lib.mrcnn_winograd_buffer_floats(2048, 14, 14, 256, 2) == 16 * 100352 * 256          # 2048 * 49 tiles: already whole row tiles
+    assert lib.mrcnn_winograd_buffer_floats(2048, 14, 14, 256, 4) == 36 * 32768 * 256           # 2048 * 16 tiles
+    assert lib.mrcnn_winograd_buffer_floats(37, 14, 14, 64, 2) == 16 * 1920 * 64                # 1813 tiles -> 15 row tiles of 128
+    assert lib.mrcnn_winograd_buffer_floats(5, 7, 9, 32, 4) == 36 * 128 * 32                    # 5 * 2 * 3 tiles
+    assert lib.mrcnn_winograd_buffer_floats(5, 7, 9, 32, 2) == 0                                # tile 2 wants even extents
+    assert lib.mrcnn_winograd_buffer_floats(5, 8, 8, 32, 3) == 0                                # no such tile
+
+
 def test_param_layout_counts_and_names():
     from caesar_mrcnn_amd.config import run_py_config
     from caesar_mrcnn_amd.params import ParamLayout, init_weights
