@@ -60,11 +60,12 @@ __device__ __forceinline__ void h16_static_for(F&& f, std::integer_sequence<int,
 
 // s_waitcnt vmcnt(N) for a compile-time N (the immediate has to be in the instruction text)
 template <int N> __device__ __forceinline__ void h16_wait_vmcnt() {
-    static_assert(N == 0 || N == 4 || N == 6 || N == 8 || N == 12, "add the count");
+    static_assert(N == 0 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16, "add the count");
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 }
 
@@ -77,11 +78,15 @@ template <int N> __device__ __forceinline__ void h16_wait_vmcnt() {
 //                 stay in flight across the raw s_barrier).  32 KiB per 4.2 MFLOP halves the L2 traffic per flop, and
 //                 with one 256-row tile per CU the nine shifted tap reads of a channel chunk (K is walked chunk-outer,
 //                 tap-inner) find their rows in the CU's own vector cache instead of evicting each other.
-template <typename T, int NBUF, int WAVES_M, int WAVES_N>
+//   <T, 4, 2, 2, 4>  256 x 256 with FOUR waves of 128 x 128 (TN = 4: 4 x 4 MFMA tiles, 256 accumulator registers -- one wave per SIMD,
+//                 so they fit): a wave reads 16 KiB of operands per K-step for 32 MFMAs where the 8-wave forms read 12 KiB for 16;
+//                 per CU and K-step 64 + 32 KiB of LDS traffic against 1024 matrix cycles instead of 96 + 32.  Epilogue through
+//                 LDS (16-byte stores), wave by wave.  MRCNN_H16_TILE=wave128.
+template <typename T, int NBUF, int WAVES_M, int WAVES_N, int TN = 2>      // TN = 4 wants NBUF = 4 (the ring index is masked)
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, NBUF <= 3 ? 2 : (WAVES_M * WAVES_N) / 4) void conv_fwd_h16_kernel(const ConvH16Args p) {
     typedef typename H16Traits<T>::v8 v8;
     constexpr int NW = WAVES_M * WAVES_N;
-    constexpr int BM = WAVES_M * 128, BN = WAVES_N * 64, TM = 4, TN = 2;
+    constexpr int BM = WAVES_M * 128, BN = WAVES_N * 32 * TN, TM = 4;
     constexpr int ROWB = 64;                                    // bytes per LDS row (32 x 16-bit)
     constexpr int AB = BM * ROWB, BB = BN * ROWB;               // bytes per stage
     constexpr int APW = BM / 16 / NW, BPW = BN / 16 / NW;       // 1 KiB DMA pieces (16 rows) per wave and stage
@@ -123,8 +128,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, NBUF <= 3 ? 2 : (WAVES_M * 
         a_mask[jj] = mk;
     }
     // B = W^T [Cout][Ktot]: BN / 16 pieces of 16 output channels
-    unsigned b_voff[2];                                         // [BPW] in use
-    static_assert(APW <= 4 && BPW <= 2, "piece bookkeeping arrays");
+    unsigned b_voff[4];                                         // [BPW] in use
+    static_assert(APW <= 4 && BPW <= 4, "piece bookkeeping arrays");
 #pragma unroll
     for (int jj = 0; jj < BPW; ++jj) {
         const int r = (wave + jj * NW) * 16 + (lane >> 2);
@@ -160,7 +165,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, NBUF <= 3 ? 2 : (WAVES_M * 
 
     const int li = lane & 31, lh = lane >> 5;
     // operand k-group kk (16 k values) of a 32-row tile: lane (li, lh) reads logical chunk 2*kk + lh of row li
-    const int arow = wm * 128 + li, brow = wn * 64 + li;
+    const int arow = wm * 128 + li, brow = wn * (32 * TN) + li;
     const char* a_rd[2];
     const char* b_rd[2];
 #pragma unroll
@@ -186,7 +191,63 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, NBUF <= 3 ? 2 : (WAVES_M * 
     };
 
     const int nk = p.Ktot / 32;
-    if constexpr (NBUF == 2) {
+    if constexpr (TN == 4) {
+        // One wave per SIMD: nobody else hides this wave's operand reads, so they are software-pipelined against its own MFMAs.  Two
+        // fragment sets; the reads of the NEXT half K-step (16 k) are issued before the 16 MFMAs of the current one (issuing those
+        // takes the wave ~512 cycles, the reads land meanwhile), and the barrier / DMA issue of the next stage sit between the two
+        // halves of a K-step instead of in front of it.
+        constexpr int D = NBUF - 1;
+        v8 fa[2][TM], fb[2][TN];
+        // (a plain loop with a runtime stage offset: unrolled over the four stages, the allocator no longer kept the 256
+        // accumulators in place and moved half of them between registers every K-step)
+        auto rd = [&](auto setc, const int bo, auto kkc) {
+            constexpr int F = decltype(setc)::value, kk = decltype(kkc)::value;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[F][a] = *(const v8*)(a_rd[kk] + bo + a * 32 * ROWB);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[F][b] = *(const v8*)(b_rd[kk] + bo + b * 32 * ROWB);
+        };
+        auto mm = [&](auto setc) {
+            constexpr int F = decltype(setc)::value;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = H16Traits<T>::mfma(fa[F][a], fb[F][b], acc[a][b]);
+        };
+        typedef std::integral_constant<int, 0> I0;
+        typedef std::integral_constant<int, 1> I1;
+        auto land = [&](int ks) {                               // stage ks has landed for this wave (younger stages stay in flight)
+            const int younger = nk - 1 - ks;
+            if (younger >= 2) h16_wait_vmcnt<2 * DPS>();
+            else if (younger >= 1) h16_wait_vmcnt<DPS>();
+            else h16_wait_vmcnt<0>();
+        };
+        for (int s0 = 0; s0 < D && s0 < nk; ++s0) stage(lds + s0 * (AB + BB));
+        land(0);
+        __builtin_amdgcn_s_barrier();
+        if (D < nk) stage(lds + D * (AB + BB));
+        rd(I0{}, 0, I0{});
+        int cur = 0;                                            // ring slot of stage ks
+#pragma nounroll
+        for (int ks = 0; ks < nk; ++ks) {
+            const int nxt = (cur + 1) & (NBUF - 1);
+            if (!(p.mtile0 & 2)) rd(I1{}, cur * (AB + BB), I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(p.mtile0 & 1)) mm(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < nk) {
+                land(ks + 1);
+                __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0), as a builtin so that the compiler's own wait bookkeeping sees it: this wave's reads of stage ks are done (issued 16 MFMAs ago)
+                __builtin_amdgcn_s_barrier();                           // ... and everybody's: its slot may be refilled
+                if (ks + 1 + D < nk) stage(lds + cur * (AB + BB));      // stage ks + 1 + D lives in slot (cur + 1 + D) % NBUF = cur
+                if (!(p.mtile0 & 2)) rd(I0{}, nxt * (AB + BB), I0{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(p.mtile0 & 1)) mm(I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            cur = nxt;
+        }
+    } else if constexpr (NBUF == 2) {
         stage(lds);
         __syncthreads();
         for (int ks = 0; ks < nk; ks += 2) {
@@ -225,11 +286,62 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, NBUF <= 3 ? 2 : (WAVES_M * 
     T* out = (T*)p.out;
     T* zo = (T*)p.z;
     const bool deconv = p.out_mode == MRCNN_OUT_DECONV2;        // column n = (a*2+b)*cmod + c -> pixel (2oh+a, 2ow+b), channel c
+    if constexpr (TN == 4) {
+        // 128 x 128 accumulators per wave: 256 two-byte stores per lane would cost more than the K loop.  Each 32-pixel block goes
+        // through the wave's own LDS region in float32 (rows of 132 floats) and leaves as 16-byte pieces, a pixel's 256 bytes by 16
+        // neighbouring lanes.  Dense NHWC output only (the host checks).
+        typedef T t8 __attribute__((ext_vector_type(8)));
+        constexpr int SST = 132;
+        __syncthreads();                                        // every wave is done with the ring
+        float* stg = (float*)lds + wave * (32 * SST);
+        const int c8 = (lane & 15) * 8, nn = n0 + wn * 128 + c8;
+        float cbv[8], csv[8], chv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            cbv[e] = p.bias ? p.bias[nn + e] : 0.f;
+            csv[e] = p.scale ? p.scale[nn + e] : 1.f;
+            chv[e] = p.scale ? p.shift[nn + e] : 0.f;
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stg[(4 * lh + (r & 3) + 8 * (r >> 2)) * SST + b * 32 + li] = acc[a][b][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = it * 4 + (lane >> 4);
+                const int m = m0 + wm * 128 + a * 32 + row;
+                const f32x4 v0 = *(const f32x4*)&stg[row * SST + c8], v1 = *(const f32x4*)&stg[row * SST + c8 + 4];
+                if (m >= p.M) continue;
+                const long long addr = (long long)m * p.Cout + nn;
+                t8 yo, zv8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float zv = (e < 4 ? v0[e & 3] : v1[e & 3]) + cbv[e];
+                    zv8[e] = (T)zv;
+                    float y = csv[e] * zv + chv[e];
+                    if (p.act == MRCNN_ACT_RELU) y = fmaxf(y, 0.f);
+                    else if (p.act == MRCNN_ACT_SIGMOID) y = 1.f / (1.f + expf(-y));
+                    yo[e] = (T)y;
+                }
+                if (zo) *(t8*)(zo + addr) = zv8;
+                *(t8*)(out + addr) = yo;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        return;
+    }
     int cn[TN], cab[TN];
     float cbias[TN], csc[TN], csh[TN];
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-        const int n = n0 + wn * 64 + b * 32 + li;
+        const int n = n0 + wn * (32 * TN) + b * 32 + li;
         cab[b] = deconv ? n / p.cmod : 0;
         cn[b] = deconv ? n - cab[b] * p.cmod : n;
         cbias[b] = p.bias ? p.bias[cn[b]] : 0.f;
@@ -1947,6 +2059,14 @@ extern "C" int mrcnn_conv2d_fwd_h16_res(const mrcnn_conv_desc* d, int dtype, con
     // where the tiles are whole rounds; measured shader clock under it: 1.96 GHz, tools/h16p_trace.py).
     bool big = false;
     if (tile && !strcmp(tile, "big")) big = d->Cout % 256 == 0;
+    if (tile && !strcmp(tile, "wave128") && d->Cout % 256 == 0 && a.dense && !res && d->Cin % 32 == 0 &&
+        !((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(z_out)) & 15)) {
+        const unsigned blocks = (unsigned)big_tiles;
+        if (const char* dbg = getenv("MRCNN_H16W_DBG")) a.mtile0 = atoi(dbg);      // timing experiments: 1 = no MFMAs, 2 = no operand reads
+        if (dtype == MRCNN_DTYPE_F16) hipLaunchKernelGGL((conv_fwd_h16_kernel<_Float16, 4, 2, 2, 4>), dim3(blocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_fwd_h16_kernel<__bf16, 4, 2, 2, 4>), dim3(blocks), dim3(256), 0, s, a);
+        return mrcnn_launch_status();
+    }
     // the transposed convolution's pixel-shuffle store (MRCNN_OUT_DECONV2) is the same kernel with another row address
     const bool deconv_p = d->out_mode == MRCNN_OUT_DECONV2 && d->cmod % 64 == 0 && d->cmod <= 512 && d->Cout == 4 * d->cmod && !z_out;
     const bool phased_ok = d->Cout % 256 == 0 && (deconv_p || (d->Cout <= 512 && a.dense)) && d->Cin % 64 == 0 && d->KH * d->KW <= 31 &&

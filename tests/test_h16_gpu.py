@@ -41,11 +41,12 @@ H16_CASES = [
 ]
 
 
-@pytest.fixture(params=["small", "big", "phase"])
+@pytest.fixture(params=["small", "big", "phase", "wave128"])
 def h16_tile(request):
-    """Both forward tilings on every eligible shape: MRCNN_H16_TILE is read per call (256 x 128 / 4 waves / double
+    """The forward tilings on every eligible shape: MRCNN_H16_TILE is read per call (256 x 128 / 4 waves / double
     buffered; 256 x 256 / 8 waves / 4-stage ring with counted waits; 256 x 256 / 8 waves in two staggered groups, phased
-    K-steps -- the last two need Cout % 256 == 0, the phased one also Cin % 64 == 0, else the call takes the default)."""
+    K-steps; 256 x 256 / 4 waves of 128 x 128 with software-pipelined operand reads and the epilogue through LDS -- the last
+    three need Cout % 256 == 0, the phased one also Cin % 64 == 0, else the call takes the default)."""
     os.environ["MRCNN_H16_TILE"] = request.param
     yield request.param
     del os.environ["MRCNN_H16_TILE"]
@@ -56,7 +57,7 @@ def h16_tile(request):
 def test_conv_fwd_h16(dev, case, dtype, h16_tile):
     ops = _ops()
     N, H, W, Cin, Cout, k, padding, act, bn = case
-    if h16_tile in ("big", "phase") and (Cout % 256 or (h16_tile == "phase" and Cin % 64)):
+    if h16_tile in ("big", "phase", "wave128") and (Cout % 256 or (h16_tile == "phase" and Cin % 64)):
         pytest.skip("256 x 256 tile needs Cout % 256 == 0")
     rng = np.random.default_rng(sum(case[:6]))
     x = torch.tensor(rng.standard_normal((N, H, W, Cin)).astype(np.float32)).to(dtype)
