@@ -196,7 +196,7 @@ def _train_loop_leg(args, res, model, cfg, nimg, world, rank):
 
 TRAFFIC_PER_LAUNCH = {1024: None, 2048: 1.810e9}   # mask-head conv, PMC passes: profiles/r01_pmc_conv_traffic.md
 TRAFFIC_WGRAD_PER_LAUNCH = {1024: None, 2048: 4.55e9}   # its weight gradient (same file)
-TRAFFIC_WINOGRAD_GEMM = {(2048, 2): 3.647e9, (2048, 4): 2.676e9}   # (ROIs, tile) -> FETCH_SIZE + WRITE_SIZE bytes per launch (profiles/r02_pmc_winograd_gemm.txt)
+TRAFFIC_WINOGRAD_GEMM = {(2048, 2): 3.647e9, (2048, 4): 2.676e9, (2048, 6): None}   # (ROIs, tile) -> FETCH_SIZE + WRITE_SIZE bytes per launch (profiles/r02_pmc_winograd_gemm.txt)
 
 
 def measure(args, backbone, nimg, rank, local_rank, world, full):
@@ -416,39 +416,48 @@ def _roofline_leg(res, ops, torch, dev, nimg, cfg):
         return e0.elapsed_time(e1) / reps
     peak = 157.3
     flops_direct = 2.0 * (M_rois * 196) * C_ * 9 * C_          # the layer as a direct convolution
-    tile = ops.winograd_tile((M_rois, 14, 14, C_))             # what the step uses for this layer: 4 (F(4x4,3x3)) unless MRCNN_WINOGRAD_TILE=2
-    nb = (tile + 2) ** 2
-    T = M_rois * ((14 + tile - 1) // tile) ** 2                # output tiles (tile 4: 4 x 4 per map, the last row / column half used)
-    flops_gemm = 2.0 * nb * T * C_ * C_                        # what the transform-domain GEMMs multiply (2.25 x / 3.06 x fewer)
+    tile = ops.winograd_tile((M_rois, 14, 14, C_))             # what the step uses for this layer: TILE_MIXED (F(4x4) tiles + a last row / column of 4x2, 2x4, 2x2) unless MRCNN_WINOGRAD_MIXED=0 / MRCNN_WINOGRAD_TILE=2
+    import ctypes as _C
+    groups = ops.winograd_groups(14, 14, tile)
     lib = ops._hip.lib()
-    nv = lib.mrcnn_winograd_buffer_floats(M_rois, 14, 14, C_, tile)
+    g0 = groups[0]                                             # the group that carries the layer: 3 x 3 tiles of 4 x 4 (or the uniform tiling)
+    nb = (g0.oth + 2) * (g0.otw + 2)
+    T = M_rois * g0.th_n * g0.tw_n
+    flops_gemm = 2.0 * nb * T * C_ * C_                        # what this launch multiplies
+    flops_layer_gemm = sum(2.0 * (g.oth + 2) * (g.otw + 2) * M_rois * g.th_n * g.tw_n * C_ * C_ for g in groups)
+    nv = lib.mrcnn_winograd_group_floats(_C.byref(g0), M_rois, C_)
     rows = nv // (nb * C_)
-    V = torch.empty(nv, device=dev); Mt = torch.empty(nv, device=dev)
+    V = torch.empty(ops.winograd_v_floats((M_rois, 14, 14, C_), tile), device=dev); Mt = torch.empty(nv, device=dev)
     U = ops.winograd_weights(wm, tile=tile)
+    U0 = U[0] if isinstance(U, (list, tuple)) else U
     st = ops.current_stream
     P = ops.ptr
-    t_in = timed_ms(lambda: lib.mrcnn_winograd_input(P(xm), P(V), M_rois, 14, 14, C_, tile, st()))
-    t_gemm = timed_ms(lambda: lib.mrcnn_winograd_gemm(P(V), P(U), P(Mt), nb, rows, C_, C_, st()))
-    t_gemm_blds = timed_ms(lambda: lib.mrcnn_gemm_batched_f32(P(V), P(U), P(Mt), nb, rows, C_, C_, st()))
-    t_out = timed_ms(lambda: lib.mrcnn_winograd_output(P(Mt), P(om), P(zm), P(bm), P(sc), P(bm), M_rois, 14, 14, C_, 1, tile, st()))
+    t_in = timed_ms(lambda: lib.mrcnn_winograd_input_g(P(xm), P(V), M_rois, 14, 14, C_, _C.byref(g0), st()))
+    t_gemm = timed_ms(lambda: lib.mrcnn_winograd_gemm(P(V), P(U0), P(Mt), nb, rows, C_, C_, st()))
+    t_gemm_blds = timed_ms(lambda: lib.mrcnn_gemm_batched_f32(P(V), P(U0), P(Mt), nb, rows, C_, C_, st()))
+    t_out = timed_ms(lambda: lib.mrcnn_winograd_output_g(P(Mt), P(om), P(zm), P(bm), P(sc), P(bm), M_rois, 14, 14, C_, 1, _C.byref(g0), st()))
     t_layer = timed_ms(lambda: ops.conv2d_winograd(xm, U, bm, sc, bm, 1, out=om, z_out=zm))
     ach = flops_gemm / (t_gemm * 1e-3) / 1e12
     res["roofline"] = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
                        "traffic": TRAFFIC_WINOGRAD_GEMM.get((M_rois, tile)),
-                       "kernel": "winograd_gemm_kernel (mrcnn_winograd_gemm): the %d transform-domain GEMMs [%d x 256] . [256 x 256] of a "
-                                 "Winograd F(%dx%d,3x3) mask-head layer in one launch of persistent workgroups (128x128 tiles, K = 256, "
-                                 "LDS-DMA operands, next tile's first stage in flight under the current tile's stores: %.1f "
-                                 "GFLOP/launch, %.3f ms/launch; the one-tile-per-workgroup LDS-DMA kernel on the same product: %.3f ms)"
-                                 % (nb, T, tile, tile, flops_gemm / 1e9, t_gemm, t_gemm_blds),
-                       "layer_ms": {"input_transform": round(t_in, 3), "gemm": round(t_gemm, 3), "output_transform_with_epilogue": round(t_out, 3),
-                                    "whole_layer": round(t_layer, 3)},
+                       "kernel": "winograd_gemm_kernel (mrcnn_winograd_gemm): the %d transform-domain GEMMs [%d x 256] . [256 x 256] of the "
+                                 "F(%dx%d,3x3) tiles of a Winograd mask-head layer (%.0f %% of the layer's multiplications; tiling %s) in "
+                                 "one launch of persistent workgroups (128x256 tiles, K = 256, LDS-DMA operands, next tile's first stage "
+                                 "in flight under the current tile's stores: %.1f GFLOP/launch, %.3f ms/launch; the one-tile-per-workgroup "
+                                 "LDS-DMA kernel on the same product: %.3f ms)"
+                                 % (nb, T, g0.oth, g0.otw, 100.0 * flops_gemm / flops_layer_gemm,
+                                    {2: "2x2", 4: "4x4 with overhang", 6: "4x4 + last row / column of 4x2, 2x4, 2x2"}[tile],
+                                    flops_gemm / 1e9, t_gemm, t_gemm_blds),
+                       "layer_ms": {"input_transform_main_group": round(t_in, 3), "gemm_main_group": round(t_gemm, 3),
+                                    "output_transform_with_epilogue_main_group": round(t_out, 3), "whole_layer": round(t_layer, 3)},
+                       "layer_gemm_gflop": round(flops_layer_gemm / 1e9, 1),
                        "layer_equivalent_direct_tflops": round(flops_direct / (t_layer * 1e-3) / 1e12, 2),
                        "winograd_tile": tile,
                        "note": "the layer computes what a direct 3x3 convolution of %.1f GFLOP computes (tile 4: 1.3e-5 of its result's "
                                "range, tile 2: 1.6e-6) with %.1f GFLOP of MFMA work plus two memory-bound transform passes; layer_equivalent_direct_tflops = the "
                                "direct convolution's flops over the whole layer's time (a rate the direct kernel would need, not one "
                                "the matrix cores run at)" %
-                               (flops_direct / 1e9, flops_gemm / 1e9)}
+                               (flops_direct / 1e9, flops_layer_gemm / 1e9)}
     # the direct kernel (detect, small ROI counts): the variant with the pre-BN z store and the bare one
     k_ms = timed_ms(lambda: ops.conv2d(xm, wm, bm, sc, bm, act=1, out=om, z_out=zm))
     k_ms_bare = timed_ms(lambda: ops.conv2d(xm, wm, bm, sc, bm, act=1, out=om))
@@ -465,7 +474,7 @@ def _roofline_leg(res, ops, torch, dev, nimg, cfg):
     ops.conv2d_winograd(xm, U, keep_v=V)
     wl_ms = timed_ms(lambda: ops.conv2d_wgrad_winograd(V, (M_rois, 14, 14, C_), dym, dwm, tile=tile))
     dM = torch.randn((nb, rows, C_), device=dev); dU = torch.empty((nb, C_, C_), device=dev)
-    Vv = V.view(nb, rows, C_)
+    Vv = V[:nv].view(nb, rows, C_)
     items = [(Vv[k, :T].view(T, 1, 1, C_), dM[k, :T].view(T, 1, 1, C_), (1, 1, C_, C_), 1, "valid", dU[k].view(1, 1, C_, C_), False)
              for k in range(nb)]
     per = 16 if nb == 16 else 12                               # GEMMs per launch (what conv2d_wgrad_winograd does)
@@ -478,7 +487,7 @@ def _roofline_leg(res, ops, torch, dev, nimg, cfg):
     res["roofline_wgrad"] = {"bound": "mfma", "achieved": round(w_ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(w_ach / peak, 4),
                              "traffic": None,
                              "kernel": "conv_wgrad_blds_multi_kernel<16>: the %d transform-domain weight-gradient GEMMs [256 x %d] . [%d x 256] "
-                                       "of a Winograd layer in %d launch(es) + their slab reductions (%.1f GFLOP, %.3f ms)" %
+                                       "of a Winograd layer's main tile group in %d launch(es) + their slab reductions (%.1f GFLOP, %.3f ms)" %
                                        (nb, T, T, nb // per, flops_gemm / 1e9, wg_ms),
                              "layer_ms": round(wl_ms, 3),
                              "layer_equivalent_direct_tflops": round(flops_direct / (wl_ms * 1e-3) / 1e12, 2)}

@@ -53,6 +53,11 @@ class RpnTargetDesc(C.Structure):
                 ("bbox_std_dev", C.c_double * 4)]
 
 
+class WinoGroup(C.Structure):
+    """mrcnn_wino_group (include/mrcnn_hip.h): a group of Winograd tiles of one map."""
+    _fields_ = [("oth", C.c_int), ("otw", C.c_int), ("th_n", C.c_int), ("tw_n", C.c_int), ("oh0", C.c_int), ("ow0", C.c_int)]
+
+
 class BwdEpilogue(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("out", "z", "scale", "mean", "rstd", "dgamma", "dbeta", "dbias")] + [
         ("act", C.c_int32), ("dy", C.c_void_p)]
@@ -143,6 +148,14 @@ _SIGNATURES = {
     "mrcnn_gemm_batched_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_winograd_gemm": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_winograd_output": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mrcnn_winograd_group_floats": (C.c_size_t, [C.POINTER(WinoGroup), C.c_int, C.c_int]),
+    "mrcnn_winograd_input_g": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(WinoGroup), _P]),
+    "mrcnn_winograd_weights_g": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
+    "mrcnn_winograd_output_g": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(WinoGroup), _P]),
+    "mrcnn_winograd_output_bwd_g": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.POINTER(WinoGroup), _P]),
+    "mrcnn_winograd_dy_g": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(WinoGroup), _P]),
+    "mrcnn_winograd_dw_g": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_deconv2x2_gemm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_winograd_dy": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_winograd_dw": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

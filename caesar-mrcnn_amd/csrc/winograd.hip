@@ -99,7 +99,11 @@ template <int OT> __device__ __forceinline__ void wino_gt(const float (&u)[OT + 
     }
 }
 
-// tile t of [0, N * th_n * tw_n) -> (n, th, tw), row-major: tile (th, tw) covers outputs (OT th .. OT th + OT - 1, OT tw .. )
+// A GROUP of tiles: th_n x tw_n tiles per map of OTH x OTW outputs each, the first one at output (oh0, ow0).  A uniform tiling is
+// one group at (0, 0); a 14 x 14 map without overhang is four: 3 x 3 tiles of 4 x 4, 3 x 1 of 4 x 2 (columns 12..13), 1 x 3 of
+// 2 x 4 (rows 12..13) and one 2 x 2 -- 484 multiplications per map and channel pair instead of 576.
+// tile t of [0, N * th_n * tw_n) -> (n, th, tw), row-major
+struct WinoGrp { int th_n, tw_n, oh0, ow0; };
 struct WinoTile { int n, th, tw; };
 __device__ __forceinline__ WinoTile wino_tile(long long t, int th_n, int tw_n) {
     WinoTile r;
@@ -110,92 +114,92 @@ __device__ __forceinline__ WinoTile wino_tile(long long t, int th_n, int tw_n) {
     return r;
 }
 
-// B^T d B: one thread = one tile x CV channels.  V [IT * IT][Tp][C]
-template <int OT, int CV>
+// B^T d B: one thread = one tile x CV channels.  V [ITH * ITW][Tp][C]
+template <int OTH, int OTW, int CV>
 __global__ __launch_bounds__(256) void winograd_input_kernel(const float* __restrict__ x, float* __restrict__ V, int N, int H, int W,
-                                                             int C, long long T, long long Tp, int th_n, int tw_n) {
+                                                             int C, long long T, long long Tp, const WinoGrp g) {
     typedef typename WinoVec<CV>::type vec;
-    constexpr int IT = OT + 2;
+    constexpr int ITH = OTH + 2, ITW = OTW + 2;
     const int cn = C / CV;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= T * cn) return;
     const long long t = i / cn;
     const int c = (int)(i - t * cn) * CV;
-    const WinoTile q = wino_tile(t, th_n, tw_n);
-    const int ih0 = OT * q.th - 1, iw0 = OT * q.tw - 1;
-    vec tt[IT][IT];
+    const WinoTile q = wino_tile(t, g.th_n, g.tw_n);
+    const int ih0 = g.oh0 + OTH * q.th - 1, iw0 = g.ow0 + OTW * q.tw - 1;
+    vec tt[ITH][ITW];
 #pragma unroll
-    for (int s = 0; s < IT; ++s) {               // columns of the tile: B^T applied down the rows
-        vec col[IT], o[IT];
+    for (int s = 0; s < ITW; ++s) {              // columns of the tile: B^T applied down the rows
+        vec col[ITH], o[ITH];
 #pragma unroll
-        for (int r = 0; r < IT; ++r) {
+        for (int r = 0; r < ITH; ++r) {
             const int ih = ih0 + r, iw = iw0 + s;
             vec val = {};
             if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) val = *(const vec*)(x + (((long long)q.n * H + ih) * W + iw) * C + c);
             col[r] = val;
         }
-        wino_bt<OT>(col, o);
+        wino_bt<OTH>(col, o);
 #pragma unroll
-        for (int r = 0; r < IT; ++r) tt[r][s] = o[r];
+        for (int r = 0; r < ITH; ++r) tt[r][s] = o[r];
     }
 #pragma unroll
-    for (int r = 0; r < IT; ++r) {               // then along each row
-        vec v[IT];
-        wino_bt<OT>(tt[r], v);
+    for (int r = 0; r < ITH; ++r) {              // then along each row
+        vec v[ITW];
+        wino_bt<OTW>(tt[r], v);
 #pragma unroll
-        for (int s = 0; s < IT; ++s) *(vec*)(V + ((long long)(r * IT + s) * Tp + t) * C + c) = v[s];
+        for (int s = 0; s < ITW; ++s) *(vec*)(V + ((long long)(r * ITW + s) * Tp + t) * C + c) = v[s];
     }
 }
 
-// U[xi][ci][co] = (G g G^T)[xi] from the HWIO kernel g[3][3][ci][co]; one thread per (ci, co)
-template <int OT>
+// U[xi][ci][co] = (G_h g G_w^T)[xi] from the HWIO kernel g[3][3][ci][co]; one thread per (ci, co)
+template <int OTH, int OTW>
 __global__ __launch_bounds__(256) void winograd_weight_kernel(const float* __restrict__ g, float* __restrict__ U, int Cin, int Cout) {
-    constexpr int IT = OT + 2;
+    constexpr int ITH = OTH + 2, ITW = OTW + 2;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long n = (long long)Cin * Cout;
     if (i >= n) return;
-    float t[IT][3];
+    float t[ITH][3];
 #pragma unroll
     for (int b = 0; b < 3; ++b) {
-        float col[3], o[IT];
+        float col[3], o[ITH];
 #pragma unroll
         for (int a = 0; a < 3; ++a) col[a] = g[(long long)(a * 3 + b) * n + i];
-        wino_g<OT>(col, o);
+        wino_g<OTH>(col, o);
 #pragma unroll
-        for (int a = 0; a < IT; ++a) t[a][b] = o[a];
+        for (int a = 0; a < ITH; ++a) t[a][b] = o[a];
     }
 #pragma unroll
-    for (int a = 0; a < IT; ++a) {
-        float u[IT];
-        wino_g<OT>(t[a], u);
+    for (int a = 0; a < ITH; ++a) {
+        float u[ITW];
+        wino_g<OTW>(t[a], u);
 #pragma unroll
-        for (int b = 0; b < IT; ++b) U[(long long)(a * IT + b) * n + i] = u[b];
+        for (int b = 0; b < ITW; ++b) U[(long long)(a * ITW + b) * n + i] = u[b];
     }
 }
 
-// A^T m A (OT x OT outputs of one tile) + epilogue: z = y + bias (stored when asked), out = act(scale z + shift)
-template <int OT, int CV>
+// A^T m A (OTH x OTW outputs of one tile) + epilogue: z = y + bias (stored when asked), out = act(scale z + shift)
+template <int OTH, int OTW, int CV>
 __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ Mt, float* __restrict__ out, float* __restrict__ z,
                                                               const float* __restrict__ bias, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, int N, int H, int W, int C, long long T,
-                                                              long long Tp, int act, int th_n, int tw_n) {
+                                                              long long Tp, int act, const WinoGrp g) {
     typedef typename WinoVec<CV>::type vec;
-    constexpr int IT = OT + 2;
+    constexpr int ITH = OTH + 2, ITW = OTW + 2;
     const int cn = C / CV;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= T * cn) return;
     const long long t = i / cn;
     const int c = (int)(i - t * cn) * CV;
-    const WinoTile q = wino_tile(t, th_n, tw_n);
-    vec s[OT][IT];
+    const WinoTile q = wino_tile(t, g.th_n, g.tw_n);
+    vec s[OTH][ITW];
 #pragma unroll
-    for (int k = 0; k < IT; ++k) {               // A^T down the rows of every column k
-        vec col[IT], o[OT];
+    for (int k = 0; k < ITW; ++k) {              // A^T down the rows of every column k
+        vec col[ITH], o[OTH];
 #pragma unroll
-        for (int r = 0; r < IT; ++r) col[r] = *(const vec*)(Mt + ((long long)(r * IT + k) * Tp + t) * C + c);
-        wino_at<OT>(col, o);
+        for (int r = 0; r < ITH; ++r) col[r] = *(const vec*)(Mt + ((long long)(r * ITW + k) * Tp + t) * C + c);
+        wino_at<OTH>(col, o);
 #pragma unroll
-        for (int a = 0; a < OT; ++a) s[a][k] = o[a];
+        for (int a = 0; a < OTH; ++a) s[a][k] = o[a];
     }
     vec bi = {}, sc, sh = {};
 #pragma unroll
@@ -203,14 +207,14 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
     if (bias) bi = *(const vec*)(bias + c);
     if (scale) { sc = *(const vec*)(scale + c); sh = *(const vec*)(shift + c); }
 #pragma unroll
-    for (int a = 0; a < OT; ++a) {
-        vec y[OT];
-        wino_at<OT>(s[a], y);
-        const int oh = OT * q.th + a;
+    for (int a = 0; a < OTH; ++a) {
+        vec y[OTW];
+        wino_at<OTW>(s[a], y);
+        const int oh = g.oh0 + OTH * q.th + a;
         if (oh >= H) continue;
 #pragma unroll
-        for (int b = 0; b < OT; ++b) {
-            const int ow = OT * q.tw + b;
+        for (int b = 0; b < OTW; ++b) {
+            const int ow = g.ow0 + OTW * q.tw + b;
             if (ow >= W) continue;
             const long long addr = (((long long)q.n * H + oh) * W + ow) * C + c;
             vec zv, o;
@@ -232,15 +236,15 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
 //   g = y * act'(out_below);  dz = g * scale_below -> stored;  dbeta += sum g, dgamma += sum g (z_below - mean) rstd, dbias += sum dz.
 // A workgroup walks a range of tiles: lane = CV-channel group (C / CV of them, a power of two <= 256), 256 / (C / CV) tiles in
 // flight; channel sums stay in registers, meet in LDS and leave as one atomic per channel and workgroup.
-template <int OT, int CV>
+template <int OTH, int OTW, int CV>
 __global__ __launch_bounds__(256) void winograd_output_bwd_kernel(const float* __restrict__ Mt, float* __restrict__ dz_out,
                                                                   const float* __restrict__ below_out, const float* __restrict__ below_z,
                                                                   const float* __restrict__ scale, const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, float* dgamma, float* dbeta, float* dbias,
                                                                   int N, int H, int W, int C, long long T, long long Tp, int act,
-                                                                  long long tiles_per_block, int lg, int th_n, int tw_n) {
+                                                                  long long tiles_per_block, int lg, const WinoGrp g) {
     typedef typename WinoVec<CV>::type vec;
-    constexpr int IT = OT + 2;
+    constexpr int ITH = OTH + 2, ITW = OTW + 2;
     __shared__ float sacc[3 * 4 * 256];
     const int L = 1 << lg, R = 256 >> lg;                       // L = C / CV lanes, R tiles in flight
     for (int c = threadIdx.x; c < 3 * CV * L; c += 256) sacc[c] = 0.f;
@@ -257,44 +261,44 @@ __global__ __launch_bounds__(256) void winograd_output_bwd_kernel(const float* _
     if (dgamma) { mu = *(const vec*)(mean + c); rs = *(const vec*)(rstd + c); }
     vec a_db = {}, a_dg = {}, a_bias = {};
     for (long long t = t0 + rsub; t < t1; t += R) {
-        const WinoTile q = wino_tile(t, th_n, tw_n);
-        vec s[OT][IT];
+        const WinoTile q = wino_tile(t, g.th_n, g.tw_n);
+        vec s[OTH][ITW];
 #pragma unroll
-        for (int k = 0; k < IT; ++k) {
-            vec col[IT], o[OT];
+        for (int k = 0; k < ITW; ++k) {
+            vec col[ITH], o[OTH];
 #pragma unroll
-            for (int r = 0; r < IT; ++r) col[r] = *(const vec*)(Mt + ((long long)(r * IT + k) * Tp + t) * C + c);
-            wino_at<OT>(col, o);
+            for (int r = 0; r < ITH; ++r) col[r] = *(const vec*)(Mt + ((long long)(r * ITW + k) * Tp + t) * C + c);
+            wino_at<OTH>(col, o);
 #pragma unroll
-            for (int a = 0; a < OT; ++a) s[a][k] = o[a];
+            for (int a = 0; a < OTH; ++a) s[a][k] = o[a];
         }
 #pragma unroll
-        for (int a = 0; a < OT; ++a) {
-            vec y[OT];
-            wino_at<OT>(s[a], y);
-            const int oh = OT * q.th + a;
+        for (int a = 0; a < OTH; ++a) {
+            vec y[OTW];
+            wino_at<OTW>(s[a], y);
+            const int oh = g.oh0 + OTH * q.th + a;
             if (oh >= H) continue;
 #pragma unroll
-            for (int b = 0; b < OT; ++b) {
-                const int ow = OT * q.tw + b;
+            for (int b = 0; b < OTW; ++b) {
+                const int ow = g.ow0 + OTW * q.tw + b;
                 if (ow >= W) continue;
                 const long long addr = (((long long)q.n * H + oh) * W + ow) * C + c;
-                vec g = y[b], dz;
+                vec gg = y[b], dz;
                 if (act == MRCNN_ACT_RELU) {
                     const vec oo = *(const vec*)(below_out + addr);
 #pragma unroll
-                    for (int e = 0; e < CV; ++e) g[e] = oo[e] > 0.f ? g[e] : 0.f;
+                    for (int e = 0; e < CV; ++e) gg[e] = oo[e] > 0.f ? gg[e] : 0.f;
                 }
 #pragma unroll
-                for (int e = 0; e < CV; ++e) dz[e] = g[e] * sc[e];
+                for (int e = 0; e < CV; ++e) dz[e] = gg[e] * sc[e];
                 *(vec*)(dz_out + addr) = dz;
                 if (dgamma) {
                     const vec zz = *(const vec*)(below_z + addr);
 #pragma unroll
-                    for (int e = 0; e < CV; ++e) a_dg[e] += g[e] * (zz[e] - mu[e]) * rs[e];
+                    for (int e = 0; e < CV; ++e) a_dg[e] += gg[e] * (zz[e] - mu[e]) * rs[e];
                 }
 #pragma unroll
-                for (int e = 0; e < CV; ++e) { a_db[e] += g[e]; a_bias[e] += dz[e]; }
+                for (int e = 0; e < CV; ++e) { a_db[e] += gg[e]; a_bias[e] += dz[e]; }
             }
         }
     }
@@ -312,65 +316,65 @@ __global__ __launch_bounds__(256) void winograd_output_bwd_kernel(const float* _
     }
 }
 
-// Weight gradient through the same domain: dU[xi] = V[xi]^T . dM[xi] (IT * IT GEMMs contracting over the tiles: 1 x 1 weight
+// Weight gradient through the same domain: dU[xi] = V[xi]^T . dM[xi] (ITH * ITW GEMMs contracting over the tiles: 1 x 1 weight
 // gradients for the float32 weight-gradient kernel), with V = B^T d B the forward's input transform (kept from the forward
 // pass) and dM = A dy A^T the ADJOINT of the output transform (outputs past the map's edge count as zero); then dW = G^T dU G.
-template <int OT, int CV>
+template <int OTH, int OTW, int CV>
 __global__ __launch_bounds__(256) void winograd_dy_kernel(const float* __restrict__ dy, float* __restrict__ dM, int N, int H, int W, int C,
-                                                          long long T, long long Tp, int th_n, int tw_n) {
+                                                          long long T, long long Tp, const WinoGrp g) {
     typedef typename WinoVec<CV>::type vec;
-    constexpr int IT = OT + 2;
+    constexpr int ITH = OTH + 2, ITW = OTW + 2;
     const int cn = C / CV;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= T * cn) return;
     const long long t = i / cn;
     const int c = (int)(i - t * cn) * CV;
-    const WinoTile q = wino_tile(t, th_n, tw_n);
-    vec u[IT][OT];
+    const WinoTile q = wino_tile(t, g.th_n, g.tw_n);
+    vec u[ITH][OTW];
 #pragma unroll
-    for (int b = 0; b < OT; ++b) {               // A down the rows of every output column b
-        vec col[OT], o[IT];
+    for (int b = 0; b < OTW; ++b) {              // A down the rows of every output column b
+        vec col[OTH], o[ITH];
 #pragma unroll
-        for (int a = 0; a < OT; ++a) {
-            const int oh = OT * q.th + a, ow = OT * q.tw + b;
+        for (int a = 0; a < OTH; ++a) {
+            const int oh = g.oh0 + OTH * q.th + a, ow = g.ow0 + OTW * q.tw + b;
             vec val = {};
             if (oh < H && ow < W) val = *(const vec*)(dy + (((long long)q.n * H + oh) * W + ow) * C + c);
             col[a] = val;
         }
-        wino_a<OT>(col, o);
+        wino_a<OTH>(col, o);
 #pragma unroll
-        for (int r = 0; r < IT; ++r) u[r][b] = o[r];
+        for (int r = 0; r < ITH; ++r) u[r][b] = o[r];
     }
 #pragma unroll
-    for (int r = 0; r < IT; ++r) {               // (A d) A^T
-        vec m[IT];
-        wino_a<OT>(u[r], m);
+    for (int r = 0; r < ITH; ++r) {              // (A d) A^T
+        vec m[ITW];
+        wino_a<OTW>(u[r], m);
 #pragma unroll
-        for (int k = 0; k < IT; ++k) *(vec*)(dM + ((long long)(r * IT + k) * Tp + t) * C + c) = m[k];
+        for (int k = 0; k < ITW; ++k) *(vec*)(dM + ((long long)(r * ITW + k) * Tp + t) * C + c) = m[k];
     }
 }
 
-// dW [3][3][ci][co] (= or +=) G^T dU G, dU [IT * IT][ci][co]; one thread per (ci, co)
-template <int OT>
+// dW [3][3][ci][co] (= or +=) G_h^T dU G_w, dU [ITH * ITW][ci][co]; one thread per (ci, co)
+template <int OTH, int OTW>
 __global__ __launch_bounds__(256) void winograd_dw_kernel(const float* __restrict__ dU, float* dW, int Cin, int Cout, int accumulate) {
-    constexpr int IT = OT + 2;
+    constexpr int ITH = OTH + 2, ITW = OTW + 2;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long n = (long long)Cin * Cout;
     if (i >= n) return;
-    float t[3][IT];
+    float t[3][ITW];
 #pragma unroll
-    for (int b = 0; b < IT; ++b) {
-        float col[IT], o[3];
+    for (int b = 0; b < ITW; ++b) {
+        float col[ITH], o[3];
 #pragma unroll
-        for (int a = 0; a < IT; ++a) col[a] = dU[(long long)(a * IT + b) * n + i];
-        wino_gt<OT>(col, o);
+        for (int a = 0; a < ITH; ++a) col[a] = dU[(long long)(a * ITW + b) * n + i];
+        wino_gt<OTH>(col, o);
 #pragma unroll
         for (int a = 0; a < 3; ++a) t[a][b] = o[a];
     }
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
         float w[3];
-        wino_gt<OT>(t[a], w);
+        wino_gt<OTW>(t[a], w);
         float* o = dW + (long long)(a * 3) * n + i;
 #pragma unroll
         for (int b = 0; b < 3; ++b) o[b * n] = accumulate ? o[b * n] + w[b] : w[b];
@@ -542,97 +546,156 @@ __global__ __launch_bounds__(256, 2) void winograd_gemm_kernel(const float* __re
     }
 }
 
-// tile = outputs per tile and dimension: 2 (F(2x2, 3x3), 16 GEMMs) or 4 (F(4x4, 3x3), 36 GEMMs; edge tiles may hang over the map)
-static inline int wino_tdim(int extent, int tile) { return (extent + tile - 1) / tile; }
-static inline long long wino_tiles(int N, int H, int W, int tile) { return (long long)N * wino_tdim(H, tile) * wino_tdim(W, tile); }
+// ---- host side: tile groups ------------------------------------------------------------------------------------------------------
 static inline long long wino_rows(long long T) { return (T + 127) / 128 * 128; }      // rows per transform-domain matrix: whole 128-row tiles
-static inline int wino_nb(int tile) { return (tile + 2) * (tile + 2); }
+static inline int wino_tdim(int extent, int tile) { return (extent + tile - 1) / tile; }
 
-static int wino_shape_ok(int N, int H, int W, int C, int tile) {
-    if (tile != 2 && tile != 4) return 0;
-    if (tile == 2 && ((H & 1) || (W & 1))) return 0;
+static int wino_grp_ok(const mrcnn_wino_group* g, int N, int H, int W, int C) {
+    if (!g || (g->oth != 2 && g->oth != 4) || (g->otw != 2 && g->otw != 4)) return 0;
+    if (g->th_n <= 0 || g->tw_n <= 0 || g->oh0 < 0 || g->ow0 < 0 || g->oh0 >= H || g->ow0 >= W) return 0;
     return N > 0 && H > 0 && W > 0 && C > 0 && !(C & 3);
 }
+static inline long long wino_grp_tiles(const mrcnn_wino_group* g, int N) { return (long long)N * g->th_n * g->tw_n; }
+static inline int wino_grp_nb(const mrcnn_wino_group* g) { return (g->oth + 2) * (g->otw + 2); }
+static inline int wino_grp_cv(const mrcnn_wino_group* g) { return g->oth == 2 && g->otw == 2 ? 4 : 2; }   // channels per thread
 
-// launch one of the two instantiations of a transform kernel: <2, 4> (one thread = a tile x 4 channels) or <4, 2> (36 + 36 values of
-// 2 channels: 4 would not fit the register file without spilling)
-#define WINO_LAUNCH(kernel, tile, cv_count, ...)                                                                                   \
-    do {                                                                                                                           \
-        if ((tile) == 2)                                                                                                           \
-            hipLaunchKernelGGL((kernel<2, 4>), dim3((unsigned)cdiv64((cv_count) / 4, 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
-        else                                                                                                                       \
-            hipLaunchKernelGGL((kernel<4, 2>), dim3((unsigned)cdiv64((cv_count) / 2, 256)), dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+// the uniform tilings of the `tile` entries as one group: tile 2 wants even extents, tile 4 lets the last tiles hang over the edge
+static int wino_uniform(int N, int H, int W, int C, int tile, mrcnn_wino_group* g) {
+    if (tile != 2 && tile != 4) return 0;
+    if (tile == 2 && ((H & 1) || (W & 1))) return 0;
+    if (!(N > 0 && H > 0 && W > 0 && C > 0 && !(C & 3))) return 0;
+    g->oth = g->otw = tile; g->th_n = wino_tdim(H, tile); g->tw_n = wino_tdim(W, tile); g->oh0 = g->ow0 = 0;
+    return 1;
+}
+
+// launch the instantiation of a transform kernel for a group: <2, 2, 4> (one thread = a tile x 4 channels), the others x 2 channels
+// (36 + 36 values of 4 channels would not fit the register file without spilling)
+#define WINO_LAUNCH_G(kernel, g, grid4, grid2, ...)                                                                          \
+    do {                                                                                                                     \
+        if ((g)->oth == 2 && (g)->otw == 2) hipLaunchKernelGGL((kernel<2, 2, 4>), grid4, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        else if ((g)->oth == 4 && (g)->otw == 4) hipLaunchKernelGGL((kernel<4, 4, 2>), grid2, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        else if ((g)->oth == 4) hipLaunchKernelGGL((kernel<4, 2, 2>), grid2, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        else hipLaunchKernelGGL((kernel<2, 4, 2>), grid2, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);                  \
+    } while (0)
+#define WINO_LAUNCH_W(kernel, oth, otw, grid, ...)                                                                           \
+    do {                                                                                                                     \
+        if ((oth) == 2 && (otw) == 2) hipLaunchKernelGGL((kernel<2, 2>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        else if ((oth) == 4 && (otw) == 4) hipLaunchKernelGGL((kernel<4, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__); \
+        else if ((oth) == 4) hipLaunchKernelGGL((kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);     \
+        else hipLaunchKernelGGL((kernel<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, __VA_ARGS__);                     \
     } while (0)
 
+extern "C" size_t mrcnn_winograd_group_floats(const mrcnn_wino_group* g, int N, int C) {
+    if (!g || N <= 0 || C <= 0 || (g->oth != 2 && g->oth != 4) || (g->otw != 2 && g->otw != 4) || g->th_n <= 0 || g->tw_n <= 0) return 0;
+    return (size_t)wino_grp_nb(g) * (size_t)wino_rows(wino_grp_tiles(g, N)) * (size_t)C;
+}
+
+extern "C" int mrcnn_winograd_input_g(const float* x, float* V, int N, int H, int W, int C, const mrcnn_wino_group* g, void* stream) {
+    if (!x || !V || !wino_grp_ok(g, N, H, W, C)) return MRCNN_ERR_ARG;
+    const long long T = wino_grp_tiles(g, N);
+    const WinoGrp k = {g->th_n, g->tw_n, g->oh0, g->ow0};
+    const dim3 g4((unsigned)cdiv64(T * C / 4, 256)), g2((unsigned)cdiv64(T * C / 2, 256));
+    WINO_LAUNCH_G(winograd_input_kernel, g, g4, g2, x, V, N, H, W, C, T, wino_rows(T), k);
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_winograd_weights_g(const float* w, float* U, int Cin, int Cout, int oth, int otw, void* stream) {
+    if (!w || !U || Cin <= 0 || Cout <= 0 || (oth != 2 && oth != 4) || (otw != 2 && otw != 4)) return MRCNN_ERR_ARG;
+    const dim3 grid((unsigned)cdiv64((long long)Cin * Cout, 256));
+    WINO_LAUNCH_W(winograd_weight_kernel, oth, otw, grid, w, U, Cin, Cout);
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_winograd_output_g(const float* Mt, float* out, float* z, const float* bias, const float* scale, const float* shift,
+                                       int N, int H, int W, int C, int act, const mrcnn_wino_group* g, void* stream) {
+    if (!Mt || !out || !wino_grp_ok(g, N, H, W, C) || (scale && !shift)) return MRCNN_ERR_ARG;
+    if (act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) return MRCNN_ERR_UNSUPPORTED;
+    const long long T = wino_grp_tiles(g, N);
+    const WinoGrp k = {g->th_n, g->tw_n, g->oh0, g->ow0};
+    const dim3 g4((unsigned)cdiv64(T * C / 4, 256)), g2((unsigned)cdiv64(T * C / 2, 256));
+    WINO_LAUNCH_G(winograd_output_kernel, g, g4, g2, Mt, out, z, bias, scale, shift, N, H, W, C, T, wino_rows(T), act, k);
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_winograd_output_bwd_g(const float* Mt, float* dz_below, const float* below_out, const float* below_z, const float* scale,
+                                           const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H,
+                                           int W, int C, int act, const mrcnn_wino_group* g, void* stream) {
+    if (!Mt || !dz_below || !wino_grp_ok(g, N, H, W, C)) return MRCNN_ERR_ARG;
+    if ((act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) || (act == MRCNN_ACT_RELU && !below_out)) return MRCNN_ERR_ARG;
+    if (dgamma && (!below_z || !mean || !rstd)) return MRCNN_ERR_ARG;
+    const int cv = wino_grp_cv(g);
+    const int cn = C / cv;
+    if (cn > 256 || (cn & (cn - 1))) return MRCNN_ERR_UNSUPPORTED;
+    int lg = 0;
+    while ((1 << lg) < cn) ++lg;
+    const long long T = wino_grp_tiles(g, N);
+    const long long R = 256 >> lg;
+    long long per = (T + 2047) / 2048;                          // ~2048 workgroups; every one a whole number of passes
+    per = (per + R - 1) / R * R;
+    const dim3 grid((unsigned)cdiv64(T, per));
+    const WinoGrp k = {g->th_n, g->tw_n, g->oh0, g->ow0};
+    WINO_LAUNCH_G(winograd_output_bwd_kernel, g, grid, grid, Mt, dz_below, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, N, H, W,
+                  C, T, wino_rows(T), act, per, lg, k);
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_winograd_dy_g(const float* dy, float* dM, int N, int H, int W, int C, const mrcnn_wino_group* g, void* stream) {
+    if (!dy || !dM || !wino_grp_ok(g, N, H, W, C)) return MRCNN_ERR_ARG;
+    const long long T = wino_grp_tiles(g, N);
+    const WinoGrp k = {g->th_n, g->tw_n, g->oh0, g->ow0};
+    const dim3 g4((unsigned)cdiv64(T * C / 4, 256)), g2((unsigned)cdiv64(T * C / 2, 256));
+    WINO_LAUNCH_G(winograd_dy_kernel, g, g4, g2, dy, dM, N, H, W, C, T, wino_rows(T), k);
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_winograd_dw_g(const float* dU, float* dw_hwio, int Cin, int Cout, int accumulate, int oth, int otw, void* stream) {
+    if (!dU || !dw_hwio || Cin <= 0 || Cout <= 0 || (oth != 2 && oth != 4) || (otw != 2 && otw != 4)) return MRCNN_ERR_ARG;
+    const dim3 grid((unsigned)cdiv64((long long)Cin * Cout, 256));
+    WINO_LAUNCH_W(winograd_dw_kernel, oth, otw, grid, dU, dw_hwio, Cin, Cout, accumulate);
+    return mrcnn_launch_status();
+}
+
+// ---- the uniform tilings (tile = 2 or 4 outputs per tile and dimension) as one group ----------------------------------------------
 /* floats of V (input transform) or Mt (transform-domain product) for a layer: (tile + 2)^2 x rows x C */
 extern "C" size_t mrcnn_winograd_buffer_floats(int N, int H, int W, int C, int tile) {
-    if (!wino_shape_ok(N, H, W, C, tile)) return 0;
-    return (size_t)wino_nb(tile) * (size_t)wino_rows(wino_tiles(N, H, W, tile)) * (size_t)C;
+    mrcnn_wino_group g;
+    if (!wino_uniform(N, H, W, C, tile, &g)) return 0;
+    return mrcnn_winograd_group_floats(&g, N, C);
 }
 
 extern "C" int mrcnn_winograd_input(const float* x, float* V, int N, int H, int W, int C, int tile, void* stream) {
-    if (!x || !V || !wino_shape_ok(N, H, W, C, tile)) return MRCNN_ERR_ARG;
-    const long long T = wino_tiles(N, H, W, tile);
-    WINO_LAUNCH(winograd_input_kernel, tile, T * C, x, V, N, H, W, C, T, wino_rows(T), wino_tdim(H, tile), wino_tdim(W, tile));
-    return mrcnn_launch_status();
+    mrcnn_wino_group g;
+    if (!wino_uniform(N, H, W, C, tile, &g)) return MRCNN_ERR_ARG;
+    return mrcnn_winograd_input_g(x, V, N, H, W, C, &g, stream);
 }
 
-extern "C" int mrcnn_winograd_weights(const float* g, float* U, int Cin, int Cout, int tile, void* stream) {
-    if (!g || !U || Cin <= 0 || Cout <= 0 || (tile != 2 && tile != 4)) return MRCNN_ERR_ARG;
-    const dim3 grid((unsigned)cdiv64((long long)Cin * Cout, 256));
-    if (tile == 2) hipLaunchKernelGGL(winograd_weight_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, g, U, Cin, Cout);
-    else hipLaunchKernelGGL(winograd_weight_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, g, U, Cin, Cout);
-    return mrcnn_launch_status();
+extern "C" int mrcnn_winograd_weights(const float* w, float* U, int Cin, int Cout, int tile, void* stream) {
+    return mrcnn_winograd_weights_g(w, U, Cin, Cout, tile, tile, stream);
 }
 
 extern "C" int mrcnn_winograd_output(const float* Mt, float* out, float* z, const float* bias, const float* scale, const float* shift,
                                      int N, int H, int W, int C, int act, int tile, void* stream) {
-    if (!Mt || !out || !wino_shape_ok(N, H, W, C, tile) || (scale && !shift)) return MRCNN_ERR_ARG;
-    if (act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) return MRCNN_ERR_UNSUPPORTED;
-    const long long T = wino_tiles(N, H, W, tile);
-    WINO_LAUNCH(winograd_output_kernel, tile, T * C, Mt, out, z, bias, scale, shift, N, H, W, C, T, wino_rows(T), act, wino_tdim(H, tile),
-                wino_tdim(W, tile));
-    return mrcnn_launch_status();
+    mrcnn_wino_group g;
+    if (!wino_uniform(N, H, W, C, tile, &g)) return MRCNN_ERR_ARG;
+    return mrcnn_winograd_output_g(Mt, out, z, bias, scale, shift, N, H, W, C, act, &g, stream);
 }
 
 extern "C" int mrcnn_winograd_output_bwd(const float* Mt, float* dz_below, const float* below_out, const float* below_z, const float* scale,
                                          const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H, int W,
                                          int C, int act, int tile, void* stream) {
-    if (!Mt || !dz_below || !wino_shape_ok(N, H, W, C, tile)) return MRCNN_ERR_ARG;
-    if ((act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) || (act == MRCNN_ACT_RELU && !below_out)) return MRCNN_ERR_ARG;
-    if (dgamma && (!below_z || !mean || !rstd)) return MRCNN_ERR_ARG;
-    const int cv = tile == 2 ? 4 : 2;
-    const int cn = C / cv;
-    if (cn > 256 || (cn & (cn - 1))) return MRCNN_ERR_UNSUPPORTED;
-    int lg = 0;
-    while ((1 << lg) < cn) ++lg;
-    const long long T = wino_tiles(N, H, W, tile);
-    const long long R = 256 >> lg;
-    long long per = (T + 2047) / 2048;                          // ~2048 workgroups; every one a whole number of passes
-    per = (per + R - 1) / R * R;
-    const dim3 grid((unsigned)cdiv64(T, per));
-    if (tile == 2)
-        hipLaunchKernelGGL((winograd_output_bwd_kernel<2, 4>), grid, dim3(256), 0, (hipStream_t)stream, Mt, dz_below, below_out, below_z, scale,
-                           mean, rstd, dgamma, dbeta, dbias, N, H, W, C, T, wino_rows(T), act, per, lg, wino_tdim(H, tile), wino_tdim(W, tile));
-    else
-        hipLaunchKernelGGL((winograd_output_bwd_kernel<4, 2>), grid, dim3(256), 0, (hipStream_t)stream, Mt, dz_below, below_out, below_z, scale,
-                           mean, rstd, dgamma, dbeta, dbias, N, H, W, C, T, wino_rows(T), act, per, lg, wino_tdim(H, tile), wino_tdim(W, tile));
-    return mrcnn_launch_status();
+    mrcnn_wino_group g;
+    if (!wino_uniform(N, H, W, C, tile, &g)) return MRCNN_ERR_ARG;
+    return mrcnn_winograd_output_bwd_g(Mt, dz_below, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, N, H, W, C, act, &g, stream);
 }
 
 extern "C" int mrcnn_winograd_dy(const float* dy, float* dM, int N, int H, int W, int C, int tile, void* stream) {
-    if (!dy || !dM || !wino_shape_ok(N, H, W, C, tile)) return MRCNN_ERR_ARG;
-    const long long T = wino_tiles(N, H, W, tile);
-    WINO_LAUNCH(winograd_dy_kernel, tile, T * C, dy, dM, N, H, W, C, T, wino_rows(T), wino_tdim(H, tile), wino_tdim(W, tile));
-    return mrcnn_launch_status();
+    mrcnn_wino_group g;
+    if (!wino_uniform(N, H, W, C, tile, &g)) return MRCNN_ERR_ARG;
+    return mrcnn_winograd_dy_g(dy, dM, N, H, W, C, &g, stream);
 }
 
 extern "C" int mrcnn_winograd_dw(const float* dU, float* dw_hwio, int Cin, int Cout, int accumulate, int tile, void* stream) {
-    if (!dU || !dw_hwio || Cin <= 0 || Cout <= 0 || (tile != 2 && tile != 4)) return MRCNN_ERR_ARG;
-    const dim3 grid((unsigned)cdiv64((long long)Cin * Cout, 256));
-    if (tile == 2) hipLaunchKernelGGL(winograd_dw_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dU, dw_hwio, Cin, Cout, accumulate);
-    else hipLaunchKernelGGL(winograd_dw_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, dU, dw_hwio, Cin, Cout, accumulate);
-    return mrcnn_launch_status();
+    return mrcnn_winograd_dw_g(dU, dw_hwio, Cin, Cout, accumulate, tile, tile, stream);
 }
 
 /* the persistent form of mrcnn_gemm_batched_f32 (same arguments and result; K % 16 == 0, N % 128 == 0, rows % 128 == 0) */

@@ -683,16 +683,43 @@ _WINO_TILE = int(os.environ.get("MRCNN_WINOGRAD_TILE", "4"))
 _WINO_TILE4_MIN_ROWS = int(os.environ.get("MRCNN_WINOGRAD_TILE4_MIN_ROWS", "100352"))
 
 
+_WINO_MIXED = os.environ.get("MRCNN_WINOGRAD_MIXED", "1") != "0"          # tile 4 on maps with extent % 4 == 2: four groups, no overhang
+TILE_MIXED = 6                                                              # "4 + 2": 4 x 4 tiles and a last row / column of 2
+
+
 def winograd_tile(xshape):
-    """Outputs per tile and dimension for a layer of this input shape: 4 (36 GEMMs over a quarter of the tiles, 1.36 x fewer
-    multiplications on 14 x 14 maps, about one decimal digit less accurate: 1.3e-5 of the result's range against 1.6e-6) for
-    training-sized layers, else 2; MRCNN_WINOGRAD_TILE=2 keeps 2 everywhere.  A pure function of the shape, so the forward pass,
-    the data gradient and the weight gradient of a layer agree on it."""
+    """Tiling of a TRAINING layer of this input shape: 2 (F(2x2,3x3) everywhere), 4 (F(4x4,3x3): 36 GEMMs over a quarter of the
+    tiles, about one decimal digit less accurate: 1.3e-5 of the result's range against 1.6e-6) for layers of at least
+    MRCNN_WINOGRAD_TILE4_MIN_ROWS pixels, or TILE_MIXED when H and W are 2 mod 4 (the mask head's 14 x 14): 4 x 4 tiles plus a
+    last row / column of 4 x 2, 2 x 4 and 2 x 2 tiles -- 484 multiplications per map and channel pair where the uniform 4 x 4
+    tiling with its overhang needs 576.  MRCNN_WINOGRAD_TILE=2 keeps 2 everywhere, MRCNN_WINOGRAD_MIXED=0 the uniform tiling.
+    A pure function of the shape, so the forward pass, the data gradient and the weight gradient of a layer agree on it."""
     N, H, W, _ = xshape
-    return 4 if (_WINO_TILE == 4 and N * H * W >= _WINO_TILE4_MIN_ROWS) else 2
+    if not (_WINO_TILE == 4 and N * H * W >= _WINO_TILE4_MIN_ROWS):
+        return 2
+    return TILE_MIXED if (_WINO_MIXED and H % 4 == 2 and W % 4 == 2 and H > 4 and W > 4) else 4
+
+
+def winograd_groups(H, W, tile):
+    """The tile groups (mrcnn_wino_group) of an H x W map under a tiling."""
+    G = _hip.WinoGroup
+    if tile == 2:
+        assert H % 2 == 0 and W % 2 == 0
+        return [G(2, 2, H // 2, W // 2, 0, 0)]
+    if tile == 4:
+        return [G(4, 4, (H + 3) // 4, (W + 3) // 4, 0, 0)]
+    assert tile == TILE_MIXED and H % 4 == 2 and W % 4 == 2
+    return [G(4, 4, H // 4, W // 4, 0, 0), G(4, 2, H // 4, 1, 0, W - 2), G(2, 4, 1, W // 4, H - 2, 0), G(2, 2, 1, 1, H - 2, W - 2)]
+
+
+def _wino_nb(g):
+    return (g.oth + 2) * (g.otw + 2)
 
 
 def _wino_tile_of(U):
+    if isinstance(U, (list, tuple)):
+        assert [u.shape[0] for u in U] == [36, 24, 24, 16], "U is not a mixed Winograd weight transform"
+        return TILE_MIXED
     nb = U.shape[0]
     assert nb in (16, 36), "U is not a Winograd weight transform"
     return 2 if nb == 16 else 4
@@ -710,66 +737,95 @@ def winograd_ok(xshape, wshape, stride=1, padding="same", min_rows=None):
 
 
 def winograd_weights(w, out=None, tile=2):
-    """HWIO 3 x 3 kernel -> U [(tile + 2)^2, Cin, Cout] = G g G^T."""
-    _need_cuda(w, out)
+    """HWIO 3 x 3 kernel -> U = G g G^T: [(tile + 2)^2, Cin, Cout] for the uniform tilings, a list of four (36, 24, 24, 16
+    matrices) for TILE_MIXED."""
     kh, kw, cin, cout = w.shape
     assert kh == 3 and kw == 3 and w.is_contiguous()
-    nb = (tile + 2) ** 2
+    if tile != TILE_MIXED:
+        _need_cuda(w, out)
+        nb = (tile + 2) ** 2
+        if out is None:
+            out = torch.empty((nb, cin, cout), dtype=torch.float32, device=w.device)
+        assert out.shape[0] == nb
+        check(_hip.lib().mrcnn_winograd_weights(ptr(w), ptr(out), cin, cout, tile, current_stream()), "mrcnn_winograd_weights")
+        return out
+    shapes = ((4, 4), (4, 2), (2, 4), (2, 2))
     if out is None:
-        out = torch.empty((nb, cin, cout), dtype=torch.float32, device=w.device)
-    assert out.shape[0] == nb
-    check(_hip.lib().mrcnn_winograd_weights(ptr(w), ptr(out), cin, cout, tile, current_stream()), "mrcnn_winograd_weights")
+        out = [torch.empty(((a + 2) * (b + 2), cin, cout), dtype=torch.float32, device=w.device) for a, b in shapes]
+    _need_cuda(w, *out)
+    for (a, b), u in zip(shapes, out):
+        assert u.shape[0] == (a + 2) * (b + 2)
+        check(_hip.lib().mrcnn_winograd_weights_g(ptr(w), ptr(u), cin, cout, a, b, current_stream()), "mrcnn_winograd_weights_g")
     return out
 
 
-def _winograd_product(x, U, keep_v=None, after_input=None):
-    """Input transform + the transform-domain GEMMs; returns Mt (a per-stream scratch buffer, valid until the next call).
-    keep_v: a float32 tensor of mrcnn_winograd_buffer_floats elements that receives V (the weight gradient reuses it)."""
+def _winograd_run(x, U, finish, keep_v=None, after_input=None):
+    """Per tile group: input transform, the group's transform-domain GEMMs, then finish(group, Mt) -- the output transform the caller
+    wants.  V of all groups lives in one flat buffer (keep_v: kept for the weight gradient), Mt is a per-stream scratch buffer
+    reused group after group (stream order)."""
     N, H, W, Cin = x.shape
-    nb, _, cout = U.shape
     tile = _wino_tile_of(U)
+    Us = U if isinstance(U, (list, tuple)) else [U]
+    cout = Us[0].shape[2]
+    groups = winograd_groups(H, W, tile)
     lib = _hip.lib()
-    nv, nm = lib.mrcnn_winograd_buffer_floats(N, H, W, Cin, tile), lib.mrcnn_winograd_buffer_floats(N, H, W, cout, tile)
-    V = keep_v if keep_v is not None else workspace(nv * 4, x.device, "winograd_v")
+    nvs = [lib.mrcnn_winograd_group_floats(C.byref(g), N, Cin) for g in groups]
+    nms = [lib.mrcnn_winograd_group_floats(C.byref(g), N, cout) for g in groups]
+    nv = sum(nvs)
+    V = keep_v if keep_v is not None else workspace(nv * 4, x.device, "winograd_v")[:nv * 4].view(torch.float32)
     assert keep_v is None or (keep_v.numel() == nv and keep_v.dtype == torch.float32)
-    Mt = workspace(nm * 4, x.device, "winograd_m")
-    check(lib.mrcnn_winograd_input(ptr(x), ptr(V), N, H, W, Cin, tile, current_stream()), "mrcnn_winograd_input")
-    if after_input is not None:
-        after_input()                    # e.g. an event: a second chain on another stream starts one transform behind this one
+    Mt = workspace(max(nms) * 4, x.device, "winograd_m")
     gemm = lib.mrcnn_winograd_gemm if _WINO_PERSISTENT_GEMM else lib.mrcnn_gemm_batched_f32
-    check(gemm(ptr(V), ptr(U), ptr(Mt), nb, nv // (nb * Cin), Cin, cout, current_stream()), "mrcnn_winograd_gemm")
-    return Mt
+    off = 0
+    for gi, (g, u) in enumerate(zip(groups, Us)):
+        Vg = V[off:off + nvs[gi]]
+        off += nvs[gi]
+        check(lib.mrcnn_winograd_input_g(ptr(x), ptr(Vg), N, H, W, Cin, C.byref(g), current_stream()), "mrcnn_winograd_input_g")
+        if gi == 0 and after_input is not None:
+            after_input()                # e.g. an event: a second chain on another stream starts one transform behind this one
+        nb = _wino_nb(g)
+        check(gemm(ptr(Vg), ptr(u), ptr(Mt), nb, nvs[gi] // (nb * Cin), Cin, cout, current_stream()), "mrcnn_winograd_gemm")
+        finish(g, Mt)
 
 
 def winograd_v_floats(xshape, tile=None):
     N, H, W, Cin = xshape
-    return _hip.lib().mrcnn_winograd_buffer_floats(N, H, W, Cin, winograd_tile(xshape) if tile is None else tile)
+    if tile is None:
+        tile = winograd_tile(xshape)
+    lib = _hip.lib()
+    return sum(lib.mrcnn_winograd_group_floats(C.byref(g), N, Cin) for g in winograd_groups(H, W, tile))
 
 
 def conv2d_winograd(x, U, bias=None, scale=None, shift=None, act=ACT_NONE, out=None, z_out=None, keep_v=None, after_input=None):
     """3 x 3 'same' stride-1 convolution with its epilogue through the Winograd domain (U = winograd_weights(w, tile=...))."""
-    _need_cuda(x, U, bias, scale, shift, out, z_out, keep_v)
+    _need_cuda(x, bias, scale, shift, out, z_out, keep_v)
     N, H, W, _ = x.shape
-    cout = U.shape[2]
+    cout = (U[0] if isinstance(U, (list, tuple)) else U).shape[2]
     if out is None:
         out = empty((N, H, W, cout), torch.float32, x.device)
-    Mt = _winograd_product(x, U, keep_v, after_input)
-    check(_hip.lib().mrcnn_winograd_output(ptr(Mt), ptr(out), ptr(z_out), ptr(bias), ptr(scale), ptr(shift), N, H, W, cout, act,
-                                           _wino_tile_of(U), current_stream()), "mrcnn_winograd_output")
+    lib = _hip.lib()
+
+    def finish(g, Mt):
+        check(lib.mrcnn_winograd_output_g(ptr(Mt), ptr(out), ptr(z_out), ptr(bias), ptr(scale), ptr(shift), N, H, W, cout, act, C.byref(g),
+                                          current_stream()), "mrcnn_winograd_output_g")
+    _winograd_run(x, U, finish, keep_v, after_input)
     return out
 
 
 def conv2d_dgrad_ep_winograd(dz, Ut, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, act):
     """Data gradient of a 3 x 3 'same' convolution (Ut = winograd_weights of the flipped / transposed kernel) fused with the
     epilogue backward of the layer below: returns dz_below, channel sums are added to dgamma / dbeta / dbias."""
-    _need_cuda(dz, Ut, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias)
+    _need_cuda(dz, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias)
     N, H, W, _ = dz.shape
-    cout = Ut.shape[2]
+    cout = (Ut[0] if isinstance(Ut, (list, tuple)) else Ut).shape[2]
     out = empty((N, H, W, cout), torch.float32, dz.device)
-    Mt = _winograd_product(dz, Ut)
-    check(_hip.lib().mrcnn_winograd_output_bwd(ptr(Mt), ptr(out), ptr(below_out), ptr(below_z), ptr(scale), ptr(mean), ptr(rstd),
-                                               ptr(dgamma), ptr(dbeta), ptr(dbias), N, H, W, cout, act, _wino_tile_of(Ut),
-                                               current_stream()), "mrcnn_winograd_output_bwd")
+    lib = _hip.lib()
+
+    def finish(g, Mt):
+        check(lib.mrcnn_winograd_output_bwd_g(ptr(Mt), ptr(out), ptr(below_out), ptr(below_z), ptr(scale), ptr(mean), ptr(rstd),
+                                              ptr(dgamma), ptr(dbeta), ptr(dbias), N, H, W, cout, act, C.byref(g), current_stream()),
+              "mrcnn_winograd_output_bwd_g")
+    _winograd_run(dz, Ut, finish)
     return out
 
 
@@ -782,24 +838,32 @@ def conv2d_wgrad_winograd(V, xshape, dz, dw, accumulate=False, tile=None):
     cout = dz.shape[3]
     if tile is None:
         tile = winograd_tile(xshape)
-    nb = (tile + 2) ** 2
+    groups = winograd_groups(H, W, tile)
     lib = _hip.lib()
-    nm = lib.mrcnn_winograd_buffer_floats(N, H, W, cout, tile)
-    assert V.numel() == lib.mrcnn_winograd_buffer_floats(N, H, W, Cin, tile), "V was made with another tile size"
-    rows = nm // (nb * cout)
-    T = N * ((H + tile - 1) // tile) * ((W + tile - 1) // tile)
-    dM = workspace(nm * 4, dz.device, "winograd_dm")[:nm * 4].view(torch.float32).view(nb, rows, cout)
-    dU = workspace(nb * Cin * cout * 4, dz.device, "winograd_du")[:nb * Cin * cout * 4].view(torch.float32).view(nb, Cin, cout)
-    check(lib.mrcnn_winograd_dy(ptr(dz), ptr(dM), N, H, W, cout, tile, current_stream()), "mrcnn_winograd_dy")
-    Vv = V.view(nb, rows, Cin)
-    items = [(Vv[k, :T].view(T, 1, 1, Cin), dM[k, :T].view(T, 1, 1, cout), (1, 1, Cin, cout), 1, "valid", dU[k].view(1, 1, Cin, cout), False)
-             for k in range(nb)]
-    per = 16 if nb == 16 else 12                               # GEMMs per launch (+ one launch for their slab reductions): the argument block holds 16
-    for i in range(0, nb, per):
-        if not conv2d_wgrad_multi(items[i:i + per]):
-            for x_, dy_, wshape, stride, padding, dw_, acc in items[i:i + per]:
-                conv2d_wgrad(x_, dy_, wshape, stride, padding, dw=dw_, accumulate=acc)
-    check(lib.mrcnn_winograd_dw(ptr(dU), ptr(dw), Cin, cout, 1 if accumulate else 0, tile, current_stream()), "mrcnn_winograd_dw")
+    nvs = [lib.mrcnn_winograd_group_floats(C.byref(g), N, Cin) for g in groups]
+    nms = [lib.mrcnn_winograd_group_floats(C.byref(g), N, cout) for g in groups]
+    assert V.numel() == sum(nvs), "V was made with another tiling"
+    dM_all = workspace(max(nms) * 4, dz.device, "winograd_dm")
+    dU_all = workspace(36 * Cin * cout * 4, dz.device, "winograd_du")
+    off = 0
+    for gi, g in enumerate(groups):
+        nb = _wino_nb(g)
+        rows = nms[gi] // (nb * cout)
+        T = N * g.th_n * g.tw_n
+        dM = dM_all[:nms[gi] * 4].view(torch.float32).view(nb, rows, cout)
+        dU = dU_all[:nb * Cin * cout * 4].view(torch.float32).view(nb, Cin, cout)
+        check(lib.mrcnn_winograd_dy_g(ptr(dz), ptr(dM), N, H, W, cout, C.byref(g), current_stream()), "mrcnn_winograd_dy_g")
+        Vv = V[off:off + nvs[gi]].view(nb, rows, Cin)
+        off += nvs[gi]
+        items = [(Vv[k, :T].view(T, 1, 1, Cin), dM[k, :T].view(T, 1, 1, cout), (1, 1, Cin, cout), 1, "valid", dU[k].view(1, 1, Cin, cout), False)
+                 for k in range(nb)]
+        per = 16 if nb == 16 else 12                           # GEMMs per launch (+ one launch for their slab reductions): the argument block holds 16
+        for i in range(0, nb, per):
+            if not conv2d_wgrad_multi(items[i:i + per]):
+                for x_, dy_, wshape, stride, padding, dw_, acc in items[i:i + per]:
+                    conv2d_wgrad(x_, dy_, wshape, stride, padding, dw=dw_, accumulate=acc)
+        check(lib.mrcnn_winograd_dw_g(ptr(dU), ptr(dw), Cin, cout, 1 if (accumulate or gi > 0) else 0, g.oth, g.otw, current_stream()),
+              "mrcnn_winograd_dw_g")
     return dw
 
 

@@ -414,6 +414,29 @@ int mrcnn_winograd_output_bwd(const float* Mt, float* dz_below, const float* bel
                               const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H, int W,
                               int C, int act, int tile, void* stream);
 
+/* The same passes for one GROUP of tiles -- th_n x tw_n tiles per map of oth x otw outputs (2 or 4 each), the first at output
+ * (oh0, ow0) -- so that a map whose extent is not a multiple of 4 is covered without overhang: 14 x 14 = 3 x 3 tiles of 4 x 4,
+ * 3 x 1 of 4 x 2 (columns 12..13), 1 x 3 of 2 x 4 (rows 12..13), one of 2 x 2: 484 multiplications per map and channel pair instead of
+ * 576 (uniform 4 x 4 with overhang) or 784 (uniform 2 x 2).  Every group has its own V / Mt ((oth + 2)(otw + 2) matrices of
+ * mrcnn_winograd_group_floats / C rows) and its own weight transform U = G_oth g G_otw^T; the groups of a map write disjoint
+ * outputs, their channel sums (output_bwd) and weight gradients (dw with accumulate) add up.  The `tile` entries above are the
+ * one-group case.                                                                                                               */
+typedef struct mrcnn_wino_group {
+    int oth, otw;      /* outputs per tile, rows / columns: 2 or 4 */
+    int th_n, tw_n;    /* tiles per map */
+    int oh0, ow0;      /* output row / column of the first tile */
+} mrcnn_wino_group;
+size_t mrcnn_winograd_group_floats(const mrcnn_wino_group* g, int N, int C);
+int mrcnn_winograd_input_g(const float* x, float* V, int N, int H, int W, int C, const mrcnn_wino_group* g, void* stream);
+int mrcnn_winograd_weights_g(const float* w_hwio, float* U, int Cin, int Cout, int oth, int otw, void* stream);
+int mrcnn_winograd_output_g(const float* Mt, float* out, float* z_out, const float* bias, const float* scale, const float* shift,
+                            int N, int H, int W, int C, int act, const mrcnn_wino_group* g, void* stream);
+int mrcnn_winograd_output_bwd_g(const float* Mt, float* dz_below, const float* below_out, const float* below_z, const float* scale,
+                                const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H, int W,
+                                int C, int act, const mrcnn_wino_group* g, void* stream);
+int mrcnn_winograd_dy_g(const float* dy, float* dM, int N, int H, int W, int C, const mrcnn_wino_group* g, void* stream);
+int mrcnn_winograd_dw_g(const float* dU, float* dw_hwio, int Cin, int Cout, int accumulate, int oth, int otw, void* stream);
+
 /* KL.Conv2DTranspose(256, (2, 2), strides=2, activation="relu") of build_fpn_mask_graph (mrcnn/model.py:1084-1086) as one product
  * [N H W x Cin] . [Cin x 4 Cd] on the persistent GEMM (mrcnn_winograd_gemm's kernel) with bias, activation and the pixel-shuffle
  * store in its epilogue: K is a single filter tap deep, where the persistent form beats the one-tile-per-workgroup kernel

@@ -105,8 +105,20 @@ def test_winograd_path_selection_and_buffer_sizes():
     assert not ops.winograd_ok((2048, 15, 14, 256), w)                    # odd extent (the engine's rule; tile 4 alone would take it)
     assert not ops.winograd_ok((2048, 14, 14, 256), (3, 3, 256, 64))      # Cout % 128
     if ops._WINO_TILE == 4:
-        assert ops.winograd_tile((2048, 14, 14, 256)) == 4 and ops.winograd_tile((1024, 14, 14, 256)) == 4
-        assert ops.winograd_tile((512, 14, 14, 256)) == 4 and ops.winograd_tile((511, 14, 14, 256)) == 2
+        big = ops.TILE_MIXED if ops._WINO_MIXED else 4              # 14 = 4 + 4 + 4 + 2: mixed groups instead of an overhanging 4th tile
+        assert ops.winograd_tile((2048, 14, 14, 256)) == big and ops.winograd_tile((1024, 14, 14, 256)) == big
+        assert ops.winograd_tile((512, 14, 14, 256)) == big and ops.winograd_tile((511, 14, 14, 256)) == 2
+        assert ops.winograd_tile((2048, 16, 16, 256)) == 4
+    gs = ops.winograd_groups(14, 14, ops.TILE_MIXED)
+    assert [(g.oth, g.otw, g.th_n, g.tw_n, g.oh0, g.ow0) for g in gs] == [(4, 4, 3, 3, 0, 0), (4, 2, 3, 1, 0, 12), (2, 4, 1, 3, 12, 0),
+                                                                          (2, 2, 1, 1, 12, 12)]
+    covered = np.zeros((14, 14), int)                              # every output exactly once
+    for g in gs:
+        for th in range(g.th_n):
+            for tw in range(g.tw_n):
+                covered[g.oh0 + g.oth * th:g.oh0 + g.oth * (th + 1), g.ow0 + g.otw * tw:g.ow0 + g.otw * (tw + 1)] += 1
+    assert (covered == 1).all()
+    assert ops.winograd_v_floats((2048, 14, 14, 256), ops.TILE_MIXED) == (36 * 18432 + 2 * 24 * 6144 + 16 * 2048) * 256
     assert ops.winograd_tile((100, 14, 14, 256)) == 2
     lib = _hip.lib()
     assert lib.mrcnn_winograd_buffer_floats(2048, 14, 14, 256, 2) == 16 * 100352 * 256          # 2048 * 49 tiles: already whole row tiles

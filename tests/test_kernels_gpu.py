@@ -101,14 +101,17 @@ def test_conv_fwd(dev, case, tail_split_env):
 
 
 @pytest.mark.parametrize("case", [(2, 37, 14, 14, 64, 128), (2, 5, 8, 12, 32, 256), (2, 130, 14, 14, 256, 256),
-                                  (4, 37, 14, 14, 64, 128), (4, 5, 7, 9, 32, 256), (4, 130, 14, 14, 256, 256), (4, 3, 16, 8, 128, 128)])
+                                  (4, 37, 14, 14, 64, 128), (4, 5, 7, 9, 32, 256), (4, 130, 14, 14, 256, 256), (4, 3, 16, 8, 128, 128),
+                                  (6, 37, 14, 14, 64, 128), (6, 9, 6, 10, 32, 256), (6, 130, 14, 14, 256, 256)])
 def test_conv_winograd(dev, case):
     """Winograd F(2x2, 3x3) / F(4x4, 3x3) path of the 3x3 'same' convolutions (input transform, 16 / 36 batched GEMMs in one launch,
     output transform with bias / frozen BN / ReLU / pre-BN z): against the oracle -- tile 2 at the float32 tolerance of the direct
     kernels (its transforms use +-1 and 1/2 only), tile 4 at 5e-5 of the result's range (constants up to 8: one decimal digit;
     measured 1.3e-5 at K = 256).  Tile counts that are not multiples of 128 exercise the padded GEMM rows; 14, 7 and 9 are not
-    multiples of 4 (tiles that hang over the edge).  Then the weight gradient through the same domain and the data-gradient form
-    fused with the epilogue backward of the layer below, against the direct kernels of the package."""
+    multiples of 4 (tiles that hang over the edge).  Tile 6 = TILE_MIXED: extents that are 2 mod 4 covered by 4 x 4 tiles and a
+    last row / column of 4 x 2, 2 x 4 and 2 x 2 tiles (four groups, no overhang; same tolerance as tile 4).  Then the weight
+    gradient through the same domain and the data-gradient form fused with the epilogue backward of the layer below, against the
+    direct kernels of the package."""
     ops = _ops()
     tile, N, H, W, Cin, Cout = case
     rng = np.random.default_rng(300 + sum(case))
@@ -120,7 +123,10 @@ def test_conv_winograd(dev, case):
     y_ref = torch.relu(z_ref * torch.tensor(sc) + torch.tensor(sh))
     xt, wt, bt, sct, sht = (torch.tensor(a, device=dev) for a in (x, w, b, sc, sh))
     U = ops.winograd_weights(wt, tile=tile)
-    assert tuple(U.shape) == ((tile + 2) ** 2, Cin, Cout)
+    if tile == ops.TILE_MIXED:
+        assert [tuple(u.shape) for u in U] == [(nb, Cin, Cout) for nb in (36, 24, 24, 16)]
+    else:
+        assert tuple(U.shape) == ((tile + 2) ** 2, Cin, Cout)
     tol = lambda ref: F32 if tile == 2 else dict(rtol=1e-4, atol=5e-5 * float(ref.abs().max()))
     z = torch.empty((N, H, W, Cout), device=dev)
     y = ops.conv2d_winograd(xt, U, bt, sct, sht, 1, z_out=z)
