@@ -673,9 +673,10 @@ def main():
             "detect_ms_per_image_f16_stages": rnd(r.get("detect_ms_f16")),
             "value_direct_conv_kernels": None if r.get("images_per_s_direct") is None else round(r["images_per_s_direct"], 3),
             "note_direct_conv_kernels": "the same step with the Winograd path of the mask head switched off (direct 3x3 implicit-GEMM "
-                                        "kernels, MRCNN_WINOGRAD=0): `value` computes the same layers in float32 through F(4x4,3x3) -- 3.06x "
-                                        "fewer matrix multiplications on 14x14 maps, 1.3e-5 of the direct result's range; F(2x2,3x3) under "
-                                        "MRCNN_WINOGRAD_TILE=2: 2.25x, 1.6e-6 (DESIGN.md 4.1d)",
+                                        "kernels, MRCNN_WINOGRAD=0): `value` computes the same layers in float32 through F(4x4,3x3) tiles plus "
+                                        "a last row / column of 4x2, 2x4, 2x2 tiles -- 3.6x fewer matrix multiplications on 14x14 maps, "
+                                        "1.3e-5 of the direct result's range; F(2x2,3x3) under MRCNN_WINOGRAD_TILE=2: 2.25x, 1.6e-6 "
+                                        "(DESIGN.md 4.1d)",
             "value_exact_zero_skip": None if args.dense_only else round(r["images_per_s_sparse"], 3),
             "note_exact_zero_skip": "same step with the mask head (forward and backward) run on the <=168 positive-quota ROI "
                                     "rows per image only: the other rows are never read by the loss and carry exactly-zero "
