@@ -230,7 +230,9 @@ class MaskRCNNEngine(object):
         # matrix-core flops through three launches per layer; MRCNN_WINOGRAD=0 keeps the direct kernels
         self.winograd = os.environ.get("MRCNN_WINOGRAD", "1") != "0"
         self.winograd_wgrad = os.environ.get("MRCNN_WINOGRAD_WGRAD", "1") != "0"    # weight gradients through the same domain
-        self.winograd_split = os.environ.get("MRCNN_WINOGRAD_SPLIT", "1") != "0"    # forward: two half-batch chains on two streams
+        # forward as two half-batch chains on two streams: +0.7 ms with the F(2x2) layers, level with the uniform F(4x4) tiling, a loss with
+        # the mixed tiling (its small tile groups halve again: ResNet-101 / 4 images 37.6 -> 37.4 ms, ResNet-50 / 2 images 20.8 -> 20.0) -> off
+        self.winograd_split = os.environ.get("MRCNN_WINOGRAD_SPLIT", "0") != "0"
         self._wino_V = {}               # layer -> input transform V of this step's forward pass
         self._wino = {}                 # layer -> [U forward, U data gradient] (allocated once, refreshed after weight updates)
         self._wino_valid = {}           # layer -> [forward valid, data-gradient valid]

@@ -573,6 +573,28 @@ def test_fused_dgrad_epilogue_equals_unfused(dev):
     assert np.abs(res[0][1] - res[1][1]).max() <= 2e-5 * scale and scale > 0
 
 
+def test_winograd_split_forward_equals_whole(dev):
+    """engine.winograd_split (the mask head's Winograd layers as two half-batch chains on two streams, off by default since the
+    mixed tiling) against the whole-batch chain: same losses, gradients equal up to the order of the float32 atomics and of the
+    two accumulating weight-gradient calls per layer.  ResNet-50 256x256, 2 images = 1024 ROI rows = two halves of 512."""
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _full_cfg("resnet50", 256)
+    w = _weights(cfg, 47)
+    inputs, keys = _train_inputs(cfg, 2, 49)
+    res = []
+    for split in (True, False):
+        model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+        assert model.engine.winograd
+        model.engine.winograd_split = split
+        model.engine.sparse_mask_bwd = False
+        losses = model.train_on_batch(inputs, rand_keys=keys, apply=False)
+        torch.cuda.synchronize()
+        res.append((losses.cpu().numpy(), model.engine.grads.cpu().numpy().copy()))
+    np.testing.assert_allclose(res[0][0], res[1][0], rtol=5e-6)
+    scale = np.abs(res[1][1]).max()
+    assert np.abs(res[0][1] - res[1][1]).max() <= 2e-5 * scale and scale > 0
+
+
 def test_graph_replay_with_multiworkgroup_topk_512(dev):
     """512x512 (A = 65 472 anchors >= 32 768): the proposal layer selects its top-k over many workgroups; several
     HIP-graph replays must return exactly what the eager launches return (the selection zeroes its counters itself --
