@@ -188,7 +188,8 @@ def _train_loop_leg(args, res, model, cfg, nimg, world, rank):
         gen.close()
         eng.sparse_mask_bwd = True
     res["train_loop"] = dict(dense, steps=steps, loader_threads=nw, exact_zero_skip=sparse,
-        what="MaskRCNN.train()'s own iteration: Prefetcher threads over data_generator on 32 synthetic FITS tiles "
+        launch_tape=bool(getattr(cfg, "TRAIN_LAUNCH_TAPE", False)),
+        what="MaskRCNN.train()'s own iteration (steps re-issued from the launch recording when launch_tape): Prefetcher threads over data_generator on 32 synthetic FITS tiles "
              "(read_fits + zscale + uint8 RGB + resize + extract_bboxes), per-step H2D of images and the used GT-mask planes, "
              "bit-packed (8 instances per byte), RPN targets built on the device; dense mask head like `value`, and the product-default step under "
              "exact_zero_skip; feed-inclusive, never `value`")

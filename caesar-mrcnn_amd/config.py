@@ -3,6 +3,8 @@ of scripts/run.py:93-239).  Attribute names, defaults and the three derived fiel
 everything else here is ours.  Unlike the reference, ``BATCH_SIZE`` is a live property so overriding
 IMAGES_PER_GPU / GPU_COUNT on an instance (as run.py:1632-1633 does) stays consistent.
 """
+import os
+
 import numpy as np
 
 _LOSS_NAMES = ("rpn_class_loss", "rpn_bbox_loss", "mrcnn_class_loss", "mrcnn_bbox_loss", "mrcnn_mask_loss")
@@ -66,6 +68,12 @@ class Config(object):
     # three forked streams of the step with less overlap than the eager queues do, which costs more than the host
     # time it saves
     TRAIN_HIP_GRAPH = False
+    # extension: single-rank training steps re-issued from a launch recording (engine.step_taped): the same launches on the same
+    # streams as the eager step, without the engine's Python per launch.  Device time is unchanged; what it buys is the
+    # interpreter lock -- the loader threads of MaskRCNN.train() share it with the main thread, and the positive-quota loop went
+    # from 121-127 to 168-182 images/s (ResNet-101, 4 images, 8 loader threads; the dense loop is device-bound either way).
+    # MRCNN_TRAIN_TAPE=0 switches it off.  Data-parallel runs keep eager launches (gradient hooks are not recorded).
+    TRAIN_LAUNCH_TAPE = os.environ.get("MRCNN_TRAIN_TAPE", "1") != "0"
     # extension: None (float32 everywhere, the reference's precision) | "float16" | "bfloat16": run the 3x3
     # convolutions of the mask head on the 16-bit matrix cores (csrc/conv_h16.hip; float32 master weights,
     # accumulation and gradients; HEAD_LOSS_SCALE guards float16 gradients)

@@ -1453,6 +1453,15 @@ class MaskRCNNEngine(object):
     # =========================================================================================
     #  the whole training step as one HIP graph
     # =========================================================================================
+    _MODE_ATTRS = ("sparse_mask_bwd", "h16_wide", "h16_blocks", "h16_all_blocks", "h16_fused_bwd", "h16_phase_bwd", "winograd",
+                   "winograd_wgrad", "winograd_split", "fused_mask_out_bwd", "fused_dgrad_epilogue", "defer_mask_wgrad",
+                   "gather_roialign_bwd", "multi_launch")
+
+    def _mode_key(self):
+        """Every engine switch a captured graph / recorded launch tape bakes in besides the tensors: a replay is only valid for the
+        mode it was made in (tests and tools flip these attributes between steps of one engine)."""
+        return tuple(getattr(self, a, None) for a in self._MODE_ATTRS) + (float(self.loss_scale), self.forced_rpn_rois is not None)
+
     def step_graphed(self, dev_inputs, learning_rate, momentum):
         """forward_backward + apply_gradients (single rank) replayed from a HIP graph: one capture per input signature,
         learning rate / momentum and engine mode.  A step is ~670 launches in float32 and ~930 with the 16-bit blocks; issued
@@ -1461,7 +1470,7 @@ class MaskRCNNEngine(object):
         concurrency.  Inputs are copied into the graph's static buffers; the returned losses tensor is the graph's static
         output (valid until the next replay).  Nothing on this path may use memset / memcpy nodes."""
         key = (tuple((tuple(t.shape), t.dtype) for t in dev_inputs), float(learning_rate), float(momentum), self.head_dtype,
-               self.sparse_mask_bwd, self.h16_wide, self.h16_blocks, id(self.cfg))
+               id(self.cfg), self._mode_key())
         entry = self._train_graphs.get(key)
         main = torch.cuda.current_stream(self.dev)
         if entry is None:
@@ -1470,7 +1479,7 @@ class MaskRCNNEngine(object):
             for s_, t in zip(static, dev_inputs):
                 s_.copy_(t)
             # two eager steps size every workspace, arena slot and weight image; they must not count as training steps
-            keep = (self.params.clone(), self.momentum.clone())
+            keep = (self.params.clone(), self.momentum.clone(), self.skipped_steps.clone())
             side = torch.cuda.Stream(device=self.dev)
             _hip_mod.stream_wait(side, main)
             with torch.cuda.stream(side):
@@ -1479,6 +1488,7 @@ class MaskRCNNEngine(object):
                     self.apply_gradients(learning_rate, momentum, 1)
                 self.params.copy_(keep[0])
                 self.momentum.copy_(keep[1])
+                self.skipped_steps.copy_(keep[2])
                 self.wt_valid = self._h16_valid = False
                 self.fold_bn()
             _hip_mod.stream_wait(main, side)
@@ -1506,8 +1516,7 @@ class MaskRCNNEngine(object):
         order as the eager step (so, unlike the HIP-graph replay, the same overlap), without the engine's Python per launch.
         Valid because the step arena, the workspaces and the weight images have stable addresses."""
         key = (tuple((tuple(t.shape), t.dtype) for t in dev_inputs), float(learning_rate), float(momentum), self.head_dtype,
-               self.sparse_mask_bwd, self.h16_wide, self.h16_blocks, self.h16_all_blocks, id(self.cfg),
-               torch.cuda.current_stream(self.dev).cuda_stream)
+               id(self.cfg), torch.cuda.current_stream(self.dev).cuda_stream, self._mode_key())
         entry = self._train_tapes.get(key)
         if entry is None:
             assert self.grad_ready is None, "the launch tape is single-rank: gradient hooks are not recorded"
@@ -1515,11 +1524,12 @@ class MaskRCNNEngine(object):
             for s_, t in zip(static, dev_inputs):
                 s_.copy_(t)
             # one eager step settles arena slots, workspaces and weight images (rolled back: it is not a training step)
-            keep = (self.params.clone(), self.momentum.clone())
+            keep = (self.params.clone(), self.momentum.clone(), self.skipped_steps.clone())
             self.forward_backward(*static)
             self.apply_gradients(learning_rate, momentum, 1)
             self.params.copy_(keep[0])
             self.momentum.copy_(keep[1])
+            self.skipped_steps.copy_(keep[2])               # a settle pass that overflowed in float16 is not a skipped training step
             self.wt_valid = self._h16_valid = False
             self.fold_bn()
             del keep
