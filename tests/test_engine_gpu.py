@@ -584,7 +584,8 @@ def test_winograd_split_forward_equals_whole(dev):
     res = []
     for split in (True, False):
         model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
-        assert model.engine.winograd
+        if not model.engine.winograd:
+            pytest.skip("MRCNN_WINOGRAD=0: nothing to split")
         model.engine.winograd_split = split
         model.engine.sparse_mask_bwd = False
         losses = model.train_on_batch(inputs, rand_keys=keys, apply=False)
