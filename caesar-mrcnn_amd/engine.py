@@ -693,8 +693,13 @@ class MaskRCNNEngine(object):
     def set_trainable(self, layer_regex):
         mask = self.layout.trainable_mask(layer_regex)
         self.trainable_host = mask
-        self.gran_coef = torch.tensor(granule_coefficients(self.layout, self.cfg.WEIGHT_DECAY, mask),
-                                      dtype=torch.float32, device=self.dev)
+        coef = torch.tensor(granule_coefficients(self.layout, self.cfg.WEIGHT_DECAY, mask), dtype=torch.float32)
+        # ONE buffer for the life of the engine, refreshed in place: recorded launch tapes and captured step graphs carry its
+        # address in their grad_prepare / sgd_momentum calls (a second train(..., layers=...) on the same model replays them)
+        if getattr(self, "gran_coef", None) is None or self.gran_coef.numel() != coef.numel():
+            self.gran_coef = torch.empty(coef.numel(), dtype=torch.float32, device=self.dev)
+            self._train_tapes, self._train_graphs = {}, {}
+        self.gran_coef.copy_(coef)           # (the backward pass computes every gradient whatever the mask: the mask acts here only)
 
     # ---- anchors -------------------------------------------------------------------------------
     def anchors(self, image_shape):
@@ -1460,7 +1465,12 @@ class MaskRCNNEngine(object):
     def _mode_key(self):
         """Every engine switch a captured graph / recorded launch tape bakes in besides the tensors: a replay is only valid for the
         mode it was made in (tests and tools flip these attributes between steps of one engine)."""
-        return tuple(getattr(self, a, None) for a in self._MODE_ATTRS) + (float(self.loss_scale), self.forced_rpn_rois is not None)
+        # ... and what a launch bakes in by VALUE: the loss weights and the clip norm are scalar arguments of recorded calls
+        # (cfg is mutable: run.py patches it in place).  The trainable mask / weight decay live in gran_coef, a buffer with a
+        # stable address that set_trainable refreshes in place, so recordings survive a change of `layers`.
+        return tuple(getattr(self, a, None) for a in self._MODE_ATTRS) + (
+            float(self.loss_scale), self.forced_rpn_rois is not None, tuple(self.loss_weights()),
+            float(self.cfg.GRADIENT_CLIP_NORM))
 
     def step_graphed(self, dev_inputs, learning_rate, momentum):
         """forward_backward + apply_gradients (single rank) replayed from a HIP graph: one capture per input signature,

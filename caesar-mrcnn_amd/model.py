@@ -332,15 +332,16 @@ class MaskRCNN(object):
             image_metas.append(meta)
         return np.stack(molded_images), np.stack(image_metas), np.stack(windows)
 
-    def unmold_detections(self, detections, mrcnn_mask, original_image_shape, image_shape, window):
-        """Network output -> boxes/class ids/scores/full-size masks of one image
-        (mrcnn/model.py:2558-2621)."""
+    def _unmold_boxes(self, detections, original_image_shape, image_shape, window):
+        """Host half of unmold_detections (mrcnn/model.py:2578-2605): the rows before the first class id 0, boxes from
+        normalised window coordinates to pixels of the original image, zero-area boxes dropped.  Returns boxes [n,4] int32,
+        class_ids [n] int32, scores [n] float32 and the rows of `detections` they came from."""
         zero_ix = np.where(detections[:, 4] == 0)[0]
         N = zero_ix[0] if zero_ix.shape[0] > 0 else detections.shape[0]
         boxes = detections[:N, :4]
         class_ids = detections[:N, 4].astype(np.int32)
         scores = detections[:N, 5]
-        masks = mrcnn_mask[np.arange(N), :, :, class_ids]
+        rows = np.arange(N, dtype=np.int32)
         window = utils.norm_boxes(window, image_shape[:2])
         wy1, wx1, wy2, wx2 = window
         shift = np.array([wy1, wx1, wy1, wx1])
@@ -348,19 +349,50 @@ class MaskRCNN(object):
         scale = np.array([wh, ww, wh, ww])
         boxes = np.divide(boxes - shift, scale)
         boxes = utils.denorm_boxes(boxes, original_image_shape[:2])
-        exclude_ix = np.where((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]) <= 0)[0]
-        if exclude_ix.shape[0] > 0:
-            boxes = np.delete(boxes, exclude_ix, axis=0)
-            class_ids = np.delete(class_ids, exclude_ix, axis=0)
-            scores = np.delete(scores, exclude_ix, axis=0)
-            masks = np.delete(masks, exclude_ix, axis=0)
-            N = class_ids.shape[0]
-        full_masks = [utils.unmold_mask(masks[i], boxes[i], original_image_shape) for i in range(N)]
-        full_masks = np.stack(full_masks, axis=-1) if full_masks else np.empty(tuple(original_image_shape[:2]) + (0,))
-        return boxes, class_ids, scores, full_masks
+        keep = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]) > 0
+        if not keep.all():
+            boxes, class_ids, scores, rows = boxes[keep], class_ids[keep], scores[keep], rows[keep]
+        return boxes, class_ids, scores, rows
 
-    def _predict_molded(self, molded_images, image_metas):
-        """The seven outputs of the inference graph as host arrays (model.py:2156-2159)."""
+    def _unmold_masks_device(self, boxes, class_ids, rows, mrcnn_mask_dev, original_image_shape):
+        """Device half (mrcnn/model.py:2607-2619): every detection's class mask resized to its box, thresholded and pasted
+        (ops.unmold_masks); returns the pinned host tensor the [H, W, n] uint8 result is being copied into -- valid after the
+        next synchronisation of the current stream."""
+        import torch
+        from . import ops
+        H, W = int(original_image_shape[0]), int(original_image_shape[1])
+        n = boxes.shape[0]
+        C_ = mrcnn_mask_dev.shape[-1]
+        if n and (class_ids.min() < 0 or class_ids.max() >= C_ or (boxes[:, 0] < 0).any() or (boxes[:, 1] < 0).any() or
+                  (boxes[:, 2] > H).any() or (boxes[:, 3] > W).any()):
+            # the reference's paste `full_mask[y1:y2, x1:x2] = mask` raises on such a box too (shape mismatch)
+            raise ValueError("detection box outside the %dx%d image or class id outside [0, %d)" % (H, W, C_))
+        host = torch.empty((H, W, n), dtype=torch.uint8, pin_memory=True)
+        if n:
+            dets = np.empty((n, 6), np.int32)
+            dets[:, :4], dets[:, 4], dets[:, 5] = boxes, class_ids, rows
+            d = torch.from_numpy(dets).to(mrcnn_mask_dev.device, non_blocking=True)
+            host.copy_(ops.unmold_masks(mrcnn_mask_dev, d, (H, W)), non_blocking=True)
+        return host
+
+    def unmold_detections(self, detections, mrcnn_mask, original_image_shape, image_shape, window):
+        """Network output -> boxes/class ids/scores/full-size masks of one image (mrcnn/model.py:2558-2621).  `mrcnn_mask`
+        [N, mh, mw, num_classes] may be a host array (uploaded) or a device tensor; the masks are resized and pasted on the
+        GPU (utils.unmold_mask is the host statement of the same arithmetic, tests/test_kernels_gpu.py::test_unmold_masks)."""
+        import torch
+        detections = np.asarray(detections)
+        boxes, class_ids, scores, rows = self._unmold_boxes(detections, original_image_shape, image_shape, window)
+        if not torch.is_tensor(mrcnn_mask):
+            mrcnn_mask = torch.from_numpy(np.ascontiguousarray(mrcnn_mask, dtype=np.float32))
+        mrcnn_mask = mrcnn_mask.to(self.engine.dev).contiguous()
+        if boxes.shape[0] == 0:
+            return boxes, class_ids, scores, np.empty(tuple(original_image_shape[:2]) + (0,))
+        host = self._unmold_masks_device(boxes, class_ids, rows, mrcnn_mask, original_image_shape)
+        torch.cuda.current_stream(self.engine.dev).synchronize()
+        return boxes, class_ids, scores, host.numpy().view(np.bool_)
+
+    def _run_graph(self, molded_images, image_metas):
+        """The inference graph on molded inputs (model.py:2156-2159); outputs stay on the device."""
         import torch
         eng = self.engine
         x = torch.from_numpy(np.ascontiguousarray(molded_images, dtype=np.float32))
@@ -370,21 +402,50 @@ class MaskRCNN(object):
               (np.array([shape[0], shape[1], shape[0], shape[1]], np.float32) - np.float32(1.0))
         wt = torch.from_numpy(np.ascontiguousarray(win, dtype=np.float32))
         if self.use_hip_graph:
-            out = eng.infer_graphed(x, wt)
-        else:
-            out = eng.infer(x.to(eng.dev), wt.to(eng.dev))
-        torch.cuda.synchronize(eng.dev)
+            return eng.infer_graphed(x, wt)
+        return eng.infer(x.to(eng.dev), wt.to(eng.dev))
+
+    def _predict_molded(self, molded_images, image_metas):
+        """The seven outputs of the inference graph as host arrays (model.py:2156-2159)."""
+        import torch
+        out = self._run_graph(molded_images, image_metas)
+        torch.cuda.synchronize(self.engine.dev)
         return [out[k].cpu().numpy() for k in ("detections", "mrcnn_class", "mrcnn_bbox", "mrcnn_mask", "rpn_rois",
                                                "rpn_class", "rpn_bbox")]
 
-    def detect(self, images, verbose=0):
-        """List of [h,w,3] images -> list of {rois, class_ids, scores, masks} (mrcnn/model.py:2623-2704)."""
+    def _detect_results(self, out, shapes, molded_shapes, windows, timing=None):
+        """detections (host, 2.4 KB per image) -> box arithmetic on the host -> masks resized / pasted on the device -> one
+        pinned D2H copy of the [H, W, n] planes per image.  mrcnn_mask never leaves the device."""
+        import time
+        import torch
+        stream = torch.cuda.current_stream(self.engine.dev)
+        detections = out["detections"].cpu().numpy()                       # synchronises: the graph is done here
+        if timing is not None:
+            timing["graph_done"] = time.perf_counter()
+        pending = []
+        for i in range(len(shapes)):
+            boxes, class_ids, scores, rows = self._unmold_boxes(detections[i], shapes[i], molded_shapes[i], windows[i])
+            host = self._unmold_masks_device(boxes, class_ids, rows, out["mrcnn_mask"][i], shapes[i]) if boxes.shape[0] else None
+            pending.append((boxes, class_ids, scores, host))
+        stream.synchronize()
+        results = []
+        for (boxes, class_ids, scores, host), shp in zip(pending, shapes):
+            masks = host.numpy().view(np.bool_) if host is not None else np.empty(tuple(shp[:2]) + (0,))
+            results.append({"rois": boxes, "class_ids": class_ids, "scores": scores, "masks": masks})
+        return results
+
+    def detect(self, images, verbose=0, timing=None):
+        """List of [h,w,3] images -> list of {rois, class_ids, scores, masks} (mrcnn/model.py:2623-2704).  `timing`: an
+        optional dict that receives perf_counter() marks after the molding, the graph and the un-molding."""
         assert self.mode == "inference", "Create model in inference mode."
         assert len(images) == self.config.BATCH_SIZE, "len(images) must be equal to BATCH_SIZE"
         if verbose:
             log("Processing {} images".format(len(images)))
             for image in images:
                 log("image", image)
+        if timing is not None:
+            import time
+            timing["start"] = time.perf_counter()
         molded_images, image_metas, windows = self.mold_inputs(images)
         image_shape = molded_images[0].shape
         for g in molded_images[1:]:
@@ -393,12 +454,12 @@ class MaskRCNN(object):
         if verbose:
             log("molded_images", molded_images)
             log("image_metas", image_metas)
-        detections, _, _, mrcnn_mask, _, _, _ = self._predict_molded(molded_images, image_metas)
-        results = []
-        for i, image in enumerate(images):
-            rois, class_ids, scores, masks = self.unmold_detections(detections[i], mrcnn_mask[i], image.shape,
-                                                                    molded_images[i].shape, windows[i])
-            results.append({"rois": rois, "class_ids": class_ids, "scores": scores, "masks": masks})
+        if timing is not None:
+            timing["molded"] = time.perf_counter()
+        out = self._run_graph(molded_images, image_metas)
+        results = self._detect_results(out, [im.shape for im in images], [m.shape for m in molded_images], windows, timing)
+        if timing is not None:
+            timing["end"] = time.perf_counter()
         return results
 
     def detect_molded(self, molded_images, image_metas, verbose=0):
@@ -408,14 +469,9 @@ class MaskRCNN(object):
         image_shape = molded_images[0].shape
         for g in molded_images[1:]:
             assert g.shape == image_shape, "Images must have the same size"
-        detections, _, _, mrcnn_mask, _, _, _ = self._predict_molded(np.asarray(molded_images), image_metas)
-        results = []
-        for i, image in enumerate(molded_images):
-            window = [0, 0, image.shape[0], image.shape[1]]
-            rois, class_ids, scores, masks = self.unmold_detections(detections[i], mrcnn_mask[i], image.shape,
-                                                                    molded_images[i].shape, window)
-            results.append({"rois": rois, "class_ids": class_ids, "scores": scores, "masks": masks})
-        return results
+        out = self._run_graph(np.asarray(molded_images), image_metas)
+        shapes = [im.shape for im in molded_images]
+        return self._detect_results(out, shapes, shapes, [[0, 0, s[0], s[1]] for s in shapes])
 
     def get_anchors(self, image_shape):
         """Normalised anchor pyramid for an image shape, cached (mrcnn/model.py:2764-2784)."""

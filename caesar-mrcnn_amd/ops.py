@@ -636,6 +636,31 @@ def unpack_mask_bits(packed, n_used, G):
     return out
 
 
+def unmold_masks(mrcnn_mask, dets, image_hw, packed=False, out=None):
+    """utils.unmold_mask for all detections of one image on the device (mrcnn/model.py:2607-2619, mrcnn/utils.py:629-645).
+    mrcnn_mask [R, MH, MW, C] float32 device; dets [n, 6] int32 device = (y1, x1, y2, x2, class_id, row of mrcnn_mask), boxes in
+    pixels of the original image.  Returns uint8 [H, W, n] (0 / 1; .view(bool) is the reference's array) or, packed, [H, W,
+    ceil(n / 8)] with detection d in bit d & 7 of byte d >> 3."""
+    _need_cuda(mrcnn_mask, dets, out)
+    assert mrcnn_mask.dtype == torch.float32 and mrcnn_mask.dim() == 4 and mrcnn_mask.is_contiguous()
+    assert dets.dtype == torch.int32 and dets.dim() == 2 and dets.shape[1] == 6 and dets.is_contiguous()
+    R, MH, MW, C_ = mrcnn_mask.shape
+    n = dets.shape[0]
+    H, W = int(image_hw[0]), int(image_hw[1])
+    shape = (H, W, (n + 7) // 8 if packed else n)
+    if out is None:
+        out = torch.empty(shape, dtype=torch.uint8, device=mrcnn_mask.device)
+    assert tuple(out.shape) == shape and out.dtype == torch.uint8 and out.is_contiguous()
+    if n == 0 or H == 0 or W == 0:
+        return out
+    L = _hip.lib()
+    nbytes = L.mrcnn_unmold_masks_workspace(n, MH, MW)
+    ws = workspace(nbytes, mrcnn_mask.device, "unmold")
+    check(L.mrcnn_unmold_masks(ptr(mrcnn_mask), R, MH, MW, C_, ptr(dets), n, H, W, 1 if packed else 0, ptr(out), ptr(ws),
+                               ws.numel(), current_stream()), "mrcnn_unmold_masks")
+    return out
+
+
 def fill_zero(t):
     _need_cuda(t)
     check(_hip.lib().mrcnn_fill_zero(ptr(t), t.numel() * t.element_size(), current_stream()), "mrcnn_fill_zero")

@@ -185,6 +185,21 @@ int mrcnn_fill_zero(void* dst, size_t bytes, void* stream);
  * >= n_used are written as zeros.                                                                                           */
 int mrcnn_unpack_mask_bits(const void* packed, void* out, int64_t npix, int nbytes_per_pixel, int n_used, int G, void* stream);
 
+/* detect() post-processing (MaskRCNN.unmold_detections, mrcnn/model.py:2607-2619; utils.unmold_mask, mrcnn/utils.py:629-645;
+ * utils.resize -> skimage.transform.resize(order=1, mode='constant', cval=0, clip=True), mrcnn/utils.py:957-978): for each of
+ * the n detections of ONE image, resize the class channel of its MH x MW mask to its integer pixel box (float64, half-pixel
+ * centres, zero outside the mask, clipped to the mask's [min, max]), threshold `>= 0.5` and paste it into the image plane.
+ *   mrcnn_mask [n_rows, MH, MW, C] float32 (the graph's output for this image);
+ *   dets [n, 6] int32 = (y1, x1, y2, x2, class_id, row): box in pixels of the ORIGINAL image (y2 / x2 exclusive, as
+ *        utils.denorm_boxes returns them; the box arithmetic and the zero-area filter stay with the caller), the class
+ *        channel and the row of mrcnn_mask the detection came from;
+ *   out  packed == 0: [H, W, n] uint8 0 / 1 (np.stack(full_masks, axis=-1) of the reference, viewable as bool);
+ *        packed != 0: [H, W, ceil(n / 8)] uint8, bit (d & 7) of byte d >> 3 = detection d (little bit order).
+ * Pixels of a box outside the image are dropped.  workspace: mrcnn_unmold_masks_workspace(n, MH, MW) bytes.          */
+size_t mrcnn_unmold_masks_workspace(int n, int MH, int MW);
+int mrcnn_unmold_masks(const float* mrcnn_mask, int n_rows, int MH, int MW, int C, const int32_t* dets, int n, int H, int W,
+                       int packed, void* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Elementwise helpers on flat buffers. */
 int mrcnn_add_inplace(float* dst, const float* src, int64_t n, void* stream);
 int mrcnn_softmax_rows(const float* logits, float* probs, int64_t rows, int C, void* stream);

@@ -109,7 +109,13 @@ def _check_gradients(g, o, names, tag=""):
         if err > 5e-3:
             (flips if (err <= 2e-2 and l2 <= 5e-3) else bad).append((name, err, l2, scale))
     assert not bad, (tag, bad[:8])
+    # how many tensors needed the flip allowance is part of the test's output (pytest -rP / -s shows it; a drift from the 0-2
+    # seen so far is visible before it reaches the cap)
+    print("[gradient check %s] %d tensors, %d within 5e-3, %d tolerated as ReLU-boundary flips (cap %d): %s" % (
+        tag, len(names), len(names) - len(flips), len(flips), max(1, len(names) // 100),
+        ", ".join("%s max %.2e l2 %.2e" % f[:3] for f in flips)))
     assert len(flips) <= max(1, len(names) // 100), (tag, flips)
+    return len(flips)
 
 
 def _close(got, ref, rtol, name):
@@ -330,6 +336,16 @@ def test_detect_on_reference_fits_cutout_and_graph_replay(dev):
     assert res["masks"].shape[:2] == (132, 132) and res["rois"].dtype == np.int32
     assert res["rois"].shape[0] == res["class_ids"].shape[0] == res["scores"].shape[0] == res["masks"].shape[2]
     assert res["rois"].shape[0] > 0 and res["rois"].max() <= 132 and (res["class_ids"] > 0).all()
+    # detect() un-molds on the device (mrcnn_unmold_masks); the host statement of mrcnn/model.py:2558-2621 on the same graph
+    # outputs (utils.unmold_mask per detection) must give the identical boxes and boolean planes
+    from caesar_mrcnn_amd import utils
+    det, mm = g1[0][0], g1[3][0]
+    boxes, class_ids, scores, rows = model._unmold_boxes(det, img.shape, molded[0].shape, windows[0])
+    want = np.stack([utils.unmold_mask(mm[r, :, :, c], b, img.shape) for r, c, b in zip(rows, class_ids, boxes)], axis=-1)
+    assert res["masks"].dtype == np.bool_ and np.array_equal(res["masks"], want) and want.any()
+    assert np.array_equal(res["rois"], boxes) and np.array_equal(res["class_ids"], class_ids) and np.array_equal(res["scores"], scores)
+    b2, c2, s2, m2 = model.unmold_detections(det, mm, img.shape, molded[0].shape, windows[0])     # the public method, host arrays in
+    assert np.array_equal(m2, want) and np.array_equal(b2, boxes)
 
 
 def _full_cfg(backbone, size, mode="training", nimg=2):
@@ -629,17 +645,33 @@ def test_graphed_training_steps_equal_eager(dev, head_dtype, how):
     cfg = _small_cfg("resnet50", 128)
     w = _weights(cfg, 71, damp=0.5)
     batches = [_train_inputs(cfg, 2, 73), _train_inputs(cfg, 2, 75)]
+    forced = None
+    if head_dtype:
+        # 16-bit rounding moves RPN scores in the 4th digit, which can re-order an NMS decision and hand the two trajectories
+        # different ROI sets (the differences that forced rtol 0.15 here in round 2).  Both runs therefore take their proposals
+        # from one fixed set per batch (engine.forced_rpn_rois: the float32 engine's proposals at the initial weights, refreshed
+        # in place before every step -- the replayed launches read the same buffer), which leaves the differentiable part, the
+        # streams and the optimiser under test at float32-like tolerances.
+        m0 = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+        forced = []
+        for inputs, keys in batches:
+            m0.train_on_batch(inputs, rand_keys=keys, apply=False, keep_outputs=True)
+            forced.append(m0.engine.last["rpn_rois"].clone())
+        del m0
     out = {}
     for graphed in (False, True):
         model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
         eng = model.engine
         if head_dtype:
             eng.head_dtype = getattr(torch, head_dtype)
+            eng.forced_rpn_rois = torch.empty_like(forced[0])
         model.compile(0.002, 0.9)
         losses = []
         for s in range(4):
             inputs, keys = batches[s % 2]
             di = model._to_device(inputs, keys)
+            if forced is not None:
+                eng.forced_rpn_rois.copy_(forced[s % 2])
             if graphed:
                 ls = (eng.step_graphed if how == "graph" else eng.step_taped)(di, 0.002, 0.9)
             else:
@@ -650,19 +682,20 @@ def test_graphed_training_steps_equal_eager(dev, head_dtype, how):
         out[graphed] = (np.stack(losses), eng.params.cpu().numpy().copy(), eng.momentum.cpu().numpy().copy())
         if graphed:
             assert len(eng._train_graphs if how == "graph" else eng._train_tapes) == 1
-    # the first two steps see (almost) identical weights: tight; afterwards the atomics-order noise of the updates has been
-    # through the network again -- with 16-bit rounding it can re-order an NMS decision, which moves the class / box losses
-    # of that step by a fraction of a per cent (same in two eager runs)
-    tight = 1 if head_dtype else 2                # 16-bit rounding can already flip a proposal after ONE update
-    np.testing.assert_allclose(out[True][0][:tight], out[False][0][:tight], rtol=2e-4, atol=1e-5)
-    tol = 3e-2 if head_dtype else 2e-4
-    # (16-bit: a re-ordered proposal moves single loss terms of the later steps by several per cent -- the float32 case is
-    # the exactness check of the replay, the 16-bit one checks that its kernels and streams are replayed at all)
-    np.testing.assert_allclose(out[True][0], out[False][0], rtol=0.15 if head_dtype else tol, atol=1e-5)
-    if head_dtype:                                     # diverged trajectories: relative L2 of parameters / momentum history
-        for k, t in ((1, 1e-3), (2, 0.5)):
+    # float32: the first two steps see (almost) identical weights: tight; afterwards the atomics-order noise of the updates has
+    # been through the network again.  16-bit: same ROI sets in both runs (see above), so the losses agree to 2e-3 on the
+    # first two steps (measured: 2e-4) and to 5e-3 on steps 3-4 (measured 2.3e-3 on the box loss: a float32 weight that
+    # differs in its last bit after an update can round to the neighbouring float16 value, 2^13 times that), the momentum
+    # history to 1e-2 in relative L2 (round 2: 0.15 / 0.5 with free-running proposals).
+    if head_dtype:
+        np.testing.assert_allclose(out[True][0][:2], out[False][0][:2], rtol=2e-3, atol=1e-5)
+        np.testing.assert_allclose(out[True][0], out[False][0], rtol=5e-3, atol=1e-5)
+        for k, t in ((1, 1e-4), (2, 1e-2)):
             assert np.linalg.norm(out[True][k] - out[False][k]) <= t * np.linalg.norm(out[False][k]), k
     else:
+        tol = 2e-4
+        np.testing.assert_allclose(out[True][0][:2], out[False][0][:2], rtol=2e-4, atol=1e-5)
+        np.testing.assert_allclose(out[True][0], out[False][0], rtol=tol, atol=1e-5)
         for k, t in ((1, tol), (2, max(tol, 5e-3))):   # parameters; momentum buffer (= -lr * gradient history: atomics-order noise)
             scale = np.abs(out[False][k]).max()
             assert np.abs(out[True][k] - out[False][k]).max() <= t * scale, k

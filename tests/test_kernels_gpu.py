@@ -779,6 +779,72 @@ def test_unpack_mask_bits(dev, n_used, G):
     np.testing.assert_array_equal(got.cpu().numpy(), masks)
 
 
+def _unmold_boxes_for_test(rng, n, H, W):
+    """Random integer boxes inside an H x W image: 1-pixel boxes, 1-pixel-wide rows / columns, boxes touching every edge,
+    the full tile, sizes below / equal to / above the 28-pixel mask (down-, iso- and up-sampling)."""
+    boxes = np.zeros((n, 4), np.int32)
+    for i in range(n):
+        kind = i % 10
+        if kind == 0:                                   # one pixel
+            y1, x1 = rng.integers(0, H), rng.integers(0, W); y2, x2 = y1 + 1, x1 + 1
+        elif kind == 1:                                 # the whole tile
+            y1, x1, y2, x2 = 0, 0, H, W
+        elif kind == 2:                                 # touches the top-left corner
+            y1, x1 = 0, 0; y2, x2 = rng.integers(1, H + 1), rng.integers(1, W + 1)
+        elif kind == 3:                                 # touches the bottom-right corner
+            y2, x2 = H, W; y1, x1 = rng.integers(0, H), rng.integers(0, W)
+        elif kind == 4:                                 # one pixel wide / high
+            y1 = rng.integers(0, H); y2 = y1 + 1; x1 = rng.integers(0, W - 1); x2 = rng.integers(x1 + 1, W + 1)
+        elif kind == 5:
+            x1 = rng.integers(0, W); x2 = x1 + 1; y1 = rng.integers(0, H - 1); y2 = rng.integers(y1 + 1, H + 1)
+        elif kind == 6:                                 # exactly the mask's size
+            y1, x1 = rng.integers(0, H - 27), rng.integers(0, W - 27); y2, x2 = y1 + 28, x1 + 28
+        else:
+            y1, x1 = rng.integers(0, H - 1), rng.integers(0, W - 1)
+            y2, x2 = rng.integers(y1 + 1, H + 1), rng.integers(x1 + 1, W + 1)
+        boxes[i] = (y1, x1, y2, x2)
+    return boxes
+
+
+@pytest.mark.parametrize("packed", [False, True])
+def test_unmold_masks(dev, packed):
+    """mrcnn_unmold_masks against the host statement of mrcnn/utils.py:629-645 (caesar_mrcnn_amd.utils.unmold_mask: float64
+    bilinear resize of the 28 x 28 class mask to the integer box, clip to the mask's range, `>= 0.5`, paste): 1040 boxes in
+    batches of 104 detections (13 bytes in the packed form, the last one partial) on a 96 x 80 image -- 1-pixel, edge-touching,
+    full-tile, down- / up-sampled boxes; masks with all values above / below the threshold (the clip decides those) and one
+    with a NaN.  Boolean output identical, both layouts; class channel and row indirection exercised."""
+    ops = _ops()
+    from caesar_mrcnn_amd import utils
+    rng = np.random.default_rng(77)
+    H, W, C_, R, n = 96, 80, 4, 120, 104
+    for batch in range(10):
+        mm = 1.0 / (1.0 + np.exp(-_rand(rng, R, 28, 28, C_, scale=2.0)))
+        mm = mm.astype(np.float32)
+        mm[3] = 0.5 + 0.4 * rng.random((28, 28, C_), dtype=np.float32)       # min >= 0.5: the clip fills the whole box
+        mm[4] = 0.4 * rng.random((28, 28, C_), dtype=np.float32)             # max < 0.5: nothing set
+        mm[5, 7, 9, :] = np.nan
+        boxes = _unmold_boxes_for_test(rng, n, H, W)
+        cls = rng.integers(0, C_, n).astype(np.int32)
+        rows = rng.permutation(R)[:n].astype(np.int32)
+        rows[:6] = (3, 4, 5, 3, 4, 5)
+        boxes[:3] = ((0, 0, H, W), (10, 5, 60, 70), (2, 3, 50, 40))
+        dets = np.concatenate([boxes, cls[:, None], rows[:, None]], axis=1).astype(np.int32)
+        got = ops.unmold_masks(torch.tensor(mm, device=dev), torch.tensor(dets, device=dev), (H, W), packed=packed)
+        torch.cuda.synchronize()
+        got = got.cpu().numpy()
+        if packed:
+            assert got.shape == (H, W, 13)
+            got = np.unpackbits(got, axis=-1, count=n, bitorder="little")
+        assert got.shape == (H, W, n) and set(np.unique(got)) <= {0, 1}
+        with np.errstate(invalid="ignore"):
+            want = np.stack([utils.unmold_mask(mm[rows[i], :, :, cls[i]], boxes[i], (H, W, 3)) for i in range(n)], axis=-1)
+        assert want[..., 0].all() and not want[..., 1].any() and not want[..., 2].any()      # the clip / NaN cases as intended
+        np.testing.assert_array_equal(got.view(np.bool_), want)
+    # no detections: an empty result, nothing launched
+    e = ops.unmold_masks(torch.tensor(mm, device=dev), torch.zeros((0, 6), dtype=torch.int32, device=dev), (H, W), packed=packed)
+    assert tuple(e.shape) == (H, W, 0)
+
+
 def test_guarded_sgd_skips_non_finite_steps(dev):
     """Mixed-precision form of the optimiser step (mrcnn_sgd_momentum_guarded): bitwise the plain step while the squared
     gradient norm is finite; with an overflowed float16 gradient (inf / NaN in the buffer -> non-finite norm out of
