@@ -6,6 +6,7 @@ PyTorch is used by the callers only as the owner of device memory and of the cur
 """
 import ctypes as C
 import os
+import threading
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libmrcnn_hip.so")
@@ -168,6 +169,8 @@ _SIGNATURES = {
     "mrcnn_allreduce_init": (C.c_int, [C.POINTER(_P), _P, C.c_int, C.c_int]),
     "mrcnn_allreduce_scratch": (C.c_size_t, [C.c_int, C.c_int64, C.c_int]),
     "mrcnn_allreduce_grad": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int, _P, C.c_size_t, _P]),
+    "mrcnn_allreduce_direct_plan": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int, _P, _P, _P, _P]),
+    "mrcnn_allreduce_direct_simulate": (C.c_int, [_P, _P, C.c_size_t, C.c_int, C.c_int64, C.c_int64, _P]),
     "mrcnn_allreduce_destroy": (C.c_int, [_P]),
     "mrcnn_allreduce_last_error": (C.c_char_p, []),
     "mrcnn_tuning_set": (C.c_int, [C.c_char_p, C.c_longlong]),
@@ -177,9 +180,11 @@ _SIGNATURES = {
 _lib = None
 _proxy = None
 _tape = None          # a list while a step is being recorded (engine.step_taped), else None
+_tape_owner = None    # the thread that opened it: calls from any other thread (loaders, another engine) are not part of the step
 
 # entry points that launch nothing (pure queries / process state): never recorded
-_NO_RECORD = ("_workspace", "_supported", "_status_offset", "_version", "mrcnn_allreduce_", "_scratch")
+# (mrcnn_allreduce_grad is appended by its caller, parallel.RcclComm.reduce: the other mrcnn_allreduce_* calls are set-up)
+_NO_RECORD = ("_workspace", "_supported", "_status_offset", "_version", "mrcnn_allreduce_", "_scratch", "_floats")
 
 
 class _LibProxy(object):
@@ -199,22 +204,23 @@ class _LibProxy(object):
             def f(*args, _real=real):
                 rc = _real(*args)
                 t = _tape
-                if t is not None and not rc:    # a refusal (MRCNN_ERR_UNSUPPORTED: the caller falls back) launched nothing
-                    t.append((_real, args))
+                if t is not None and not rc and _tape_owner == threading.get_ident():
+                    t.append((_real, args))     # (a refusal -- MRCNN_ERR_UNSUPPORTED: the caller falls back -- launched nothing)
                 return rc
         setattr(self, name, f)              # next look-up skips __getattr__
         return f
 
 
 def tape_begin():
-    global _tape
-    _tape = []
+    global _tape, _tape_owner
+    assert _tape is None, "a launch tape is already being recorded"
+    _tape, _tape_owner = [], threading.get_ident()
     return _tape
 
 
 def tape_end():
-    global _tape
-    t, _tape = _tape, None
+    global _tape, _tape_owner
+    t, _tape, _tape_owner = _tape, None, None
     return t
 
 

@@ -145,6 +145,89 @@ static inline int64_t direct_chunk(int64_t n, int world) {
     return (chunk + 63) / 64 * 64;                              // 256-byte granules: every chunk starts 16-byte aligned
 }
 
+// The direct form as a PLAN: what rank `me` sends to / receives from peer p in each of the two phases, as offsets and
+// lengths in floats.  Phase 0 (reduce-scatter): send chunk p of my gradients, receive my chunk of p's gradients into scratch
+// slot (p < me ? p : p - 1).  Phase 1 (all-gather): send my summed chunk, receive p's summed chunk in place.  The real
+// exchange, the single-GPU simulation and the host-side plan query all walk this one function, so the pairing of every
+// ncclSend with the matching ncclRecv (equal lengths on both ends, or RCCL hangs / corrupts) is checked without a second GPU.
+struct DirectOp {
+    int64_t send_off, send_len;      // in grads (floats from the buffer's start)
+    int64_t recv_off, recv_len;      // phase 0: in scratch; phase 1: in grads
+};
+
+static inline DirectOp direct_op(int64_t start, int64_t end, int world, int me, int p, int phase) {
+    const int64_t chunk = direct_chunk(end - start, world);
+    int64_t my_off, my_len, off, len;
+    chunk_of(start, end, chunk, me, &my_off, &my_len);
+    chunk_of(start, end, chunk, p, &off, &len);
+    DirectOp o;
+    if (phase == 0) {
+        o.send_off = off; o.send_len = len;
+        o.recv_off = (int64_t)(p < me ? p : p - 1) * chunk; o.recv_len = my_len;
+    } else {
+        o.send_off = my_off; o.send_len = my_len;
+        o.recv_off = off; o.recv_len = len;
+    }
+    return o;
+}
+
+extern "C" int mrcnn_allreduce_direct_plan(int world, int rank, int64_t start, int64_t end, int phase, int64_t* plan,
+                                           int64_t* own_off, int64_t* own_len, int64_t* slot_stride) {
+    if (world < 1 || rank < 0 || rank >= world || start < 0 || end < start || phase < 0 || phase > 1 || !plan) return MRCNN_ERR_ARG;
+    for (int p = 0; p < world; ++p) {
+        DirectOp o = {0, 0, 0, 0};
+        if (p != rank && end > start) o = direct_op(start, end, world, rank, p, phase);
+        plan[p * 4 + 0] = o.send_off; plan[p * 4 + 1] = o.send_len; plan[p * 4 + 2] = o.recv_off; plan[p * 4 + 3] = o.recv_len;
+    }
+    const int64_t chunk = end > start ? direct_chunk(end - start, world) : 0;
+    int64_t o = start, l = 0;
+    if (end > start) chunk_of(start, end, chunk, rank, &o, &l);
+    if (own_off) *own_off = o;
+    if (own_len) *own_len = l;
+    if (slot_stride) *slot_stride = chunk;
+    return MRCNN_OK;
+}
+
+static int launch_sum_chunks(float* own, const float* scratch, int64_t chunk, int64_t my_len, int me, int W, hipStream_t s) {
+    int64_t blocks = (my_len + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(allreduce_sum_chunks_kernel, dim3((unsigned)blocks), dim3(256), 0, s, own, scratch, chunk, my_len, me, W);
+    return mrcnn_launch_status();
+}
+
+// The direct exchange of `world` FABRICATED ranks on one GPU: grads[r] / scratch[r] are rank r's buffers (host arrays of
+// device pointers), every planned send is paired with the receive its peer planned (lengths must agree: a mismatch is the
+// error a real node would turn into a hang) and carried out as a device-to-device copy; the owners' sums run the real
+// kernel.  Test entry: tests/test_dp_gpu.py::test_direct_allreduce_simulated_ranks.
+extern "C" int mrcnn_allreduce_direct_simulate(float* const* grads, float* const* scratch, size_t scratch_bytes, int world,
+                                               int64_t start, int64_t end, void* stream) {
+    if (!grads || !scratch || world < 2 || world > 64 || start < 0 || end < start) return MRCNN_ERR_ARG;
+    if (end == start) return MRCNN_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t chunk = direct_chunk(end - start, world);
+    if (scratch_bytes < (size_t)(world - 1) * (size_t)chunk * sizeof(float)) return MRCNN_ERR_WORKSPACE;
+    for (int phase = 0; phase < 2; ++phase) {
+        for (int a = 0; a < world; ++a)
+            for (int b = 0; b < world; ++b) {
+                if (a == b) continue;
+                const DirectOp sa = direct_op(start, end, world, a, b, phase);        // a's send to b ...
+                const DirectOp rb = direct_op(start, end, world, b, a, phase);        // ... meets b's receive from a
+                if (sa.send_len != rb.recv_len) { set_error("direct plan", "send / receive lengths of a pair differ"); return MRCNN_ERR_LAUNCH; }
+                if (sa.send_len == 0) continue;
+                float* dst = (phase == 0 ? scratch[b] : grads[b]) + rb.recv_off;
+                if (hipMemcpyAsync(dst, grads[a] + sa.send_off, (size_t)sa.send_len * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+                    return MRCNN_ERR_LAUNCH;
+            }
+        if (phase == 0)
+            for (int r = 0; r < world; ++r) {
+                int64_t my_off, my_len;
+                chunk_of(start, end, chunk, r, &my_off, &my_len);
+                if (my_len > 0 && launch_sum_chunks(grads[r] + my_off, scratch[r], chunk, my_len, r, world, s) != MRCNN_OK) return MRCNN_ERR_LAUNCH;
+            }
+    }
+    return MRCNN_OK;
+}
+
 extern "C" size_t mrcnn_allreduce_scratch(int world, int64_t max_range_floats, int algo) {
     if (algo != MRCNN_ALLREDUCE_DIRECT || world <= 1 || max_range_floats <= 0) return 0;
     return (size_t)(world - 1) * (size_t)direct_chunk(max_range_floats, world) * sizeof(float);
@@ -167,39 +250,23 @@ extern "C" int mrcnn_allreduce_grad(void* comm, float* grads, int64_t start, int
     if (!scratch || scratch_bytes < (size_t)(W - 1) * (size_t)chunk * sizeof(float)) return MRCNN_ERR_WORKSPACE;
     int64_t my_off, my_len;
     chunk_of(start, end, chunk, me, &my_off, &my_len);
-    // ---- reduce-scatter: my chunk of every peer arrives here, their chunks of mine leave ----------------------------
-    int rc = check(g_rccl.GroupStart(), "ncclGroupStart");
-    for (int p = 0; p < W && rc == MRCNN_OK; ++p) {
-        if (p == me) continue;
-        int64_t off, len;
-        chunk_of(start, end, chunk, p, &off, &len);
-        if (len > 0) rc = check(g_rccl.Send(grads + off, (size_t)len, ncclFloat, p, c->comm, s), "ncclSend");
-        if (rc == MRCNN_OK && my_len > 0)
-            rc = check(g_rccl.Recv(scratch + (int64_t)(p < me ? p : p - 1) * chunk, (size_t)my_len, ncclFloat, p, c->comm, s), "ncclRecv");
+    for (int phase = 0; phase < 2; ++phase) {
+        // phase 0, reduce-scatter: my chunk of every peer arrives in scratch, their chunks of mine leave;
+        // phase 1, all-gather: the summed chunk goes to every peer, theirs come back in place
+        int rc = check(g_rccl.GroupStart(), "ncclGroupStart");
+        for (int p = 0; p < W && rc == MRCNN_OK; ++p) {
+            if (p == me) continue;
+            const DirectOp o = direct_op(start, end, W, me, p, phase);
+            if (o.send_len > 0) rc = check(g_rccl.Send(grads + o.send_off, (size_t)o.send_len, ncclFloat, p, c->comm, s), "ncclSend");
+            if (rc == MRCNN_OK && o.recv_len > 0)
+                rc = check(g_rccl.Recv((phase == 0 ? scratch : grads) + o.recv_off, (size_t)o.recv_len, ncclFloat, p, c->comm, s), "ncclRecv");
+        }
+        {
+            const int rc2 = check(g_rccl.GroupEnd(), "ncclGroupEnd");
+            if (rc == MRCNN_OK) rc = rc2;
+        }
+        if (rc != MRCNN_OK) return rc;
+        if (phase == 0 && my_len > 0 && launch_sum_chunks(grads + my_off, scratch, chunk, my_len, me, W, s) != MRCNN_OK) return MRCNN_ERR_LAUNCH;
     }
-    {
-        const int rc2 = check(g_rccl.GroupEnd(), "ncclGroupEnd");
-        if (rc == MRCNN_OK) rc = rc2;
-    }
-    if (rc != MRCNN_OK) return rc;
-    if (my_len > 0) {
-        int64_t blocks = (my_len + 255) / 256;
-        if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(allreduce_sum_chunks_kernel, dim3((unsigned)blocks), dim3(256), 0, s, grads + my_off, scratch, chunk, my_len, me, W);
-        if (mrcnn_launch_status() != MRCNN_OK) return MRCNN_ERR_LAUNCH;
-    }
-    // ---- all-gather: the summed chunk goes to every peer, theirs come back in place --------------------------------------
-    rc = check(g_rccl.GroupStart(), "ncclGroupStart");
-    for (int p = 0; p < W && rc == MRCNN_OK; ++p) {
-        if (p == me) continue;
-        int64_t off, len;
-        chunk_of(start, end, chunk, p, &off, &len);
-        if (my_len > 0) rc = check(g_rccl.Send(grads + my_off, (size_t)my_len, ncclFloat, p, c->comm, s), "ncclSend");
-        if (rc == MRCNN_OK && len > 0) rc = check(g_rccl.Recv(grads + off, (size_t)len, ncclFloat, p, c->comm, s), "ncclRecv");
-    }
-    {
-        const int rc2 = check(g_rccl.GroupEnd(), "ncclGroupEnd");
-        if (rc == MRCNN_OK) rc = rc2;
-    }
-    return rc;
+    return MRCNN_OK;
 }

@@ -449,11 +449,10 @@ extern "C" int mrcnn_proposal_fwd(const mrcnn_proposal_desc* d, const float* rpn
         const int chunk = (d->A + a.pre_groups - 1) / a.pre_groups;
         const dim3 grid(a.pre_groups, d->B);
         const int nz = d->B * PRE_WORDS;            // a kernel, not a memset node: the call may be inside a graph capture
-        // MRCNN_PROPOSAL_SKIP_ZERO=1 (tests only) leaves the previous call's counters in place: the fault-injection
-        // twin of "the reset did not happen", which the guards above must survive with the exact result
-        const char* sz = getenv("MRCNN_PROPOSAL_SKIP_ZERO");      // read per call: the test flips it between two calls
-        const bool skip_zero = sz && sz[0] == '1';
-        if (!skip_zero)
+        // mrcnn_tuning_set("proposal_skip_zero", 1) (tests only; explicit process state, not an environment variable a
+        // production run could inherit) leaves the previous call's counters in place: the fault-injection twin of "the reset
+        // did not happen", which the guards above must survive with the exact result
+        if (!g_mrcnn_proposal_skip_zero)
             hipLaunchKernelGGL(topk_zero_kernel, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, s, a.pre_ws, nz);
         for (int pass = 0; pass < 3; ++pass) hipLaunchKernelGGL(topk_hist_kernel, grid, dim3(PRE_THREADS), 0, s, a, pass);
         hipLaunchKernelGGL(topk_ties_kernel, grid, dim3(PRE_THREADS), 0, s, a, chunk);

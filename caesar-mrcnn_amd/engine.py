@@ -1518,24 +1518,34 @@ class MaskRCNNEngine(object):
         self.wt_valid = self._h16_valid = False
         return losses
 
-    def step_taped(self, dev_inputs, learning_rate, momentum):
+    def step_taped(self, dev_inputs, learning_rate, momentum, world_size=1, reducer=None):
         """forward_backward + apply_gradients (single rank) from a recorded launch tape (_hip.tape_*): the first call per
         input signature / rates / mode runs the step through the engine while every launch -- C-ABI calls with their
         descriptors and pointers, event records / waits between the three streams -- is written down; later calls copy the
         inputs into the recording's buffers and issue the same calls again.  Same launches on the same streams in the same
         order as the eager step (so, unlike the HIP-graph replay, the same overlap), without the engine's Python per launch.
-        Valid because the step arena, the workspaces and the weight images have stable addresses."""
+        Valid because the step arena, the workspaces and the weight images have stable addresses.
+        Data parallelism (`reducer`: parallel.GradReducer, self.grad_ready = reducer.ready): the gradient hooks are part of the
+        recording -- event hand-offs to the exchange stream, the mrcnn_allreduce_grad calls and the final join -- so a
+        data-parallel step is re-issued like a single-rank one.  The settle pass runs WITHOUT the hooks (local, rolled
+        back): every call of this function then enters exactly one set of collectives whether it records or replays, so ranks
+        that record in different steps cannot desynchronise."""
         key = (tuple((tuple(t.shape), t.dtype) for t in dev_inputs), float(learning_rate), float(momentum), self.head_dtype,
-               id(self.cfg), torch.cuda.current_stream(self.dev).cuda_stream, self._mode_key())
+               id(self.cfg), torch.cuda.current_stream(self.dev).cuda_stream, self._mode_key(), int(world_size),
+               None if reducer is None else id(reducer))
         entry = self._train_tapes.get(key)
         if entry is None:
-            assert self.grad_ready is None, "the launch tape is single-rank: gradient hooks are not recorded"
+            assert (self.grad_ready is None) == (reducer is None), "gradient hooks are recorded through their GradReducer"
             static = [torch.empty_like(t) for t in dev_inputs]
             for s_, t in zip(static, dev_inputs):
                 s_.copy_(t)
             # one eager step settles arena slots, workspaces and weight images (rolled back: it is not a training step)
             keep = (self.params.clone(), self.momentum.clone(), self.skipped_steps.clone())
-            self.forward_backward(*static)
+            hook, self.grad_ready = self.grad_ready, None
+            try:
+                self.forward_backward(*static)
+            finally:
+                self.grad_ready = hook
             self.apply_gradients(learning_rate, momentum, 1)
             self.params.copy_(keep[0])
             self.momentum.copy_(keep[1])
@@ -1546,12 +1556,14 @@ class MaskRCNNEngine(object):
             _hip_mod.tape_begin()
             try:
                 losses = self.forward_backward(*static)
-                self.apply_gradients(learning_rate, momentum, 1)
+                if reducer is not None:
+                    reducer.finish()
+                self.apply_gradients(learning_rate, momentum, world_size)
             finally:
                 tape = _hip_mod.tape_end()
             # the recorded pointers are arena slots and workspaces: hold them, so a later step of another shape or mode
             # (which replaces slots) cannot hand their memory to someone else while this tape is alive
-            self._train_tapes[key] = (tape, static, losses, list(self.arena.slots), list(ops._ws_cache.values()))
+            self._train_tapes[key] = (tape, static, losses, list(self.arena.slots), list(ops._ws_cache.values()), reducer)
             return losses                                   # the recording pass was this step
         tape, static, losses = entry[:3]
         for s_, t in zip(static, dev_inputs):

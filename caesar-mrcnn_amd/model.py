@@ -244,11 +244,13 @@ class MaskRCNN(object):
         eng.grad_ready = reducer.ready if reducer is not None else None
         if apply and reducer is None and world_size == 1 and not keep_outputs and getattr(self.config, "TRAIN_HIP_GRAPH", False):
             return eng.step_graphed(dev_inputs, self._lr, self._momentum)      # the whole step replayed from one HIP graph
-        if apply and reducer is None and world_size == 1 and not keep_outputs and getattr(self.config, "TRAIN_LAUNCH_TAPE", False):
+        if apply and not keep_outputs and getattr(self.config, "TRAIN_LAUNCH_TAPE", False) and \
+                ((reducer is None and world_size == 1) or (reducer is not None and not reducer.timing)):
             # the same launches on the same streams, re-issued from a recording without the engine's Python per launch: the device
             # time is unchanged, the main thread holds the interpreter lock for a fraction of the time -- which the loader threads
-            # of MaskRCNN.train() need (feed-inclusive loop)
-            return eng.step_taped(dev_inputs, self._lr, self._momentum)
+            # of MaskRCNN.train() need (feed-inclusive loop).  Under data parallelism the gradient hooks (hand-off
+            # events, mrcnn_allreduce_grad, the join) are part of the recording.
+            return eng.step_taped(dev_inputs, self._lr, self._momentum, world_size, reducer)
         losses = eng.forward_backward(*dev_inputs, keep_outputs=keep_outputs)
         if reducer is not None:
             reducer.finish()

@@ -74,11 +74,36 @@ class RcclComm(object):
 
     def reduce(self, flat, start, end, algo, scratch, stream):
         from . import _hip
-        rc = self.lib.mrcnn_allreduce_grad(self.handle, flat.data_ptr(), start, end, algo,
-                                           scratch.data_ptr() if scratch is not None else None,
-                                           scratch.numel() * 4 if scratch is not None else 0, stream)
+        fn = self.lib.mrcnn_allreduce_grad
+        args = (self.handle, flat.data_ptr(), start, end, algo, scratch.data_ptr() if scratch is not None else None,
+                scratch.numel() * 4 if scratch is not None else 0, stream)
+        rc = fn(*args)
         if rc != 0:
             raise _hip.HipPathError("mrcnn_allreduce_grad failed (%d): %s" % (rc, self.lib.mrcnn_allreduce_last_error().decode()))
+        if _hip._tape is not None:          # part of a recorded step (engine.step_taped): re-issued with the step's launches
+            _hip._tape.append((fn, args))
+
+    def self_test(self, device, algo, scratch, stream):
+        """Collective, once per communicator: a range whose sum over ranks is known in closed form (integer-valued floats, so
+        every summation order gives the same bits) goes through exactly the call the training step will make; any rank that
+        does not see the expected sum raises.  The first multi-GPU run of a transport is then also its first check."""
+        from . import _hip
+        n = 64 * self.world * 5 + 37                        # not a multiple of 64 * world: short last chunk
+        base = torch.arange(n, dtype=torch.float32, device=device) % 251.0
+        buf = torch.zeros(n + 128, dtype=torch.float32, device=device)
+        buf[64:64 + n] = base * float(self.rank + 1)
+        s = torch.cuda.Stream(device=device) if stream is None else stream
+        s.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(s):
+            self.reduce(buf, 64, 64 + n, algo, scratch, s.cuda_stream)
+        torch.cuda.current_stream(device).wait_stream(s)
+        want = base * float(self.world * (self.world + 1) // 2)
+        ok = bool(torch.equal(buf[64:64 + n], want)) and float(buf[:64].abs().sum()) == 0.0 and float(buf[64 + n:].abs().sum()) == 0.0
+        if not ok:
+            bad = int((buf[64:64 + n] != want).sum())
+            raise _hip.HipPathError("gradient exchange self-test failed on rank %d of %d (algo %d): %d of %d elements differ from "
+                                    "the expected sum -- refusing to train on a broken transport; MRCNN_ALLREDUCE=torch selects "
+                                    "torch.distributed's all_reduce" % (self.rank, self.world, algo, bad, n))
 
     def close(self):
         if self.handle:
@@ -92,40 +117,47 @@ class GradReducer(object):
     ``timing=True`` brackets every exchange with HIP events on the exchange stream: ``pop_timing()`` then returns the
     milliseconds the exchanges of the finished steps took there and the bytes they moved (bench.py, N > 1)."""
 
-    def __init__(self, flat_grads, world_size, rank=None, mode=None, timing=False, max_mb=None):
+    def __init__(self, flat_grads, world_size, rank=None, mode=None, timing=False, max_mb=None, force=False):
+        """force: build the transport even for a world of one rank (the sum is then the identity; tests run the whole path --
+        hooks, side stream, C-ABI call, launch tape -- on the single GPU of this pool)."""
         self.g = flat_grads
         self.world = world_size
         self.cuda = flat_grads.is_cuda
-        self.stream = torch.cuda.Stream(device=flat_grads.device) if (self.cuda and world_size > 1) else None
+        self.active = world_size > 1 or bool(force)
+        self.stream = torch.cuda.Stream(device=flat_grads.device) if (self.cuda and self.active) else None
         self.pending = []
         self.timing = timing
         self._events, self.bytes_moved, self.range_log = [], 0, []
         mode = mode or os.environ.get("MRCNN_ALLREDUCE") or ("rccl" if self.cuda else "torch")
         if dist.is_initialized() and dist.get_backend() == "gloo":
             mode = "torch"                                  # ranks sharing one GPU (rehearsals) cannot form an RCCL communicator
-        self.mode = mode if world_size > 1 else "none"
+        self.mode = mode if self.active else "none"
         mb = max_mb if max_mb is not None else os.environ.get("MRCNN_ALLREDUCE_MAX_MB")
         self.max_floats = int(float(mb) * (1 << 20) / 4) if mb else None
         self.comm = self.scratch = None
         if self.mode in ("rccl", "direct"):
-            rank = dist.get_rank() if rank is None else rank
+            rank = (dist.get_rank() if dist.is_initialized() else 0) if rank is None else rank
             self.comm = RcclComm(rank, world_size, flat_grads.device)
             self.algo = 1 if self.mode == "direct" else 0
             if self.algo == 1:
                 longest = self.max_floats or flat_grads.numel()
                 nbytes = self.comm.lib.mrcnn_allreduce_scratch(world_size, min(longest, flat_grads.numel()), 1)
                 self.scratch = torch.empty(max(nbytes // 4, 64), dtype=torch.float32, device=flat_grads.device)
+            # neither form has run on more than one GPU of this pool: the first thing a communicator does is prove itself
+            self.comm.self_test(flat_grads.device, self.algo, self.scratch, self.stream)
 
     def ready(self, start, end):
-        """Called by the engine when grads[start:end] are final."""
-        if self.world <= 1 or end <= start:
+        """Called by the engine when grads[start:end] are final.  Stream hand-offs go through _hip.ev_record / ev_wait and the
+        exchange calls append themselves to an open launch tape, so a recorded step (engine.step_taped) re-issues the
+        exchange with the rest of its launches."""
+        from . import _hip
+        if not self.active or end <= start:
             return
         pieces = split_range(start, end, self.max_floats)
         if self.stream is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.g.device))
+            ev = _hip.ev_record(torch.cuda.current_stream(self.g.device))
             with torch.cuda.stream(self.stream):
-                self.stream.wait_event(ev)
+                _hip.ev_wait(self.stream, ev)
                 if self.timing:
                     e0 = torch.cuda.Event(enable_timing=True)
                     e0.record(self.stream)
@@ -138,22 +170,39 @@ class GradReducer(object):
         else:
             for a, b in pieces:
                 self._one(a, b)
-        self.bytes_moved += (end - start) * 4
-        self.range_log.append((end - start) * 4)
+        if self.timing:                                     # only a caller that drains it (pop_timing) makes it grow
+            self.bytes_moved += (end - start) * 4
+            self.range_log.append((end - start) * 4)
 
-    def _one(self, a, b):
-        if self.comm is not None:
-            self.comm.reduce(self.g, a, b, self.algo, self.scratch, self.stream.cuda_stream)
+    def _torch_allreduce(self, a, b):
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                self.pending.append(dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, async_op=True))
         else:
             self.pending.append(dist.all_reduce(self.g[a:b], op=dist.ReduceOp.SUM, async_op=True))
 
-    def finish(self):
-        """Make the compute stream wait for every outstanding reduction."""
+    def _one(self, a, b):
+        from . import _hip
+        if self.comm is not None:
+            self.comm.reduce(self.g, a, b, self.algo, self.scratch, self.stream.cuda_stream)
+        elif self.world > 1:
+            self._torch_allreduce(a, b)
+            if _hip._tape is not None:
+                _hip._tape.append((self._torch_allreduce, (a, b)))
+
+    def _finish_pending(self):
         for w in self.pending:
             w.wait()
         self.pending = []
+
+    def finish(self):
+        """Make the compute stream wait for every outstanding reduction."""
+        from . import _hip
+        self._finish_pending()
+        if _hip._tape is not None and self.comm is None and self.world > 1:
+            _hip._tape.append((self._finish_pending, ()))
         if self.stream is not None:
-            torch.cuda.current_stream(self.g.device).wait_stream(self.stream)
+            _hip.stream_wait(torch.cuda.current_stream(self.g.device), self.stream)
 
     def pop_timing(self):
         """(ms on the exchange stream, bytes reduced, per-range byte sizes of the last step) since the last call;

@@ -268,8 +268,8 @@ def compute_matches(gt_boxes, gt_class_ids, gt_masks, pred_boxes, pred_class_ids
                     iou_threshold=0.5, score_threshold=0.0):
     """Greedy one-to-one matching of predictions (best score first) to ground truth by MASK IoU
     (mrcnn/utils.py:725-785).  A prediction takes the unmatched GT instance of highest IoU -- candidates are walked
-    in descending IoU, the walk ends at the first IoU below the threshold -- provided the class ids agree; a class
-    mismatch ends that prediction's search.  Returns (gt_match [G], pred_match [N] as float arrays of indices or -1
+    in descending IoU, the walk ends at the first IoU below the threshold -- provided the class ids agree; on a class
+    mismatch the walk goes on to the next ground-truth instance (as the reference does).  Returns (gt_match [G], pred_match [N] as float arrays of indices or -1
     in score order, overlaps [N, G])."""
     keep_g = np.any(gt_boxes != 0, axis=1)
     n_gt = int(keep_g.sum())

@@ -484,12 +484,24 @@ int mrcnn_allreduce_init(void** comm, const void* id_128_bytes, int rank, int wo
 size_t mrcnn_allreduce_scratch(int world, int64_t max_range_floats, int algo);
 int mrcnn_allreduce_grad(void* comm, float* grads, int64_t start, int64_t end, int algo, float* scratch,
                          size_t scratch_bytes, void* stream);
+/* The direct form as data (no GPU, no RCCL needed): plan[p*4 .. p*4+3] = (send_off, send_len, recv_off, recv_len) of `rank`'s
+ * transfer with peer p in phase 0 (reduce-scatter: sends index the gradient buffer, receives the scratch buffer) or phase 1
+ * (all-gather: both index the gradient buffer); zeros for p == rank.  own_off / own_len: the chunk `rank` sums, slot_stride:
+ * floats between scratch slots.  mrcnn_allreduce_grad walks the same function.                                            */
+int mrcnn_allreduce_direct_plan(int world, int rank, int64_t start, int64_t end, int phase, int64_t* plan, int64_t* own_off,
+                                int64_t* own_len, int64_t* slot_stride);
+/* Test entry: the direct exchange among `world` fabricated ranks that all live on the calling GPU (grads[r], scratch[r]:
+ * host arrays of device pointers); transfers become device-to-device copies after the send / receive lengths of every pair
+ * have been checked against each other, the sums run the real kernel.  2 <= world <= 64.                                 */
+int mrcnn_allreduce_direct_simulate(float* const* grads, float* const* scratch, size_t scratch_bytes, int world, int64_t start,
+                                    int64_t end, void* stream);
 int mrcnn_allreduce_destroy(void* comm);
 const char* mrcnn_allreduce_last_error(void);
 
 /* Process-wide tuning values, read by the host side of later launches.  Keys: "wgrad_lds_pad" (0..32768 bytes of extra
  * LDS per workgroup of the large weight-gradient kernel: 8192 caps it at four workgroups per CU so that kernels of another
- * stream find a free slot on every CU).  MRCNN_ERR_UNSUPPORTED for an unknown key.                                  */
+ * stream find a free slot on every CU); "h16_phase" (0 / 1); "proposal_skip_zero" (tests only, fault injection: 1 suppresses
+ * the counter reset of mrcnn_proposal_fwd's multi-workgroup selection).  MRCNN_ERR_UNSUPPORTED for an unknown key.   */
 int mrcnn_tuning_set(const char* key, long long value);
 
 const char* mrcnn_hip_version(void);

@@ -98,3 +98,72 @@ def test_rccl_cabi_single_rank(dev):
     red.ready(0, 100)
     red.finish()
     assert red.mode == "none" and red.comm is None
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_direct_allreduce_simulated_ranks(dev, world):
+    """The LOCAL half of the direct reduce-scatter + all-gather (chunk_of / direct_chunk / the scratch-slot indexing and
+    allreduce_sum_chunks_kernel of csrc/allreduce.hip) with fabricated peers: `world` gradient buffers on the one GPU,
+    mrcnn_allreduce_direct_simulate pairs every planned send with the receive its peer planned (equal lengths or it
+    fails), moves the chunks with device copies and sums them with the real kernel.  Every "rank" must end with the
+    rank-ordered float32 sum, bit for bit, and untouched floats outside the range -- for ranges that are not multiples of
+    64 * world, ranges with empty trailing chunks and a one-float range."""
+    import ctypes as C
+    from caesar_mrcnn_amd import _hip
+    L = _hip.lib()
+    total = 70000
+    gen = torch.Generator(device="cpu").manual_seed(world)
+    for start, end in ((0, total), (64, 64 + 64 * world * 7), (128, 128 + 6411), (5, 6), (9, 9 + world - 1), (192, 192 + 64 * world + 1)):
+        grads = [torch.randn(total, generator=gen).to(dev) for _ in range(world)]
+        before = [g.clone() for g in grads]
+        want = before[0][start:end].clone()
+        for r in range(1, world):
+            want = want + before[r][start:end]
+        nbytes = L.mrcnn_allreduce_scratch(world, end - start, 1)
+        scratch = [torch.full((max(nbytes // 4, 1),), float("nan"), device=dev) for _ in range(world)]
+        gp = (C.c_void_p * world)(*[g.data_ptr() for g in grads])
+        sp = (C.c_void_p * world)(*[t.data_ptr() for t in scratch])
+        rc = L.mrcnn_allreduce_direct_simulate(gp, sp, nbytes, world, start, end, _hip.current_stream())
+        assert rc == 0, L.mrcnn_allreduce_last_error()
+        torch.cuda.synchronize()
+        for r in range(world):
+            assert torch.equal(grads[r][start:end], want), (world, start, end, r)
+            assert torch.equal(grads[r][:start], before[r][:start]) and torch.equal(grads[r][end:], before[r][end:])
+    assert L.mrcnn_allreduce_direct_simulate(gp, sp, 0, world, 0, total, _hip.current_stream()) == -3      # scratch too small
+
+
+def test_taped_data_parallel_step_equals_eager(dev):
+    """The gradient hooks are part of the launch tape (round 2 switched the tape off under data parallelism): a
+    GradReducer over a one-rank RCCL communicator (force=True: the sum is the identity, the path is the real one --
+    hand-off events, exchange stream, mrcnn_allreduce_grad through the C-ABI, the join) drives three taped steps; they
+    must equal three eager steps with the same reducer, the recording must hold one exchange call per gradient range and
+    the communicator's start-up self-test must have passed."""
+    import test_engine_gpu as T
+    from caesar_mrcnn_amd import _hip
+    from caesar_mrcnn_amd.model import MaskRCNN
+    from caesar_mrcnn_amd.parallel import GradReducer
+    cfg = T._small_cfg("custom", 128)
+    w = T._weights(cfg, 23)
+    batches = [T._train_inputs(cfg, 2, 31), T._train_inputs(cfg, 2, 33)]
+    out = {}
+    for taped in (False, True):
+        cfg.TRAIN_LAUNCH_TAPE = taped
+        model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+        model.compile(0.01, 0.9)
+        red = GradReducer(model.engine.grads, 1, rank=0, mode="rccl", force=True)
+        assert red.mode == "rccl" and red.comm is not None
+        losses = []
+        for s in range(3):
+            inputs, keys = batches[s % 2]
+            losses.append(model.train_on_batch(inputs, rand_keys=keys, reducer=red, world_size=1).cpu().numpy().copy())
+        torch.cuda.synchronize()
+        out[taped] = (np.stack(losses), model.engine.params.cpu().numpy().copy())
+        if taped:
+            assert len(model.engine._train_tapes) == 1
+            tape = list(model.engine._train_tapes.values())[0][0]
+            real = _hip.lib().mrcnn_allreduce_grad
+            n_exchange = sum(1 for f, a in tape if f is real)
+            assert n_exchange == len(model.engine.grad_ranges), (n_exchange, len(model.engine.grad_ranges))
+        red.close()
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=2e-4, atol=1e-5)
+    assert np.abs(out[True][1] - out[False][1]).max() <= 2e-4 * np.abs(out[False][1]).max()

@@ -289,6 +289,52 @@ def test_frozen_layers_and_heads_preset(dev):
         assert changed[off:off + n].any() == bool(t) or (t and n < 8), name
 
 
+def test_taped_steps_follow_set_trainable(dev):
+    """A second train(..., layers=...) on the same model at the same rates replays the launch tape recorded under the first
+    trainable mask (engine.step_taped).  The recorded grad_prepare / sgd_momentum calls carry the ADDRESS of the per-granule
+    trainable / weight-decay coefficients, so set_trainable must refresh that buffer in place (round 2 re-allocated it: the
+    replay then read freed memory).  'heads' for two steps, then 'all' for two steps, taped against eager: frozen layers stay
+    bit-identical in phase 1 and move in phase 2 in both runs, final parameters agree, ONE tape serves both phases."""
+    from caesar_mrcnn_amd.model import MaskRCNN
+    cfg = _small_cfg("custom", 128)
+    w = _weights(cfg, 17)
+    batches = [_train_inputs(cfg, 2, 9), _train_inputs(cfg, 2, 13)]
+    snaps = {}
+    for taped in (False, True):
+        model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
+        eng = model.engine
+        model.compile(0.01, 0.9)
+        start = eng.params.clone()
+        coef_ptr = None
+        for layers in ("heads", "all"):
+            model.set_trainable(layers, verbose=0)
+            assert coef_ptr in (None, eng.gran_coef.data_ptr())          # same buffer, new contents
+            coef_ptr = eng.gran_coef.data_ptr()
+            for s in range(2):
+                di = model._to_device(*batches[s])
+                if taped:
+                    eng.step_taped(di, 0.01, 0.9)
+                else:
+                    eng.forward_backward(*di)
+                    eng.apply_gradients(0.01, 0.9, 1)
+            torch.cuda.synchronize()
+            snaps[(taped, layers)] = eng.params.cpu().numpy().copy()
+        if taped:
+            assert len(eng._train_tapes) == 1
+    start = start.cpu().numpy()
+    model.set_trainable("heads", verbose=0)
+    heads_mask = list(model.engine.trainable_host)
+    for taped in (False, True):
+        a, b = snaps[(taped, "heads")], snaps[(taped, "all")]
+        for (name, off, n, _, _), t in zip(model.engine.layout.segments, heads_mask):
+            if not t:
+                assert np.array_equal(a[off:off + n], start[off:off + n]), (taped, name)       # frozen in phase 1
+                assert n < 8 or not np.array_equal(b[off:off + n], start[off:off + n]), (taped, name)   # trained in phase 2
+    for layers in ("heads", "all"):
+        ref, got = snaps[(False, layers)], snaps[(True, layers)]
+        assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max(), layers
+
+
 def test_sparse_mask_backward_equals_dense(dev):
     """Running the mask head (forward and backward) on the positive quota only changes neither the losses
     nor the gradients: the skipped rows are never read by the loss and carry exactly-zero gradient."""
@@ -683,14 +729,19 @@ def test_graphed_training_steps_equal_eager(dev, head_dtype, how):
         if graphed:
             assert len(eng._train_graphs if how == "graph" else eng._train_tapes) == 1
     # float32: the first two steps see (almost) identical weights: tight; afterwards the atomics-order noise of the updates has
-    # been through the network again.  16-bit: same ROI sets in both runs (see above), so the losses agree to 2e-3 on the
-    # first two steps (measured: 2e-4) and to 5e-3 on steps 3-4 (measured 2.3e-3 on the box loss: a float32 weight that
-    # differs in its last bit after an update can round to the neighbouring float16 value, 2^13 times that), the momentum
-    # history to 1e-2 in relative L2 (round 2: 0.15 / 0.5 with free-running proposals).
+    # been through the network again.  16-bit: same ROI sets in both runs (see above).  What is left is the mode's own
+    # run-to-run noise, measured with tools/replay_noise_probe.py (profiles/r03_replay_noise_f16.txt: eager against EAGER, and
+    # against tape / graph) and tools/replay_noise_probe2.py (profiles/r03_gradient_noise_by_dtype.txt): two evaluations of one
+    # float16 gradient on identical weights differ by 4-8e-5 in relative L2 (float32: 5e-8) -- the order noise of the float
+    # atomics moves a few float32 sums across a float16 rounding boundary and every later rounding amplifies that; one update
+    # later the gradients of two eager runs are 1-2 % apart, after four steps 2-4 %, the losses 2e-4 / 5e-4 / 8e-4 / 4e-3.
+    # The bars are twice that floor (round 2: loss rtol 0.15, momentum 0.5 with free-running proposals); the exactness of the
+    # replay itself is the float32 case's business.
     if head_dtype:
-        np.testing.assert_allclose(out[True][0][:2], out[False][0][:2], rtol=2e-3, atol=1e-5)
-        np.testing.assert_allclose(out[True][0], out[False][0], rtol=5e-3, atol=1e-5)
-        for k, t in ((1, 1e-4), (2, 1e-2)):
+        np.testing.assert_allclose(out[True][0][:1], out[False][0][:1], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(out[True][0][:3], out[False][0][:3], rtol=2e-3, atol=1e-5)
+        np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-2, atol=1e-5)
+        for k, t in ((1, 1e-5), (2, 6e-2)):
             assert np.linalg.norm(out[True][k] - out[False][k]) <= t * np.linalg.norm(out[False][k]), k
     else:
         tol = 2e-4

@@ -334,13 +334,26 @@ assert torch.equal(g, torch.arange(1000, dtype=torch.float32) * 3), g[:5]
 assert red.mode == "torch"
 # ranges cut into <= 256-float messages (MRCNN_ALLREDUCE_MAX_MB): same sums, more, smaller exchanges
 g2 = torch.arange(1000, dtype=torch.float32) * (rank + 1)
-red2 = GradReducer(g2, world, max_mb=256 * 4 / 2 ** 20)
+red2 = GradReducer(g2, world, max_mb=256 * 4 / 2 ** 20, timing=True)     # the byte log is only kept for a caller that drains it
 for lo, hi in ((600, 1000), (200, 600), (0, 200)):
     red2.ready(lo, hi)
 assert len(red2.pending) == 2 + 2 + 1
 red2.finish()
 assert torch.equal(g2, torch.arange(1000, dtype=torch.float32) * 3)
 assert red2.range_log == [1600, 1600, 800] and red2.bytes_moved == 4000
+assert red.range_log == [] and red.bytes_moved == 0
+# a recorded step replays its exchange: the launch tape holds the reducer's calls (gloo: the torch transport's)
+from caesar_mrcnn_amd import _hip
+g3 = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+red3 = GradReducer(g3, world)
+_hip._tape, _hip._tape_owner = [], __import__("threading").get_ident()
+red3.ready(0, 1000)
+red3.finish()
+tape = _hip.tape_end()
+assert torch.equal(g3, torch.arange(1000, dtype=torch.float32) * 3) and len(tape) == 2
+g3.copy_(torch.arange(1000, dtype=torch.float32) * (rank + 1))
+_hip.tape_replay(tape)
+assert torch.equal(g3, torch.arange(1000, dtype=torch.float32) * 3) and red3.pending == []
 l = allreduce_mean_scalars(torch.full((5,), float(rank)), world)
 assert torch.allclose(l, torch.full((5,), 0.5))
 dist.barrier(); dist.destroy_process_group()
@@ -354,6 +367,76 @@ def test_split_range():
     assert split_range(64, 1000, 5000) == [(64, 1000)]
     assert split_range(0, 1000, 300) == [(0, 256), (256, 512), (512, 768), (768, 1000)]     # pieces are granule multiples
     assert split_range(128, 256, 10) == [(128, 192), (192, 256)]
+
+
+@pytest.mark.parametrize("world", [2, 3, 5, 8])
+def test_direct_allreduce_plan_indexing(world):
+    """The direct reduce-scatter + all-gather (csrc/allreduce.hip) as data: mrcnn_allreduce_direct_plan returns, for a rank
+    and a phase, what it sends to / receives from every peer -- the function mrcnn_allreduce_grad itself walks.  Executed
+    here in NumPy for every rank of the world: each ncclSend meets a receive of the same length on the other side (a
+    mismatch hangs a real node), scratch slots stay inside mrcnn_allreduce_scratch() and never overlap, and every rank ends
+    with the rank-ordered float32 sum, bit for bit.  Ranges that are not multiples of 64 * world, ranges shorter than the
+    world (empty trailing chunks), a range of one float, an offset start."""
+    import ctypes as C
+    from caesar_mrcnn_amd import _hip
+    L = _hip.lib()
+    rng = np.random.default_rng(world)
+    total = 5000
+    for start, end in ((0, total), (64, 64 + 64 * world * 3), (128, 128 + 641), (0, 1), (7, 7 + world - 1), (100, 163), (3, 3 + 64 * world + 1)):
+        n = end - start
+        nbytes = L.mrcnn_allreduce_scratch(world, n, 1)
+        grads = [rng.standard_normal(total).astype(np.float32) for _ in range(world)]
+        before = [g.copy() for g in grads]
+        want = before[0][start:end].copy()
+        for r in range(1, world):
+            want = want + before[r][start:end]                                  # rank order, float32
+        scratch = [np.full(nbytes // 4, np.nan, np.float32) for _ in range(world)]
+
+        def plan(rank, phase):
+            buf = (C.c_int64 * (4 * world))()
+            o, l, st = C.c_int64(), C.c_int64(), C.c_int64()
+            assert L.mrcnn_allreduce_direct_plan(world, rank, start, end, phase, buf, C.byref(o), C.byref(l), C.byref(st)) == 0
+            return np.array(buf[:], np.int64).reshape(world, 4), o.value, l.value, st.value
+        for phase in (0, 1):
+            plans = [plan(r, phase) for r in range(world)]
+            staged = []
+            for a in range(world):
+                pa, own_off, own_len, stride = plans[a]
+                assert pa[a].tolist() == [0, 0, 0, 0]
+                assert start <= own_off <= end and own_off + own_len <= end
+                assert stride % 64 == 0 and stride * world >= n
+                slots = []
+                for b in range(world):
+                    if a == b:
+                        continue
+                    so, sl, _, _ = pa[b]
+                    _, _, ro, rl = plans[b][0][a]
+                    assert sl == rl, (world, start, end, phase, a, b)           # the pair agrees on the length
+                    assert start <= so and so + sl <= end
+                    if phase == 0:
+                        assert ro + rl <= nbytes // 4
+                    else:
+                        assert start <= ro and ro + rl <= end
+                    staged.append((b, phase, ro, grads[a][so:so + sl].copy()))
+                    if phase == 0 and pa[b][3]:
+                        slots.append((pa[b][2], pa[b][2] + pa[b][3]))
+                slots.sort()
+                assert all(x[1] <= y[0] for x, y in zip(slots, slots[1:]))      # my scratch slots do not overlap
+            for b, ph, ro, data in staged:                                      # all transfers of a group land together
+                (scratch[b] if ph == 0 else grads[b])[ro:ro + data.size] = data
+            if phase == 0:
+                for r in range(world):
+                    _, own_off, own_len, stride = plans[r]
+                    acc = None
+                    for q in range(world):                                      # allreduce_sum_chunks_kernel's order
+                        v = grads[r][own_off:own_off + own_len] if q == r else \
+                            scratch[r][(q if q < r else q - 1) * stride:(q if q < r else q - 1) * stride + own_len]
+                        acc = v.copy() if acc is None else acc + v
+                    grads[r][own_off:own_off + own_len] = acc
+        for r in range(world):
+            assert np.array_equal(grads[r][start:end], want), (world, start, end, r)
+            assert np.array_equal(grads[r][:start], before[r][:start]) and np.array_equal(grads[r][end:], before[r][end:])
+    assert L.mrcnn_allreduce_direct_plan(world, world, 0, 10, 0, (C.c_int64 * (4 * world))(), None, None, None) != 0
 
 
 def test_grad_reducer_gloo_world2(tmp_path):

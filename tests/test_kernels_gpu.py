@@ -556,7 +556,7 @@ def test_proposal_nms_at_exact_threshold_pairs(dev):
 
 def test_proposal_selection_survives_stale_counters(dev):
     """Fault injection for the multi-workgroup top-k (A >= 32 768): the second call runs with the reset of its
-    histograms / counters suppressed (MRCNN_PROPOSAL_SKIP_ZERO=1), i.e. with the state a missing reset would leave.
+    histograms / counters suppressed (mrcnn_tuning_set("proposal_skip_zero", 1)), i.e. with the state a missing reset would leave.
     The slot taken from the global counter is bounds-guarded (nothing is written outside the candidate array, refused
     stores are counted) and the sort kernel, seeing collected != announced, selects for itself: same indices as the
     healthy call.  Regression for the 1024x1024 graph-replay memory fault of round 1."""
@@ -574,7 +574,7 @@ def test_proposal_selection_survives_stale_counters(dev):
     good = [t.cpu().numpy().copy() for t in ops.proposals(*args, debug=True)]
     st = ops.proposal_status(probs, limit, count)
     assert (st[:, 0] == limit).all() and (st[:, 1] == limit).all() and (st[:, 2] == 0).all(), st
-    os.environ["MRCNN_PROPOSAL_SKIP_ZERO"] = "1"
+    ops.tuning_set("proposal_skip_zero", 1)
     try:
         for rep in range(3):                              # counters keep growing: 2K, 3K, 4K > SORT_CAP
             bad = [t.cpu().numpy().copy() for t in ops.proposals(*args, debug=True)]
@@ -584,7 +584,7 @@ def test_proposal_selection_survives_stale_counters(dev):
                 assert np.array_equal(g, b_), rep
         assert (st[:, 2] > 0).any(), st                   # by now some stores were refused by the guard
     finally:
-        del os.environ["MRCNN_PROPOSAL_SKIP_ZERO"]
+        ops.tuning_set("proposal_skip_zero", 0)
     again = [t.cpu().numpy().copy() for t in ops.proposals(*args, debug=True)]
     st = ops.proposal_status(probs, limit, count)
     assert (st[:, 0] == limit).all() and (st[:, 2] == 0).all()
