@@ -111,6 +111,9 @@ _SIGNATURES = {
     "mrcnn_unmold_masks_workspace": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "mrcnn_unmold_masks": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P,
                                      C.c_size_t, _P]),
+    "mrcnn_fits_workspace": (C.c_size_t, [C.c_int, C.c_int]),
+    "mrcnn_fits_to_rgb": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), _P, _P, C.c_size_t, _P]),
+    "mrcnn_mold_image_u8": (C.c_int, [_P] + [C.c_int] * 9 + [C.POINTER(C.c_double), _P, _P, C.c_size_t, _P]),
     "mrcnn_add_inplace": (C.c_int, [_P, _P, C.c_int64, _P]),
     "mrcnn_softmax_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "mrcnn_roialign_fwd": (C.c_int, [C.POINTER(RoiAlignDesc)] + [_P] * 8),

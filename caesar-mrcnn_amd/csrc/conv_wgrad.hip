@@ -642,7 +642,10 @@ static bool plan_wgrad_multi(const mrcnn_wgrad_problem* pr, int n, WgradMultiPla
         if (xbytes + shift + 16LL * d.H * d.W * d.Cin * 4 >= 0x7FFFFFF0LL || M * d.Cout * 4 >= 0x7FFFFFF0LL) return false;
         tiles += (Ktot / 128) * (d.Cout / 128);
     }
-    const long long want = 1024 / (tiles > 0 ? tiles : 1);
+    // workgroups the launch aims at: 1024 = four per CU (what a launch gets beside another stream's kernels); MRCNN_WGRAD_MULTI_TARGET
+    // for A/B (1280 = all five slots per CU: the 36 transform-domain GEMMs of a Winograd layer go 48 tiles x 21 -> x 26 splits)
+    static const long long target = getenv("MRCNN_WGRAD_MULTI_TARGET") ? atoll(getenv("MRCNN_WGRAD_MULTI_TARGET")) : 1024;
+    const long long want = target / (tiles > 0 ? tiles : 1);
     pl.bytes = 0;
     for (int g = 0; g < n; ++g) {
         const mrcnn_conv_desc& d = pr[g].d;

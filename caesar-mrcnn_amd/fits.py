@@ -52,8 +52,9 @@ def _parse_card(card):
             return key, val
 
 
-def read_primary_hdu(filename):
-    """Returns (data ndarray in native byte order with NAXISn..NAXIS1 axes, FitsHeader)."""
+def read_primary_hdu(filename, native=True):
+    """Returns (data ndarray in native byte order with NAXISn..NAXIS1 axes, FitsHeader).  native=False leaves an unscaled
+    image as the read-only big-endian view of the file's bytes (the device path swaps the tile it cuts, not the whole image)."""
     with open(filename, "rb") as f:
         raw = f.read()
     header = FitsHeader()
@@ -83,7 +84,7 @@ def read_primary_hdu(filename):
         data = data.astype(np.float64) * bscale + bzero
         if dt.kind in "iu" or dt == np.dtype(">f4"):
             data = data.astype(np.float32)
-    else:
+    elif native:
         data = data.astype(dt.newbyteorder("="))
     return data, header
 
@@ -181,14 +182,19 @@ def gray2rgb(data_float, to_uint8=True):
 
 
 def read_fits(filename, xmin=-1, xmax=-1, ymin=-1, ymax=-1, stretch=True, normalize=True, convertToRGB=True,
-              zscale_contrasts=[0.25, 0.25, 0.25], to_uint8=True, stretch_biascontrast=False, contrast=1, bias=0.5):
+              zscale_contrasts=[0.25, 0.25, 0.25], to_uint8=True, stretch_biascontrast=False, contrast=1, bias=0.5, device=None):
     """Tile of a FITS image as the network's input image (utils.py:1033-1163): NaN -> min, per-channel
-    zscale, normalise by the channel maximum, uint8 RGB.  Returns (image, header) or None on error."""
+    zscale, normalise by the channel maximum, uint8 RGB.  Returns (image, header) or None on error.
+    device: a torch GPU device -- the numeric part (everything after the header parse and the tile cut) runs there
+    (mrcnn_fits_to_rgb; the file's big-endian floats cross PCIe as they are) when the flags are the run.py ones (stretch,
+    normalize, convertToRGB, to_uint8, no bias / contrast stretch); the uint8 image comes back to the host, identical to the
+    host path's."""
     if len(zscale_contrasts) != 3:
         logger.warning("Size of input zscale_contrasts is !=3, ignoring inputs and using default (0.25,0.25,0.25)...")
         zscale_contrasts = [0.25, 0.25, 0.25]
+    on_device = device is not None and stretch and normalize and convertToRGB and to_uint8 and not stretch_biascontrast
     try:
-        data, header = read_primary_hdu(filename)
+        data, header = read_primary_hdu(filename, native=not on_device)
     except Exception:
         logger.error('ERROR: Cannot read image file: ' + filename)
         return None
@@ -207,6 +213,8 @@ def read_fits(filename, xmin=-1, xmax=-1, ymin=-1, ymax=-1, stretch=True, normal
     else:
         logger.error('ERROR: Invalid/unsupported number of channels found in file %s (nchan=%d)!' % (filename, data.ndim))
         return None
+    if on_device and out.size and out.shape[0] * out.shape[1] <= 4096 * 1024:
+        return _read_fits_device(out, zscale_contrasts, device), header
     out = out.astype(np.float32)
     out[np.isnan(out)] = np.nanmin(out)
     # The reference runs the whole per-channel chain three times (utils.py:1101-1157); the channels differ only in their
@@ -233,6 +241,19 @@ def read_fits(filename, xmin=-1, xmax=-1, ymin=-1, ymax=-1, stretch=True, normal
     if convertToRGB:
         return gray2rgb(chans, to_uint8), header
     return np.copy(chans[0]) if chans[0] is out else chans[0], header
+
+
+def _read_fits_device(tile, zscale_contrasts, device):
+    """The cut tile (still in the file's dtype / byte order) -> uint8 [H, W, 3] through ops.fits_to_rgb; returns a host array."""
+    import torch
+    from . import ops
+    H, W = tile.shape
+    big = tile.dtype == np.dtype(">f4")
+    if not big and tile.dtype != np.float32:
+        tile = tile.astype(np.float32)                              # integer / float64 images: converted on the host as the host path does
+    raw = torch.from_numpy(np.array(tile, order="C", copy=True).view(np.uint8).reshape(-1))   # (a writable copy: the file view is read-only)
+    rgb = ops.fits_to_rgb(raw.to(device, non_blocking=True), H, W, zscale_contrasts, big_endian=big)
+    return rgb.cpu().numpy()
 
 
 def get_fits_header(filename):

@@ -334,6 +334,39 @@ class MaskRCNN(object):
             image_metas.append(meta)
         return np.stack(molded_images), np.stack(image_metas), np.stack(windows)
 
+    def _mold_inputs_device(self, images):
+        """mold_inputs for uint8 images with the pixel work on the GPU (ops.mold_image_u8): each image crosses PCIe as its
+        uint8 bytes and is scaled, padded and mean-subtracted there.  Returns the molded batch as a device tensor
+        [B, H, W, C] float32, image_metas and windows as mold_inputs does -- or None when an image is not uint8 HxWxC or the
+        resize mode draws random numbers ("crop"): the caller then takes the host path."""
+        import torch
+        from . import ops
+        cfg = self.config
+        if cfg.IMAGE_RESIZE_MODE not in ("square", "pad64", "none"):
+            return None
+        plans = []
+        for image in images:
+            if not (isinstance(image, np.ndarray) and image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] <= 4):
+                return None
+            scale, (oh, ow), padding, window = utils.resize_plan(image.shape, cfg.IMAGE_MIN_DIM, cfg.IMAGE_MAX_DIM, cfg.IMAGE_MIN_SCALE,
+                                                                 cfg.IMAGE_RESIZE_MODE)
+            canvas = (oh + padding[0][0] + padding[0][1], ow + padding[1][0] + padding[1][1])
+            plans.append((scale, (oh, ow), padding, window, canvas))
+        if any(p[4] != plans[0][4] for p in plans) or any(im.shape[2] != images[0].shape[2] for im in images):
+            return None                                              # the host path raises the reference's assertion
+        OH, OW = plans[0][4]
+        C_ = images[0].shape[2]
+        dev = self.engine.dev
+        batch = torch.empty((len(images), OH, OW, C_), dtype=torch.float32, device=dev)
+        metas, windows = [], []
+        for i, (image, (scale, out_hw, padding, window, canvas)) in enumerate(zip(images, plans)):
+            src = torch.from_numpy(np.ascontiguousarray(image)).to(dev, non_blocking=True)
+            ops.mold_image_u8(src, out_hw, (padding[0][0], padding[1][0]), canvas, cfg.MEAN_PIXEL, out=batch[i])
+            metas.append(utils.compose_image_meta(0, image.shape, (OH, OW, C_), window, scale,
+                                                  np.zeros([cfg.NUM_CLASSES], dtype=np.int32)))
+            windows.append(window)
+        return batch, np.stack(metas), np.stack(windows)
+
     def _unmold_boxes(self, detections, original_image_shape, image_shape, window):
         """Host half of unmold_detections (mrcnn/model.py:2578-2605): the rows before the first class id 0, boxes from
         normalised window coordinates to pixels of the original image, zero-area boxes dropped.  Returns boxes [n,4] int32,
@@ -397,7 +430,7 @@ class MaskRCNN(object):
         """The inference graph on molded inputs (model.py:2156-2159); outputs stay on the device."""
         import torch
         eng = self.engine
-        x = torch.from_numpy(np.ascontiguousarray(molded_images, dtype=np.float32))
+        x = molded_images if torch.is_tensor(molded_images) else torch.from_numpy(np.ascontiguousarray(molded_images, dtype=np.float32))
         meta = np.asarray(image_metas)
         shape = meta[0, 4:6].astype(np.float32)          # image_shape of the first image (model.py:891-893)
         win = (meta[:, 7:11].astype(np.float32) - np.array([0., 0., 1., 1.], np.float32)) / \
@@ -448,18 +481,21 @@ class MaskRCNN(object):
         if timing is not None:
             import time
             timing["start"] = time.perf_counter()
-        molded_images, image_metas, windows = self.mold_inputs(images)
+        molded = self._mold_inputs_device(images)                  # uint8 images: scaled / padded / mean-subtracted on the GPU
+        if molded is None:
+            molded = self.mold_inputs(images)
+        molded_images, image_metas, windows = molded
         image_shape = molded_images[0].shape
         for g in molded_images[1:]:
             assert g.shape == image_shape, \
                 "After resizing, all images must have the same size. Check IMAGE_RESIZE_MODE and image sizes."
         if verbose:
-            log("molded_images", molded_images)
+            log("molded_images", molded_images if isinstance(molded_images, np.ndarray) else molded_images.cpu().numpy())
             log("image_metas", image_metas)
         if timing is not None:
             timing["molded"] = time.perf_counter()
         out = self._run_graph(molded_images, image_metas)
-        results = self._detect_results(out, [im.shape for im in images], [m.shape for m in molded_images], windows, timing)
+        results = self._detect_results(out, [im.shape for im in images], [tuple(m.shape) for m in molded_images], windows, timing)
         if timing is not None:
             timing["end"] = time.perf_counter()
         return results

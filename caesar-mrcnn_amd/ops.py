@@ -661,6 +661,42 @@ def unmold_masks(mrcnn_mask, dets, image_hw, packed=False, out=None):
     return out
 
 
+def fits_to_rgb(raw, H, W, zscale_contrasts=(0.25, 0.25, 0.25), big_endian=False, out=None):
+    """utils.read_fits's numeric part on the device (mrcnn/utils.py:1088-1157): raw = the tile's H * W float32 values as a
+    device tensor (any dtype of 4 * H * W bytes: float32, or the file's big-endian bytes as uint8 with big_endian=True) ->
+    uint8 [H, W, 3] (NaN -> min, per-channel zscale, / max, round(255 x))."""
+    _need_cuda(raw, out)
+    assert raw.is_contiguous() and raw.numel() * raw.element_size() == 4 * H * W, "raw must hold H * W float32 values"
+    if out is None:
+        out = torch.empty((H, W, 3), dtype=torch.uint8, device=raw.device)
+    L = _hip.lib()
+    nbytes = L.mrcnn_fits_workspace(H, W)
+    ws = workspace(nbytes, raw.device, "fits")
+    zc = (C.c_double * 3)(*[float(v) for v in zscale_contrasts])
+    check(L.mrcnn_fits_to_rgb(ptr(raw), 1 if big_endian else 0, H, W, zc, ptr(out), ptr(ws), ws.numel(), current_stream()),
+          "mrcnn_fits_to_rgb")
+    return out
+
+
+def mold_image_u8(src, out_hw, pad_tl, canvas_hw, mean_pixel, out=None):
+    """utils.resize_image's pixel work + mold_image on the device (mrcnn/model.py:2519-2556): src [h, w, C] uint8 device ->
+    float32 [OH, OW, C]: the image scaled to out_hw (bilinear, float64, clipped to the image's range, truncated to uint8; a copy
+    when out_hw == (h, w)) at pad_tl inside a zero canvas, minus mean_pixel."""
+    import numpy as np
+    _need_cuda(src, out)
+    assert src.dtype == torch.uint8 and src.dim() == 3 and src.is_contiguous()
+    h, w, C_ = src.shape
+    (oh, ow), (top, left), (OH, OW) = out_hw, pad_tl, canvas_hw
+    if out is None:
+        out = torch.empty((OH, OW, C_), dtype=torch.float32, device=src.device)
+    assert tuple(out.shape) == (OH, OW, C_) and out.dtype == torch.float32 and out.is_contiguous()
+    ws = workspace(64, src.device, "mold")
+    mean = (C.c_double * C_)(*[float(v) for v in np.broadcast_to(np.asarray(mean_pixel, np.float64), (C_,))])
+    check(_hip.lib().mrcnn_mold_image_u8(ptr(src), h, w, C_, int(oh), int(ow), int(top), int(left), int(OH), int(OW), mean, ptr(out),
+                                         ptr(ws), ws.numel(), current_stream()), "mrcnn_mold_image_u8")
+    return out
+
+
 def fill_zero(t):
     _need_cuda(t)
     check(_hip.lib().mrcnn_fill_zero(ptr(t), t.numel() * t.element_size(), current_stream()), "mrcnn_fill_zero")

@@ -131,6 +131,41 @@ def resize(image, output_shape, order=1, mode='constant', cval=0, clip=True, pre
     return out[:, :, 0] if squeeze else out
 
 
+def resize_plan(shape, min_dim=None, max_dim=None, min_scale=None, mode="square"):
+    """The scalar half of resize_image (mrcnn/utils.py:456-561) for the modes without randomness: scale, the scaled size
+    (round(h * scale), round(w * scale)), padding [(top, bottom), (left, right), (0, 0)] and window (y1, x1, y2, x2) of an image
+    of `shape`.  The device path of MaskRCNN.mold_inputs does the pixel work from these numbers (ops.mold_image_u8)."""
+    h, w = shape[:2]
+    scale = 1
+    if mode == "none":
+        return 1, (h, w), [(0, 0), (0, 0), (0, 0)], (0, 0, h, w)
+    if min_dim:
+        scale = max(1, min_dim / min(h, w))
+    if min_scale and scale < min_scale:
+        scale = min_scale
+    if max_dim and mode == "square":
+        longest = max(h, w)
+        if round(longest * scale) > max_dim:
+            scale = max_dim / longest
+    if scale != 1:
+        h, w = round(h * scale), round(w * scale)
+    if mode == "square":
+        top, left = (max_dim - h) // 2, (max_dim - w) // 2
+        return scale, (h, w), [(top, max_dim - h - top), (left, max_dim - w - left), (0, 0)], (top, left, h + top, w + left)
+    if mode == "pad64":
+        assert min_dim % 64 == 0, "Minimum dimension must be a multiple of 64"
+        pads = []
+        for size in (h, w):
+            if size % 64 > 0:
+                full = size - (size % 64) + 64
+                before = (full - size) // 2
+                pads.append((before, full - size - before))
+            else:
+                pads.append((0, 0))
+        return scale, (h, w), [pads[0], pads[1], (0, 0)], (pads[0][0], pads[1][0], h + pads[0][0], w + pads[1][0])
+    raise Exception("Mode {} not supported".format(mode))
+
+
 def resize_image(image, min_dim=None, max_dim=None, min_scale=None, mode="square"):
     """Scale (up only) and zero-pad to the network input (mrcnn/utils.py:456-561).
     Returns image, window (y1,x1,y2,x2), scale, padding, crop."""

@@ -200,6 +200,26 @@ size_t mrcnn_unmold_masks_workspace(int n, int MH, int MW);
 int mrcnn_unmold_masks(const float* mrcnn_mask, int n_rows, int MH, int MW, int C, const int32_t* dets, int n, int H, int W,
                        int packed, void* out, void* workspace, size_t workspace_bytes, void* stream);
 
+/* FITS tile -> network input image (utils.read_fits, mrcnn/utils.py:1033-1163, on the run.py path: stretch, normalize,
+ * convertToRGB, to_uint8; per-channel astropy ZScaleInterval(contrast) [3P] -> / max -> round(255 x), :1101-1111, :1166-1208):
+ *   raw   [H, W] float32 as stored in the file (big_endian != 0: FITS byte order, swapped on the device) -- the caller has
+ *         parsed the header and cut the tile; NaN pixels are replaced by the minimum of the others (:1090-1091);
+ *   zscale_contrasts  3 doubles (HOST pointer, read at call time);
+ *   rgb   [H, W, 3] uint8, byte-identical to the host statement caesar-mrcnn_amd/fits.py:read_fits.
+ * Tiles up to 4096 x 1024 pixels (else MRCNN_ERR_UNSUPPORTED: use the host path).  workspace: mrcnn_fits_workspace(H, W).  */
+size_t mrcnn_fits_workspace(int H, int W);
+int mrcnn_fits_to_rgb(const void* raw, int big_endian, int H, int W, const double* zscale_contrasts, void* rgb, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* detect() pre-processing (MaskRCNN.mold_inputs, mrcnn/model.py:2519-2556, for uint8 images): utils.resize_image's pixel work
+ * (mrcnn/utils.py:456-561: bilinear up-scaling h x w -> oh x ow through skimage.transform.resize(order=1, mode='constant',
+ * clip=True, preserve_range=True) [3P], zero padding into the OH x OW canvas at (top, left), cast to uint8) and mold_image
+ * (mrcnn/model.py:2964-2969: float32 minus MEAN_PIXEL).  src [h, w, C] uint8 (C <= 4), out [OH, OW, C] float32 -- identical to
+ * the host path (caesar-mrcnn_amd/utils.py:resize_image + mold_image); the caller computes scale, (oh, ow) = (round(h * scale),
+ * round(w * scale)) and the padding as the reference does.  mean_pixel: C doubles on the HOST.  workspace: >= 8 bytes.   */
+int mrcnn_mold_image_u8(const void* src, int h, int w, int C, int oh, int ow, int top, int left, int OH, int OW,
+                        const double* mean_pixel, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Elementwise helpers on flat buffers. */
 int mrcnn_add_inplace(float* dst, const float* src, int64_t n, void* stream);
 int mrcnn_softmax_rows(const float* logits, float* probs, int64_t rows, int C, void* stream);

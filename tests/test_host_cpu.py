@@ -515,3 +515,19 @@ def test_prefetcher_order_errors_and_shutdown():
     assert next(p) == (7, 0) and next(p) == (7, 1)
     with pytest.raises(ValueError, match="boom 7"):
         next(p)
+
+
+def test_resize_plan_matches_resize_image():
+    """utils.resize_plan (the scalar half of resize_image that the device mold path works from) against resize_image itself:
+    same scale, window, padding and scaled size for square / pad64 / none, up-scaled and unscaled, odd sizes."""
+    from caesar_mrcnn_amd import utils
+    rng = np.random.default_rng(3)
+    for mode, min_dim, max_dim in (("square", 256, 256), ("square", 128, 192), ("pad64", 128, 1024), ("none", 256, 256)):
+        for h, w in ((132, 132), (256, 256), (100, 180), (77, 201), (256, 130), (33, 47), (300, 200)):
+            if mode == "square" and max(h, w) > max_dim and min(h, w) >= min_dim:
+                continue                                        # scale < 1 never happens on this path (scale = max(1, ...)) unless max_dim caps it
+            img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+            out, window, scale, padding, crop = utils.resize_image(img, min_dim=min_dim, max_dim=max_dim, min_scale=0, mode=mode)
+            s2, (oh, ow), pad2, win2 = utils.resize_plan(img.shape, min_dim, max_dim, 0, mode)
+            assert s2 == scale and tuple(win2) == tuple(window) and [tuple(p) for p in pad2] == [tuple(p) for p in padding], (mode, h, w)
+            assert out.shape[:2] == (oh + pad2[0][0] + pad2[0][1], ow + pad2[1][0] + pad2[1][1])

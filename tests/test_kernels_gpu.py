@@ -1028,3 +1028,101 @@ def test_proposal_topk_preselection_fallback_on_massive_ties(dev):
     for b in range(2):
         ref = orc.tf_top_k_indices(fg[b], limit)
         assert np.array_equal(top_idx[b].cpu().numpy(), ref.astype(np.int32))
+
+
+def _fits_tiles_for_test():
+    """(name, float32 tile) cases for the device FITS path: the reference's two cut-outs (one with 288 NaN pixels), seeded
+    synthetic tiles with a NaN border, +-inf pixels (-inf makes the NaN fill itself non-finite), fewer pixels than the 1000
+    zscale samples, a sample count that is not a multiple of the stride, a constant tile and a heavy-tailed one (the rejection
+    loop runs all its rounds)."""
+    import os
+    from caesar_mrcnn_amd import fits
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    cases = [(n, fits.read_primary_hdu(os.path.join(g, n))[0].astype(np.float32)) for n in ("galaxy0002.fits", "sidelobe0001.fits")]
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:256, 0:256]
+    t = rng.normal(0, 1, (256, 256)).astype(np.float32)
+    for _ in range(5):
+        cy, cx, sy, sx = rng.uniform(20, 236, 2).tolist() + rng.uniform(1.5, 12, 2).tolist()
+        t += (np.exp(-0.5 * (((yy - cy) / sy) ** 2 + ((xx - cx) / sx) ** 2)) * rng.uniform(5, 200)).astype(np.float32)
+    a = t.copy(); a[:3, :] = np.nan; a[:, -2:] = np.nan
+    cases.append(("nan border", a))
+    b = t.copy(); b[5, 7] = np.inf; b[100, 3] = np.inf; b[0, :40] = np.nan
+    cases.append(("+inf pixels", b))
+    c = t.copy(); c[9, 9] = -np.inf; c[200:203, :] = np.nan
+    cases.append(("-inf pixel: the NaN fill is -inf", c))
+    cases.append(("small 20 x 31", t[:20, :31].copy()))
+    cases.append(("non-square 300 x 217", np.tile(t, (2, 1))[:300, :217].copy()))
+    cases.append(("constant", np.full((64, 64), 3.5, np.float32)))
+    cases.append(("heavy tail", (rng.standard_cauchy((128, 128)) * 3).astype(np.float32)))
+    cases.append(("1024 x 1024", rng.normal(10, 2, (1024, 1024)).astype(np.float32)))
+    return cases
+
+
+def test_fits_to_rgb_device_equals_host(dev, tmp_path):
+    """mrcnn_fits_to_rgb against the host statement of utils.read_fits (mrcnn/utils.py:1033-1163; caesar_mrcnn_amd.fits:
+    NaN -> min, per-channel zscale, / max, round(255 x)): byte-identical uint8 images through fits.read_fits(device=...) --
+    file parse and tile cut on the host, the big-endian floats swapped on the device -- for whole images and a cut tile,
+    equal and unequal channel contrasts."""
+    import warnings
+    from caesar_mrcnn_amd import fits
+    for k, (name, tile) in enumerate(_fits_tiles_for_test()):
+        path = str(tmp_path / ("t%d.fits" % k))
+        fits.write_fits(path, tile, {"BUNIT": "JY/BEAM"})
+        for zc in ([0.25, 0.25, 0.25], [0.25, 0.3, 1.0]):
+            with warnings.catch_warnings(), np.errstate(all="ignore"):
+                warnings.simplefilter("ignore")
+                want, _ = fits.read_fits(path, zscale_contrasts=zc)
+                got, hdr = fits.read_fits(path, zscale_contrasts=zc, device=dev)
+            assert got.dtype == np.uint8 and got.shape == tile.shape + (3,) and hdr["BUNIT"] == "JY/BEAM"
+            diff = int((got != want).sum())
+            assert diff == 0, "%s zc=%s: %d of %d bytes differ (max |d| %d)" % (
+                name, zc, diff, got.size, int(np.abs(got.astype(int) - want.astype(int)).max()))
+            if name != "constant":
+                assert got.max() == 255 and len(np.unique(got)) > 8
+        if tile.shape[0] >= 200:                                   # a tile cut out of the image (xmin / xmax / ymin / ymax)
+            with warnings.catch_warnings(), np.errstate(all="ignore"):
+                warnings.simplefilter("ignore")
+                want, _ = fits.read_fits(path, xmin=17, xmax=149, ymin=30, ymax=162)
+                got, _ = fits.read_fits(path, xmin=17, xmax=149, ymin=30, ymax=162, device=dev)
+            assert got.shape == (132, 132, 3) and np.array_equal(got, want), name
+
+
+def test_mold_inputs_device_equals_host(dev):
+    """MaskRCNN._mold_inputs_device (mrcnn_mold_image_u8: bilinear up-scaling in float64, clip to the image's range, uint8
+    truncation, zero padding, minus MEAN_PIXEL) against the host mold_inputs (mrcnn/model.py:2519-2556 -> utils.resize_image,
+    mold_image): identical float32 canvas, metas and windows -- 132 -> 256 (the reference's cut-outs), non-square up-scaling,
+    unscaled with padding, a grey (1-channel) image, a non-zero mean pixel; detect() on the device-molded input equals detect
+    on the host-molded one."""
+    import os
+    from caesar_mrcnn_amd import fits
+    from caesar_mrcnn_amd.config import run_py_config
+    from caesar_mrcnn_amd.model import MaskRCNN
+    rng = np.random.default_rng(9)
+    cfg = run_py_config(backbone="custom", imgsize=256, mode="inference")
+    cfg.POST_NMS_ROIS_INFERENCE = 200
+    cfg.DETECTION_MAX_INSTANCES = 30
+    model = MaskRCNN("inference", cfg, "/tmp/mrcnn_logs", device=dev, seed=5)
+    cut, _ = fits.read_fits(os.path.join(os.path.dirname(__file__), "golden", "galaxy0002.fits"))
+    images = [cut, rng.integers(0, 256, (100, 180, 3), dtype=np.uint8), rng.integers(0, 256, (256, 256, 3), dtype=np.uint8),
+              rng.integers(0, 256, (256, 130, 3), dtype=np.uint8), rng.integers(20, 200, (77, 201, 3), dtype=np.uint8)]
+    for mean in ([0.0, 0.0, 0.0], [123.7, 116.8, 103.9]):
+        cfg.MEAN_PIXEL = np.array(mean)
+        for img in images:
+            want, wmeta, wwin = model.mold_inputs([img])
+            got = model._mold_inputs_device([img])
+            assert got is not None
+            torch.cuda.synchronize()
+            g = got[0].cpu().numpy()
+            assert g.shape == want.shape and g.dtype == np.float32
+            d = np.abs(g - want.astype(np.float32))
+            assert d.max() == 0.0, (img.shape, mean, float(d.max()), int((d > 0).sum()))
+            assert np.array_equal(got[1], wmeta) and np.array_equal(got[2], wwin)
+    cfg.MEAN_PIXEL = np.array([0.0, 0.0, 0.0])
+    assert model._mold_inputs_device([cut.astype(np.float32)]) is None            # not uint8: host path
+    res_dev = model.detect([cut])[0]
+    molded, metas, windows = model.mold_inputs([cut])
+    out = model._run_graph(molded, metas)
+    res_host = model._detect_results(out, [cut.shape], [molded[0].shape], windows)[0]
+    for k in ("rois", "class_ids", "scores", "masks"):
+        assert np.array_equal(res_dev[k], res_host[k]), k
