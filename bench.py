@@ -146,7 +146,7 @@ def synthetic_fits_dataset(cfg, n_images, root, seed=1234):
     return ds
 
 
-def _train_loop_leg(args, res, model, cfg, nimg, world, rank):
+def _train_loop_leg(args, res, model, cfg, nimg, world, rank, loader_threads=None, device_fits=None, key="train_loop"):
     """The loop MaskRCNN.train() runs, timed end to end: loader threads (FITS -> zscale -> resize -> GT boxes / masks) ->
     H2D of images and of the USED GT-mask planes -> RPN targets on the device -> step.  Unlike `value`, inputs are NOT
     resident in HBM: this is the feed-inclusive rate (reference: model.py:2487-2499, fit_generator + workers)."""
@@ -154,7 +154,12 @@ def _train_loop_leg(args, res, model, cfg, nimg, world, rank):
     from caesar_mrcnn_amd.datagen import Prefetcher, data_generator
     ds = synthetic_fits_dataset(cfg, 32, "/tmp/mrcnn_bench_data_r%d" % rank, seed=1234 + rank)
     cfg.DEVICE_RPN_TARGETS = True
-    nw = min(8, len(os.sched_getaffinity(0)))
+    if device_fits is None:
+        device_fits = bool(getattr(cfg, "DEVICE_FITS", False))
+    ds.device = model.engine.dev if device_fits else None      # FITS -> zscale -> uint8 RGB on the GPU (what MaskRCNN.train sets up)
+    # with the tile pre-processing on the device two loader threads keep up (they mostly wait on the GPU, interpreter lock
+    # released); the host path needs a thread per image of the batch and more
+    nw = loader_threads if loader_threads else (2 if device_fits else min(8, len(os.sched_getaffinity(0))))
     gen = Prefetcher([data_generator(ds, cfg, shuffle=True, batch_size=nimg, seed=99 + 1000 * k, device_targets=True)
                       for k in range(nw)], depth=2 * nw + 2)
     eng = model.engine
@@ -167,8 +172,9 @@ def _train_loop_leg(args, res, model, cfg, nimg, world, rank):
             model.train_on_batch(inputs)
         torch.cuda.synchronize()
         t0 = time.time()
-        wait, h2d = 0.0, 0
+        wait, h2d, depth = 0.0, 0, 0
         for _ in range(steps):
+            depth += gen._q.qsize()
             t1 = time.time()
             inputs, _ = next(gen)
             wait += time.time() - t1
@@ -179,7 +185,8 @@ def _train_loop_leg(args, res, model, cfg, nimg, world, rank):
         torch.cuda.synchronize()
         dt = time.time() - t0
         return {"images_per_s": round(nimg * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3),
-                "ms_per_step_waiting_for_loader": round(wait / steps * 1e3, 3), "h2d_bytes_per_step": int(h2d / steps)}
+                "ms_per_step_waiting_for_loader": round(wait / steps * 1e3, 3), "h2d_bytes_per_step": int(h2d / steps),
+                "batches_queued_when_asked": round(depth / steps, 2)}
 
     try:
         dense = run(False)                            # the headline's work per step (every ROI row through the mask head)
@@ -187,8 +194,8 @@ def _train_loop_leg(args, res, model, cfg, nimg, world, rank):
     finally:
         gen.close()
         eng.sparse_mask_bwd = True
-    res["train_loop"] = dict(dense, steps=steps, loader_threads=nw, exact_zero_skip=sparse,
-        launch_tape=bool(getattr(cfg, "TRAIN_LAUNCH_TAPE", False)),
+    res[key] = dict(dense, steps=steps, loader_threads=nw, exact_zero_skip=sparse,
+        launch_tape=bool(getattr(cfg, "TRAIN_LAUNCH_TAPE", False)), fits_preprocessing="device (mrcnn_fits_to_rgb)" if device_fits else "host (NumPy)",
         what="MaskRCNN.train()'s own iteration (steps re-issued from the launch recording when launch_tape): Prefetcher threads over data_generator on 32 synthetic FITS tiles "
              "(read_fits + zscale + uint8 RGB + resize + extract_bboxes), per-step H2D of images and the used GT-mask planes, "
              "bit-packed (8 instances per byte), RPN targets built on the device; dense mask head like `value`, and the product-default step under "

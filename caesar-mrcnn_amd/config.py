@@ -74,6 +74,9 @@ class Config(object):
     # from 121-127 to 168-182 images/s (ResNet-101, 4 images, 8 loader threads; the dense loop is device-bound either way).
     # MRCNN_TRAIN_TAPE=0 switches it off.  Data-parallel runs keep eager launches (gradient hooks are not recorded).
     TRAIN_LAUNCH_TAPE = os.environ.get("MRCNN_TRAIN_TAPE", "1") != "0"
+    # FITS tiles of the training / validation datasets: NaN fill, zscale, normalisation and the uint8 RGB conversion of
+    # utils.read_fits (mrcnn/utils.py:1088-1157) on the GPU (mrcnn_fits_to_rgb; byte-identical images), from the loader threads
+    DEVICE_FITS = os.environ.get("MRCNN_DEVICE_FITS", "1") != "0"
     # extension: None (float32 everywhere, the reference's precision) | "float16" | "bfloat16": run the 3x3
     # convolutions of the mask head on the 16-bit matrix cores (csrc/conv_h16.hip; float32 master weights,
     # accumulation and gradients; HEAD_LOSS_SCALE guards float16 gradients)

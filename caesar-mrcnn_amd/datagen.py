@@ -150,8 +150,13 @@ def data_generator(dataset, config, shuffle=True, augment=False, augmentation=No
                 batch_images = np.zeros((batch_size,) + image.shape, dtype=np.float32)
                 batch_gt_class_ids = np.zeros((batch_size, config.MAX_GT_INSTANCES), dtype=np.int32)
                 batch_gt_boxes = np.zeros((batch_size, config.MAX_GT_INSTANCES, 4), dtype=np.int32)
-                batch_gt_masks = np.zeros((batch_size, gt_masks.shape[0], gt_masks.shape[1], config.MAX_GT_INSTANCES),
-                                          dtype=gt_masks.dtype)
+                # the reference's batch carries MAX_GT_INSTANCES mask planes per image ([B, 256, 256, 300] bool = 78.6 MB on the run.py
+                # path, almost all padding): allocating, zeroing and freeing that array cost the consumer ~3 ms per step.  With
+                # device_targets (the product's own loop) the batch keeps only as many planes as its fullest image has (rounded up to
+                # 8: they cross PCIe bit-packed); the padding up to MAX_GT_INSTANCES is written on the device (MaskRCNN._to_device).
+                batch_gt_masks = None if device_targets else \
+                    np.zeros((batch_size, gt_masks.shape[0], gt_masks.shape[1], config.MAX_GT_INSTANCES), dtype=gt_masks.dtype)
+                mask_list = []
             if gt_boxes.shape[0] > config.MAX_GT_INSTANCES:
                 ids = np.random.choice(np.arange(gt_boxes.shape[0]), config.MAX_GT_INSTANCES, replace=False)
                 gt_class_ids, gt_boxes, gt_masks = gt_class_ids[ids], gt_boxes[ids], gt_masks[:, :, ids]
@@ -162,9 +167,17 @@ def data_generator(dataset, config, shuffle=True, augment=False, augmentation=No
             batch_images[b] = utils.mold_image(image.astype(np.float32), config)
             batch_gt_class_ids[b, :gt_class_ids.shape[0]] = gt_class_ids
             batch_gt_boxes[b, :gt_boxes.shape[0]] = gt_boxes
-            batch_gt_masks[b, :, :, :gt_masks.shape[-1]] = gt_masks
+            if device_targets:
+                mask_list.append(gt_masks)
+            else:
+                batch_gt_masks[b, :, :, :gt_masks.shape[-1]] = gt_masks
             b += 1
             if b >= batch_size:
+                if device_targets:
+                    planes = max(8, (max(m.shape[-1] for m in mask_list) + 7) // 8 * 8)
+                    batch_gt_masks = np.zeros((batch_size,) + mask_list[0].shape[:2] + (planes,), dtype=mask_list[0].dtype)
+                    for k, m in enumerate(mask_list):
+                        batch_gt_masks[k, :, :, :m.shape[-1]] = m
                 yield [batch_images, batch_image_meta, batch_rpn_match, batch_rpn_bbox, batch_gt_class_ids,
                        batch_gt_boxes, batch_gt_masks], []
                 b = 0

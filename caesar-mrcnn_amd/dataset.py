@@ -197,10 +197,12 @@ class SourceDataset(Dataset):
         return m if binary else m.astype(int)
 
     def load_image(self, image_id):
+        # self.device (set by MaskRCNN.train when Config.DEVICE_FITS): NaN fill / zscale / RGB on that GPU, same bytes back
         image, _ = fits.read_fits(self.image_info[image_id]['path'], stretch=self.apply_zscale,
                                   zscale_contrasts=self.zscale_contrasts, normalize=True,
                                   convertToRGB=self.convert_to_rgb, to_uint8=self.convert_to_uint8,
-                                  stretch_biascontrast=self.apply_biascontrast, bias=self.bias, contrast=self.contrast)
+                                  stretch_biascontrast=self.apply_biascontrast, bias=self.bias, contrast=self.contrast,
+                                  device=getattr(self, "device", None))
         return image
 
     def image_uuid(self, image_id):

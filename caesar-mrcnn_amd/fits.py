@@ -243,17 +243,38 @@ def read_fits(filename, xmin=-1, xmax=-1, ymin=-1, ymax=-1, stretch=True, normal
     return np.copy(chans[0]) if chans[0] is out else chans[0], header
 
 
+_loader_stream = {}
+_loader_lock = None
+
+
 def _read_fits_device(tile, zscale_contrasts, device):
-    """The cut tile (still in the file's dtype / byte order) -> uint8 [H, W, 3] through ops.fits_to_rgb; returns a host array."""
+    """The cut tile (still in the file's dtype / byte order) -> uint8 [H, W, 3] through ops.fits_to_rgb; returns a host array.
+    Called from loader threads while the main thread issues training steps: the three launches go to ONE side stream shared
+    by all loader threads (its own hardware queue beside the step's three; a stream per thread would wrap onto the step's
+    queues and wait behind a whole step) under a lock (the stream's scratch buffer is shared), and only that stream is
+    synchronised."""
+    import threading
     import torch
     from . import ops
+    global _loader_lock
+    if _loader_lock is None:
+        _loader_lock = threading.Lock()
     H, W = tile.shape
     big = tile.dtype == np.dtype(">f4")
     if not big and tile.dtype != np.float32:
         tile = tile.astype(np.float32)                              # integer / float64 images: converted on the host as the host path does
     raw = torch.from_numpy(np.array(tile, order="C", copy=True).view(np.uint8).reshape(-1))   # (a writable copy: the file view is read-only)
-    rgb = ops.fits_to_rgb(raw.to(device, non_blocking=True), H, W, zscale_contrasts, big_endian=big)
-    return rgb.cpu().numpy()
+    device = torch.device(device)
+    with _loader_lock:
+        st = _loader_stream.get(device)
+        if st is None:
+            st = _loader_stream[device] = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(st):
+            rgb = ops.fits_to_rgb(raw.to(device, non_blocking=True), H, W, zscale_contrasts, big_endian=big)
+            host = torch.empty((H, W, 3), dtype=torch.uint8, pin_memory=True)
+            host.copy_(rgb, non_blocking=True)
+        st.synchronize()
+    return host.numpy().copy()
 
 
 def get_fits_header(filename):

@@ -220,11 +220,12 @@ class MaskRCNN(object):
                                                       self.config.RPN_BBOX_STD_DEV)
         else:
             rpn_match_d, rpn_bbox_d = t(rpn_match, np.int32), t(rpn_bbox, np.float32)
-        G = gt_masks.shape[-1]
+        G = np.asarray(gt_class_ids).shape[1]                             # planes on the device: MAX_GT_INSTANCES, like the class ids
+        have = gt_masks.shape[-1]                                         # planes in the batch (data_generator(device_targets=True) trims the padding)
         used = np.flatnonzero(np.any(np.asarray(gt_class_ids) != 0, axis=0))
-        n_used = int(used[-1]) + 1 if used.size else 0
-        if n_used < G and gt_masks[..., n_used:].any():
-            n_used = G                                                    # masks without a class id: upload them all
+        n_used = min(int(used[-1]) + 1 if used.size else 0, have)
+        if n_used < have and gt_masks[..., n_used:].any():
+            n_used = min(have, G)                                         # masks without a class id: upload them all
         # bit-packed across PCIe (8 instances per byte), unpacked on the device; the padding planes are written there
         self.last_mask_h2d_bytes = 0
         if n_used:
@@ -232,7 +233,7 @@ class MaskRCNN(object):
             self.last_mask_h2d_bytes = packed.nbytes
             masks_d = ops.unpack_mask_bits(t(packed, np.uint8), n_used, G)
         else:
-            masks_d = torch.zeros(gt_masks.shape, dtype=torch.uint8, device=dev)
+            masks_d = torch.zeros(tuple(gt_masks.shape[:-1]) + (G,), dtype=torch.uint8, device=dev)
         return (t(images, np.float32), rpn_match_d, rpn_bbox_d, cls_d, t(gtn, np.float32), masks_d,
                 t(active, np.int32), t(rand_keys, np.float32))
 
@@ -274,6 +275,10 @@ class MaskRCNN(object):
         from .datagen import Prefetcher
         nw = int(n_worker_threads) if n_worker_threads and n_worker_threads > 0 else min(8, os.cpu_count() or 1)
         dev_t = bool(getattr(cfg, "DEVICE_RPN_TARGETS", False))
+        if getattr(cfg, "DEVICE_FITS", False):
+            for ds in (train_dataset, val_dataset):
+                if hasattr(ds, "load_image") and hasattr(ds, "zscale_contrasts"):     # SourceDataset: FITS -> uint8 RGB on the GPU
+                    ds.device = self.engine.dev
         train_gen = Prefetcher([data_generator(train_dataset, cfg, shuffle=True, augmentation=augmentation,
                                                batch_size=cfg.IMAGES_PER_GPU, no_augmentation_sources=no_augmentation_sources,
                                                rank=rank, world_size=world, seed=1234 + 1000 * k, device_targets=dev_t)
