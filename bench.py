@@ -164,6 +164,9 @@ def _train_loop_leg(args, res, model, cfg, nimg, world, rank, loader_threads=Non
                       for k in range(nw)], depth=2 * nw + 2)
     eng = model.engine
     steps = max(args.steps, 10)
+    t_fill = time.time()                              # steady state: let the loaders fill their queue once (cold start: first
+    while gen._q.qsize() < 2 * nw + 2 and time.time() - t_fill < 10.0:      # file reads, stream / pinned-buffer set-up)
+        time.sleep(0.01)
 
     def run(sparse):
         eng.sparse_mask_bwd = sparse

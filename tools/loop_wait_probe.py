@@ -20,7 +20,7 @@ cfg.DEVICE_RPN_TARGETS = True
 ds.device = dev if devfits else None
 gen = Prefetcher([data_generator(ds, cfg, shuffle=True, batch_size=4, seed=99 + 1000 * k, device_targets=True) for k in range(nw)], depth=2 * nw + 2)
 eng = model.engine
-eng.sparse_mask_bwd = True
+eng.sparse_mask_bwd = os.environ.get("DENSE", "0") == "0"
 for _ in range(4):
     inputs, _ = next(gen); model.train_on_batch(inputs)
 torch.cuda.synchronize()
