@@ -176,3 +176,34 @@ def test_mask_iou_matches_sklearn_jaccard():
         b = rng.uniform(size=(24, 24)) < 0.5
         ref = skm.jaccard_score(a.ravel(), b.ravel())
         assert abs(analyze.mask_iou(a, b) - ref) < 1e-12
+
+
+def test_find_contours_vertices_match_contourpy():
+    """Second source for the marching-squares restatement (skimage.measure.find_contours itself is not installable here):
+    contourpy (matplotlib's contouring engine, importable in the build image) must produce exactly the same iso-line vertices
+    -- on random fields (every square type incl. saddles: only the way saddle segments are JOINED is a convention, the
+    vertices are not) -- and, on a smooth saddle-free field, the same closed polylines (same vertex set per line, same
+    enclosed area)."""
+    contourpy = pytest.importorskip("contourpy")
+    rng = np.random.default_rng(11)
+
+    def vertex_set(lines, swap):
+        return sorted(set((round(float(p[1 if swap else 0]), 9), round(float(p[0 if swap else 1]), 9)) for l in lines for p in l))
+    for shape in ((12, 15), (28, 28), (7, 40)):
+        f = rng.random(shape)
+        for level in (0.5, 0.31):
+            theirs = contourpy.contour_generator(z=f, corner_mask=False).lines(level)      # (x, y) = (col, row)
+            mine = analyze.find_contours(f, level)
+            assert vertex_set(theirs, True) == vertex_set(mine, False), (shape, level)
+    yy, xx = np.mgrid[0:40, 0:48]
+    g = np.exp(-0.5 * (((yy - 12) / 4.0) ** 2 + ((xx - 14) / 6.0) ** 2)) + 0.8 * np.exp(-0.5 * (((yy - 28) / 5.0) ** 2 + ((xx - 33) / 3.5) ** 2))
+    theirs = contourpy.contour_generator(z=g, corner_mask=False).lines(0.5)
+    mine = analyze.find_contours(g, 0.5)
+    assert len(theirs) == len(mine) == 2
+    area = lambda y, x: abs(0.5 * np.sum(x[:-1] * y[1:] - x[1:] * y[:-1]))
+    a = sorted((round(area(l[:, 1], l[:, 0]), 9), len(l)) for l in theirs)
+    b = sorted((round(area(c[:, 0], c[:, 1]), 9), len(c)) for c in mine)
+    assert a == b
+    bm = (g > 0.5).astype(np.uint8)                                   # the binary masks Analyzer actually contours
+    assert vertex_set(contourpy.contour_generator(z=bm.astype(float), corner_mask=False).lines(0.5), True) == \
+        vertex_set(analyze.find_contours(bm, 0.5), False)

@@ -216,3 +216,55 @@ def test_connected_components_order():
         cc = connected_components(n, edges)
         assert [len(c) for c in cc] == G["graph_%s_cc_len" % tag].tolist()
         assert [v for c in cc for v in c] == G["graph_%s_cc_flat" % tag].tolist()
+
+
+def test_resize_restatement_matches_scipy_map_coordinates():
+    """utils.resize restates skimage.transform.resize(order=1, mode='constant', cval=0, clip=True) [3P; skimage is not
+    installable here].  Second source for its arithmetic: scipy.ndimage.map_coordinates(order=1, mode="grid-constant", cval=0: samples between the edge pixel and the outside blend with the constant, as skimage's warp does) at
+    the half-pixel-centre coordinates (o + 0.5) * in / out - 0.5 -- an independent bilinear sampler with the same
+    zero-outside rule -- followed by the clip to the input's range.  Up- and down-sampling, masks (28 x 28 -> box) and RGB."""
+    from scipy import ndimage
+    from caesar_mrcnn_amd import utils
+    rng = np.random.default_rng(21)
+    for (h, w), (oh, ow) in (((28, 28), (61, 17)), ((28, 28), (5, 90)), ((28, 28), (28, 28)), ((13, 31), (64, 64)), ((132, 132), (256, 256))):
+        img = rng.random((h, w))
+        ry = (np.arange(oh) + 0.5) * (h / oh) - 0.5
+        rx = (np.arange(ow) + 0.5) * (w / ow) - 0.5
+        coords = np.stack(np.meshgrid(ry, rx, indexing="ij"))
+        want = np.clip(ndimage.map_coordinates(img, coords, order=1, mode="grid-constant", cval=0.0), img.min(), img.max())
+        got = utils.resize(img, (oh, ow))
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+    rgb = rng.integers(0, 256, (20, 33, 3), dtype=np.uint8)
+    got = utils.resize(rgb, (47, 50), preserve_range=True)
+    ry = (np.arange(47) + 0.5) * (20 / 47) - 0.5
+    rx = (np.arange(50) + 0.5) * (33 / 50) - 0.5
+    coords = np.stack(np.meshgrid(ry, rx, indexing="ij"))
+    for c in range(3):
+        want = np.clip(ndimage.map_coordinates(rgb[:, :, c].astype(np.float64), coords, order=1, mode="grid-constant", cval=0.0), rgb.min(), rgb.max())
+        np.testing.assert_allclose(got[:, :, c], want, rtol=0, atol=1e-10)
+
+
+def test_oracle_crop_and_resize_matches_scipy_sampler():
+    """Second source for the ARITHMETIC of the oracle's tf.image.crop_and_resize restatement (TF itself cannot run here: the
+    sampling grid in = lo (D - 1) + i (hi - lo) (D - 1) / (crop - 1) and the zero-outside rule are SURVEY App. C-3): scipy's
+    independent bilinear sampler scipy.ndimage.map_coordinates(order=1, mode='constant', cval=0) evaluated on that grid -- a
+    sample outside [0, D - 1] is the constant, nothing is blended across the edge -- per channel, for boxes inside, partly
+    outside and wholly outside the map, and for the crop-size-1 rule.  float32 tolerance."""
+    import torch
+    from scipy import ndimage
+    import mrcnn_oracle as orc
+    rng = np.random.default_rng(33)
+    H, W, C = 19, 23, 5
+    img = rng.standard_normal((2, H, W, C)).astype(np.float32)
+    boxes = np.array([[0.1, 0.2, 0.7, 0.9], [0.0, 0.0, 1.0, 1.0], [-0.2, 0.3, 0.5, 1.3], [0.4, 0.4, 0.41, 0.41], [1.2, 0.1, 1.6, 0.5],
+                      [0.3, 0.6, 0.9, 0.2]], np.float32)           # the last one: x2 < x1 (a flipped crop, as TF allows)
+    idx = np.array([0, 1, 1, 0, 0, 1])
+    for ch, cw in ((7, 7), (14, 14), (1, 3), (28, 28)):
+        got = orc.crop_and_resize(torch.tensor(img), boxes, idx, ch, cw).numpy()
+        for n, (b, bi) in enumerate(zip(boxes.astype(np.float64), idx)):
+            ys = b[0] * (H - 1) + np.arange(ch) * (b[2] - b[0]) * (H - 1) / (ch - 1) if ch > 1 else np.array([0.5 * (b[0] + b[2]) * (H - 1)])
+            xs = b[1] * (W - 1) + np.arange(cw) * (b[3] - b[1]) * (W - 1) / (cw - 1) if cw > 1 else np.array([0.5 * (b[1] + b[3]) * (W - 1)])
+            coords = np.stack(np.meshgrid(ys, xs, indexing="ij"))
+            for c in range(C):
+                want = ndimage.map_coordinates(img[bi, :, :, c].astype(np.float64), coords, order=1, mode="constant", cval=0.0)
+                np.testing.assert_allclose(got[n, :, :, c], want, rtol=0, atol=2e-5, err_msg="box %d crop %dx%d" % (n, ch, cw))
