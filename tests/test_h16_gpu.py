@@ -470,32 +470,38 @@ def test_conv_fwd_h16_small_tile(dev, case, dtype):
         del os.environ["MRCNN_H16_SMALL"]
 
 
-def test_cfg5_r101_512_f16_training_step_vs_oracle(dev):
-    """BASELINE configs[4] at its real sizes: ResNet-101+FPN 512x512, 512 train ROIs, 2000 proposals (2 images here: the
-    float32 CPU oracle has to differentiate the same step), engine in its widest 16-bit mode (mask head, FPN smoothing,
-    shared RPN convolution, class-head FC layers and all 33 bottleneck blocks on the f16 MFMA; float32
-    master weights / accumulation / gradients, loss scale 4096).  Against the FLOAT32 oracle's autograd on the ROIs and
-    targets the engine sampled (fed to the oracle, as in test_cfg2 / cfg3):
-      losses rtol 2e-2; every parameter gradient L2 error <= 8e-2 of its norm, median over tensors <= 2.5e-2
-    (float16 keeps 11 significant bits per stored activation / gradient; ReLU-boundary flips move single elements by
-    more, which is why the bound is on the L2 norm -- see test_mixed_precision_training_step)."""
+@pytest.mark.parametrize("dtype,loss_rtol,l2_max,l2_median", [(torch.float16, 5e-3, 8e-2, 2.5e-2), (torch.bfloat16, 2e-2, 2.5e-1, 8e-2)],
+                         ids=["float16", "bfloat16"])
+def test_cfg5_r101_512_f16_training_step_vs_oracle(dev, dtype, loss_rtol, l2_max, l2_median):
+    """BASELINE configs[4] at its real sizes: ResNet-101+FPN 512x512, nimg_per_gpu = 4, 512 train ROIs, 2000 proposals (round 3:
+    all four images of a rank's batch and both 16-bit types; round 2 ran two images in float16), engine in its widest 16-bit
+    mode (mask head, FPN smoothing, shared RPN convolution, class-head FC layers and all 33 bottleneck blocks on the 16-bit
+    MFMA; float32 master weights / accumulation / gradients, loss scale 4096 for float16).  Against the FLOAT32 oracle's
+    autograd on the ROIs and targets the engine sampled (fed to the oracle, as in test_cfg2 / cfg3):
+      float16:  losses rtol 5e-3; every parameter gradient L2 error <= 8e-2 of its norm, median over tensors <= 2.5e-2
+                (measured: 2.1e-4; max 5.6e-2; median 1.2e-2)
+      bfloat16: 2e-2; 2.5e-1; 8e-2 (8 significant bits per stored activation / gradient instead of 11; measured 2.2e-3; 1.25e-1; 4.8e-2)
+    (ReLU-boundary flips move single elements by more, which is why the bound is on the L2 norm -- see
+    test_mixed_precision_training_step)."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import test_engine_gpu as T
     from caesar_mrcnn_amd.model import MaskRCNN
-    cfg = T._full_cfg("resnet101", 512, nimg=2)
-    B = 2
+    cfg = T._full_cfg("resnet101", 512, nimg=4)
+    B = 4
     w = T._weights(cfg, 61, damp=0.25)
     inputs, keys = T._train_inputs(cfg, B, 63)
     images, meta, rpn_match, rpn_bbox_t, gt_cls, gt_boxes, gt_masks = inputs
     model = MaskRCNN("training", cfg, "/tmp/mrcnn_logs", device=dev, weights=w)
     eng = model.engine
-    eng.head_dtype = torch.float16
+    eng.head_dtype = dtype
     eng.sparse_mask_bwd = True
     losses = model.train_on_batch(inputs, rand_keys=keys, apply=False, keep_outputs=True)
     torch.cuda.synchronize()
     assert sum(eng._h16_block(b) for st in eng.stages for b in st) == 33          # every bottleneck block of ResNet-101
     last = {k: v.cpu().numpy() for k, v in eng.last.items() if torch.is_tensor(v)}
-    assert (last["counts"][:, 0] > 0).all(), last["counts"]
+    # positives in (nearly) every image: with random weights one of four tiles may get no proposal of IoU >= 0.5 -- it then
+    # contributes no ROI at all (DetectionTargetLayer's ratio rule), which the oracle reproduces from the forced targets
+    assert (last["counts"][:, 0] > 0).sum() >= B - 1 and last["counts"][:, 0].sum() >= 8, last["counts"]
     eng.apply_gradients(0.0, 0.0, world_size=1)
     torch.cuda.synchronize()
     g = eng.get_weights(grads=True)
@@ -507,17 +513,20 @@ def test_cfg5_r101_512_f16_training_step_vs_oracle(dev):
     ref = o.forward_training(images, rpn_match, rpn_bbox_t.astype(np.float32), gt_cls, gt_boxes, gt_masks,
                              meta[:, 12:].astype(np.int32), orc.get_anchors(cfg, images.shape[1:]), keys, forced=forced)
     o.total_loss(ref["losses"]).backward()
-    np.testing.assert_allclose(losses.cpu().numpy(), [float(l.detach()) for l in ref["losses"]], rtol=2e-2, atol=1e-4)
+    want = np.array([float(l.detach()) for l in ref["losses"]])
     l2s, bad = [], []
     for name in names:
         rg = o.w[name].grad.numpy().astype(np.float64)
         d = g[name].astype(np.float64) - rg
         l2 = float(np.linalg.norm(d)) / max(float(np.linalg.norm(rg)), 1e-12)
         l2s.append(l2)
-        if l2 > 8e-2:
+        if l2 > l2_max:
             bad.append((name, l2))
+    print("[cfg5 %s, %d images] losses max rel error %.2e; gradient L2 error over %d tensors: median %.2e, max %.2e" % (
+        dtype, B, float(np.max(np.abs(losses.cpu().numpy() - want) / np.maximum(np.abs(want), 1e-4))), len(l2s), np.median(l2s), np.max(l2s)))
+    np.testing.assert_allclose(losses.cpu().numpy(), want, rtol=loss_rtol, atol=1e-4)
     assert not bad, bad[:8]
-    assert np.median(l2s) <= 2.5e-2, np.median(l2s)
+    assert np.median(l2s) <= l2_median, np.median(l2s)
 
 
 @pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
