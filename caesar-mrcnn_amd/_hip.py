@@ -119,6 +119,8 @@ _SIGNATURES = {
     "mrcnn_roialign_fwd": (C.c_int, [C.POINTER(RoiAlignDesc)] + [_P] * 8),
     "mrcnn_roialign_bwd": (C.c_int, [C.POINTER(RoiAlignDesc)] + [_P] * 7),
     "mrcnn_roialign_bwd_gather": (C.c_int, [C.POINTER(RoiAlignDesc)] + [_P] * 7),
+    "mrcnn_roialign_fwd_h16": (C.c_int, [C.POINTER(RoiAlignDesc), C.c_int] + [_P] * 7),
+    "mrcnn_roialign_bwd_h16": (C.c_int, [C.POINTER(RoiAlignDesc), C.c_int, _P, _P, C.c_float] + [_P] * 5),
     "mrcnn_proposal_workspace": (C.c_size_t, [C.POINTER(ProposalDesc)]),
     "mrcnn_proposal_status_offset": (C.c_size_t, [C.POINTER(ProposalDesc), _P, C.POINTER(C.c_size_t)]),
     "mrcnn_proposal_fwd": (C.c_int, [C.POINTER(ProposalDesc)] + [_P] * 8 + [C.c_size_t, _P]),

@@ -143,6 +143,134 @@ extern "C" int mrcnn_roialign_bwd(const mrcnn_roialign_desc* d, const float* box
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 16-bit form (BASELINE configs[4]: 16-bit activations): the pyramid levels and the pooled output are float16 / bfloat16,
+// the interpolation runs in float32 and is rounded once.  Same wave-per-bin mapping; a bin's C channels are C * 2 bytes
+// (256 channels: 64 lanes x 8 bytes), so the gather moves half the bytes of the float32 form and the cast passes around it
+// (float32 copies of the pyramid, pooled output back to 16 bits, the gradient up to float32) disappear.  The adjoint reads
+// the 16-bit gradient (scaled by the float16 loss scale; `mul` = 1 / scale divides it out) and adds float32 atomics into
+// the float32 pyramid gradients, zero rows skipped as in the float32 form.
+struct RoiH16Args {
+    const float* boxes; const void* fm[4]; void* out;
+    const void* dout; float* dfm[4];
+    int B, R, P, C;
+    int H[4], W[4];
+    float image_area, mul;
+};
+
+template <typename T, bool BWD>
+__global__ __launch_bounds__(256) void roialign_h16_kernel(const RoiH16Args p) {
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int64_t bin = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t nbins = (int64_t)p.B * p.R * p.P * p.P;
+    if (bin >= nbins) return;
+    const int px = (int)(bin % p.P);
+    const int py = (int)((bin / p.P) % p.P);
+    const int64_t roi = bin / (p.P * p.P);
+    const int b = (int)(roi / p.R);
+    const float* bx = p.boxes + roi * 4;
+    const float y1 = bx[0], x1 = bx[1], y2 = bx[2], x2 = bx[3];
+    const int li = roi_level(y1, x1, y2, x2, p.image_area) - 2;
+    const int H = p.H[li], W = p.W[li];
+    float in_y, in_x;
+    if (p.P > 1) {
+        const float hs = (y2 - y1) * (float)(H - 1) / (float)(p.P - 1);
+        const float ws = (x2 - x1) * (float)(W - 1) / (float)(p.P - 1);
+        in_y = y1 * (float)(H - 1) + (float)py * hs;
+        in_x = x1 * (float)(W - 1) + (float)px * ws;
+    } else {
+        in_y = 0.5f * (y1 + y2) * (float)(H - 1);
+        in_x = 0.5f * (x1 + x2) * (float)(W - 1);
+    }
+    const bool inside = !(in_y < 0.f || in_y > (float)(H - 1) || in_x < 0.f || in_x > (float)(W - 1));
+    const int c4n = p.C >> 2;
+    const int top = inside ? (int)floorf(in_y) : 0, bot = inside ? (int)ceilf(in_y) : 0;
+    const int lef = inside ? (int)floorf(in_x) : 0, rig = inside ? (int)ceilf(in_x) : 0;
+    const float yl = in_y - (float)top, xl = in_x - (float)lef;
+    if (!BWD) {
+        t4* o = (t4*)((T*)p.out + bin * p.C);
+        if (!inside) {
+            for (int c = lane; c < c4n; c += 64) o[c] = (t4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+            return;
+        }
+        const T* base = (const T*)p.fm[li] + (int64_t)b * H * W * p.C;
+        const t4* tl = (const t4*)(base + ((int64_t)top * W + lef) * p.C);
+        const t4* tr = (const t4*)(base + ((int64_t)top * W + rig) * p.C);
+        const t4* bl = (const t4*)(base + ((int64_t)bot * W + lef) * p.C);
+        const t4* br = (const t4*)(base + ((int64_t)bot * W + rig) * p.C);
+        for (int c = lane; c < c4n; c += 64) {
+            const t4 a = tl[c], bq = tr[c], cq = bl[c], dq = br[c];
+            t4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float av = (float)a[e], cv = (float)cq[e];
+                const float t = av + ((float)bq[e] - av) * xl;
+                const float u = cv + ((float)dq[e] - cv) * xl;
+                r[e] = (T)(t + (u - t) * yl);
+            }
+            o[c] = r;
+        }
+    } else {
+        if (!inside) return;
+        float* base = p.dfm[li] + (int64_t)b * H * W * p.C;
+        float* tl = base + ((int64_t)top * W + lef) * p.C;
+        float* tr = base + ((int64_t)top * W + rig) * p.C;
+        float* bl = base + ((int64_t)bot * W + lef) * p.C;
+        float* br = base + ((int64_t)bot * W + rig) * p.C;
+        const T* g = (const T*)p.dout + bin * p.C;
+        const float wtl = (1.f - yl) * (1.f - xl), wtr = (1.f - yl) * xl, wbl = yl * (1.f - xl), wbr = yl * xl;
+        for (int c = lane; c < p.C; c += 64) {
+            const float gv = (float)g[c] * p.mul;
+            if (gv == 0.f) continue;
+            if (wtl != 0.f) atomicAdd(tl + c, gv * wtl);
+            if (wtr != 0.f) atomicAdd(tr + c, gv * wtr);
+            if (wbl != 0.f) atomicAdd(bl + c, gv * wbl);
+            if (wbr != 0.f) atomicAdd(br + c, gv * wbr);
+        }
+    }
+}
+
+static int fill_roi_h16_args(const mrcnn_roialign_desc* d, RoiH16Args& a) {
+    if (!d || d->B <= 0 || d->R <= 0 || d->P <= 0 || d->C <= 0 || (d->C & 3)) return MRCNN_ERR_ARG;
+    a.B = d->B; a.R = d->R; a.P = d->P; a.C = d->C; a.image_area = d->image_area;
+    for (int i = 0; i < 4; ++i) {
+        if (d->H[i] <= 0 || d->W[i] <= 0) return MRCNN_ERR_ARG;
+        a.H[i] = d->H[i]; a.W[i] = d->W[i];
+    }
+    return MRCNN_OK;
+}
+
+extern "C" int mrcnn_roialign_fwd_h16(const mrcnn_roialign_desc* d, int dtype, const float* boxes, const void* fm2, const void* fm3,
+                                      const void* fm4, const void* fm5, void* out, void* stream) {
+    RoiH16Args a = {};
+    int rc = fill_roi_h16_args(d, a);
+    if (rc) return rc;
+    if (!boxes || !fm2 || !fm3 || !fm4 || !fm5 || !out || (dtype != MRCNN_DTYPE_F16 && dtype != MRCNN_DTYPE_BF16)) return MRCNN_ERR_ARG;
+    a.boxes = boxes; a.fm[0] = fm2; a.fm[1] = fm3; a.fm[2] = fm4; a.fm[3] = fm5; a.out = out;
+    const int64_t nbins = (int64_t)a.B * a.R * a.P * a.P;
+    if (dtype == MRCNN_DTYPE_F16)
+        hipLaunchKernelGGL((roialign_h16_kernel<_Float16, false>), dim3((unsigned)cdiv64(nbins, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((roialign_h16_kernel<__bf16, false>), dim3((unsigned)cdiv64(nbins, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    return mrcnn_launch_status();
+}
+
+extern "C" int mrcnn_roialign_bwd_h16(const mrcnn_roialign_desc* d, int dtype, const float* boxes, const void* dout, float multiplier,
+                                      float* dfm2, float* dfm3, float* dfm4, float* dfm5, void* stream) {
+    RoiH16Args a = {};
+    int rc = fill_roi_h16_args(d, a);
+    if (rc) return rc;
+    if (!boxes || !dout || !dfm2 || !dfm3 || !dfm4 || !dfm5 || (dtype != MRCNN_DTYPE_F16 && dtype != MRCNN_DTYPE_BF16)) return MRCNN_ERR_ARG;
+    a.boxes = boxes; a.dout = dout; a.mul = multiplier; a.dfm[0] = dfm2; a.dfm[1] = dfm3; a.dfm[2] = dfm4; a.dfm[3] = dfm5;
+    const int64_t nbins = (int64_t)a.B * a.R * a.P * a.P;
+    if (dtype == MRCNN_DTYPE_F16)
+        hipLaunchKernelGGL((roialign_h16_kernel<_Float16, true>), dim3((unsigned)cdiv64(nbins, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((roialign_h16_kernel<__bf16, true>), dim3((unsigned)cdiv64(nbins, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    return mrcnn_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Gather form of the adjoint (mrcnn_roialign_bwd_gather).  In training every one of the B*R class-head ROIs
 // carries gradient and they pile up on a few thousand pyramid pixels (512 ROIs per image on 64^2 + 32^2 + 16^2
 // pixels at 256^2 inputs): the scatter form issues 4 * 256 float atomics per bin (103 M per step) with ~20-fold

@@ -225,6 +225,7 @@ class MaskRCNNEngine(object):
         self.h16_blocks = os.environ.get("MRCNN_H16_BLOCKS", "1") != "0"   # bottleneck blocks in 16 bits (stage 4)
         self.h16_all_blocks = os.environ.get("MRCNN_H16_ALL_BLOCKS", "1") != "0"   # 0: only the identity blocks of res4 / res5
         self.h16_fused_bwd = os.environ.get("MRCNN_H16_FUSED_BWD", "1") != "0"     # 16-bit data gradients carry the lower layer's epilogue backward
+        self.h16_roialign = os.environ.get("MRCNN_H16_ROIALIGN", "1") != "0"       # ROI heads gather from the 16-bit pyramid (mrcnn_roialign_fwd_h16 / _bwd_h16)
         self._h16 = {}
         # Winograd F(2x2, 3x3) for the float32 3x3 convolutions of the mask head (forward and data gradients): 2.25 x fewer
         # matrix-core flops through three launches per layer; MRCNN_WINOGRAD=0 keeps the direct kernels
@@ -758,6 +759,7 @@ class MaskRCNNEngine(object):
         P2s, tape["fpn_c2p2"] = self.op("fpn_c2p2").forward(C2, res=P3s, res_mode=RES_UP2, train=train)
         names = ("fpn_p2", "fpn_p3", "fpn_p4", "fpn_p5")
         self._p16 = None
+        self._p16_heads = None                     # 16-bit P2..P5 of this pass for the ROI heads' 16-bit ROIAlign (configs[4])
         if all(self._h16_layer(n) for n in names):
             self._ensure_h16()
             outs, p16 = [], []
@@ -768,6 +770,8 @@ class MaskRCNNEngine(object):
             P2, P3, P4, P5 = outs
             P6 = ops.subsample2(P5)
             self._p16 = p16 + [ops.cast_to_h16(P6, self.head_dtype)]
+            if self.h16_roialign and all(t.shape[3] % 4 == 0 for t in p16):
+                self._p16_heads = list(p16)
             return [P2, P3, P4, P5, P6], tape
         res = self._forward_multi([self.op(n) for n in names], [P2s, P3s, P4s, P5s], train=train)
         (P2, P3, P4, P5) = [r[0] for r in res]
@@ -824,11 +828,18 @@ class MaskRCNNEngine(object):
         """fpn_classifier_graph (model.py:986-1039)."""
         cfg = self.cfg
         B, R = rois.shape[0], rois.shape[1]
-        pooled = ops.roialign(rois, fms, cfg.POOL_SIZE, image_area)
-        x = pooled.view(B * R, cfg.POOL_SIZE, cfg.POOL_SIZE, -1)
-        if self._h16_layer("mrcnn_class_conv1") and self._h16_layer("mrcnn_class_conv2"):
+        h16 = self._h16_layer("mrcnn_class_conv1") and self._h16_layer("mrcnn_class_conv2")
+        p16h = getattr(self, "_p16_heads", None) if h16 else None
+        if p16h is not None:                       # 16-bit pyramid -> 16-bit pooled features: no float32 gather, no cast pass
+            x16 = ops.roialign_h16(rois, p16h, cfg.POOL_SIZE, image_area).view(B * R, cfg.POOL_SIZE, cfg.POOL_SIZE, -1)
+        else:
+            pooled = ops.roialign(rois, fms, cfg.POOL_SIZE, image_area)
+            x = pooled.view(B * R, cfg.POOL_SIZE, cfg.POOL_SIZE, -1)
+        if h16:
             self._ensure_h16()
-            h1, c1 = self._h16_fwd(self.op("mrcnn_class_conv1"), ops.cast_to_h16(x, self.head_dtype), ACT_RELU, train)
+            if p16h is None:
+                x16 = ops.cast_to_h16(x, self.head_dtype)
+            h1, c1 = self._h16_fwd(self.op("mrcnn_class_conv1"), x16, ACT_RELU, train)
             h2_16, c2 = self._h16_fwd(self.op("mrcnn_class_conv2"), h1, ACT_RELU, train)
             h2 = ops.cast_from_h16(h2_16)                        # the 4- / 16-column output layers stay float32
         else:
@@ -844,8 +855,13 @@ class MaskRCNNEngine(object):
         """build_fpn_mask_graph (model.py:1042-1091)."""
         cfg = self.cfg
         B, R = rois.shape[0], rois.shape[1]
-        pooled = ops.roialign(rois, fms, cfg.MASK_POOL_SIZE, image_area)
-        x = pooled.view(B * R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1)
+        p16h = getattr(self, "_p16_heads", None) if self.head_dtype is not None else None
+        if p16h is not None:
+            x = None
+            x16 = ops.roialign_h16(rois, p16h, cfg.MASK_POOL_SIZE, image_area).view(B * R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1)
+        else:
+            pooled = ops.roialign(rois, fms, cfg.MASK_POOL_SIZE, image_area)
+            x = pooled.view(B * R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1)
         ctxs = []
         if self.head_dtype is None and self.winograd_split and self.wgrad_stream is not None and x.shape[0] >= 512 and \
                 all(self._wino_ok(self.op("mrcnn_mask_conv%d" % i), (x.shape[0] // 2,) + tuple(x.shape[1:3]) + (self.op("mrcnn_mask_conv%d" % i).wshape[2],))
@@ -868,7 +884,7 @@ class MaskRCNNEngine(object):
                 ctxs.append(c)
         else:                                   # 16-bit matrix cores; float32 again from the deconvolution on
             self._ensure_h16()
-            h = ops.cast_to_h16(x, self.head_dtype)
+            h = x16 if p16h is not None else ops.cast_to_h16(x, self.head_dtype)
             for i in range(1, 5):
                 op = self.op("mrcnn_mask_conv%d" % i)
                 z = ops.empty(tuple(h.shape[:3]) + (op.wshape[3],), self.head_dtype, self.dev) if (train and op.bn) else None
@@ -1224,10 +1240,13 @@ class MaskRCNNEngine(object):
                 self._mask_wgrad("h16", xin, dz, op.wshape, op.dw, 1.0 / S)
                 d16 = ops.conv2d_h16(dz, self._h16[op.name][1], (kh, kw, cout, cin), None, None, None, 1,
                                      ((kh - 1) // 2, (kw - 1) // 2), ACT_NONE)
-            d = ops.cast_from_h16(d16, 1.0 / S)
+            d = None if self.h16_roialign else ops.cast_from_h16(d16, 1.0 / S)
         B, R = rois.shape[0], rois.shape[1]
         if before_adjoint is not None:
             _hip_mod.ev_wait(torch.cuda.current_stream(self.dev), before_adjoint)
+        if self.head_dtype is not None and d is None:     # the 16-bit gradient goes straight into the float32 pyramid gradients
+            ops.roialign_bwd_h16(rois, d16.view(B, R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1), dP, cfg.MASK_POOL_SIZE, area, 1.0 / S)
+            return
         # scatter form here: the gather form measured 2 ms slower on the positive rows (14x14 samples of ~150 overlapping
         # positives: >1000 rows on the hottest pixels) and the dense head relies on the skipping of exactly-zero rows
         ops.roialign_bwd(rois, d.view(B, R, cfg.MASK_POOL_SIZE, cfg.MASK_POOL_SIZE, -1), dP, cfg.MASK_POOL_SIZE, area)
@@ -1460,7 +1479,7 @@ class MaskRCNNEngine(object):
     # =========================================================================================
     _MODE_ATTRS = ("sparse_mask_bwd", "h16_wide", "h16_blocks", "h16_all_blocks", "h16_fused_bwd", "h16_phase_bwd", "winograd",
                    "winograd_wgrad", "winograd_split", "fused_mask_out_bwd", "fused_dgrad_epilogue", "defer_mask_wgrad",
-                   "gather_roialign_bwd", "multi_launch")
+                   "gather_roialign_bwd", "multi_launch", "h16_roialign")
 
     def _mode_key(self):
         """Every engine switch a captured graph / recorded launch tape bakes in besides the tensors: a replay is only valid for the

@@ -437,6 +437,27 @@ def roialign_bwd(boxes, dout, dfms, pool, image_area, dense=False):
                                         ptr(dfms[3]), current_stream()), "mrcnn_roialign_bwd")
 
 
+def roialign_h16(boxes, fms16, pool, image_area):
+    """PyramidROIAlign on 16-bit pyramid levels -> 16-bit [B,R,pool,pool,C] (interpolation in float32, one rounding)."""
+    _need_cuda(boxes, *fms16)
+    dt = fms16[0].dtype
+    assert dt in _H16 and all(f.dtype == dt and f.is_contiguous() for f in fms16)
+    d = _roi_desc(boxes, fms16, pool, image_area)
+    out = empty((d.B, d.R, pool, pool, d.C), dt, boxes.device)
+    check(_hip.lib().mrcnn_roialign_fwd_h16(C.byref(d), _H16[dt], ptr(boxes), ptr(fms16[0]), ptr(fms16[1]), ptr(fms16[2]), ptr(fms16[3]),
+                                            ptr(out), current_stream()), "mrcnn_roialign_fwd_h16")
+    return out
+
+
+def roialign_bwd_h16(boxes, dout16, dfms, pool, image_area, multiplier=1.0):
+    """Scatter-add the 16-bit gradient dout16 [B,R,pool,pool,C] * multiplier into the float32 gradient maps dfms."""
+    _need_cuda(boxes, dout16, *dfms)
+    assert dout16.dtype in _H16 and dout16.is_contiguous()
+    d = _roi_desc(boxes, dfms, pool, image_area)
+    check(_hip.lib().mrcnn_roialign_bwd_h16(C.byref(d), _H16[dout16.dtype], ptr(boxes), ptr(dout16), float(multiplier), ptr(dfms[0]),
+                                            ptr(dfms[1]), ptr(dfms[2]), ptr(dfms[3]), current_stream()), "mrcnn_roialign_bwd_h16")
+
+
 def proposals(rpn_probs, rpn_bbox, anchors, pre_nms_limit, proposal_count, nms_threshold, std_dev, debug=False):
     """ProposalLayer. rpn_probs [B,A,2], rpn_bbox [B,A,4], anchors [A,4] (normalised) -> rois [B,count,4]."""
     _need_cuda(rpn_probs, rpn_bbox, anchors)

@@ -248,6 +248,13 @@ int mrcnn_roialign_bwd(const mrcnn_roialign_desc* d, const float* boxes, const f
  * MRCNN_ERR_UNSUPPORTED, nothing launched); same values as mrcnn_roialign_bwd up to fp32 summation order.          */
 int mrcnn_roialign_bwd_gather(const mrcnn_roialign_desc* d, const float* boxes, const float* dout, float* dfm2,
                               float* dfm3, float* dfm4, float* dfm5, void* stream);
+/* The same with 16-bit pyramid levels and a 16-bit pooled output (BASELINE configs[4]; dtype MRCNN_DTYPE_F16 / _BF16):
+ * interpolation in float32, one rounding.  The adjoint reads the 16-bit gradient (times `multiplier`, e.g. 1 / loss scale)
+ * and adds float32 atomics into the float32 pyramid gradients.                                                        */
+int mrcnn_roialign_fwd_h16(const mrcnn_roialign_desc* d, int dtype, const float* boxes, const void* fm2, const void* fm3,
+                           const void* fm4, const void* fm5, void* out, void* stream);
+int mrcnn_roialign_bwd_h16(const mrcnn_roialign_desc* d, int dtype, const float* boxes, const void* dout, float multiplier,
+                           float* dfm2, float* dfm3, float* dfm4, float* dfm5, void* stream);
 
 /* ProposalLayer (mrcnn/model.py:329-406): per image, scores = rpn_probs[:, 1]; top-k(min(pre_nms, A),
  * sorted, ties -> lower index); decode with deltas*std; clip to [0,1]; greedy NMS (IoU > thr

@@ -564,3 +564,39 @@ def test_conv_dgrad_ep_h16_equals_two_launches(dev, dtype, k, cin, cout, use_res
         assert err <= 2 * TOL[dtype], (name, err)
     for a, b in zip(sums, rs):
         torch.testing.assert_close(a, b, rtol=4 * TOL[dtype], atol=4 * TOL[dtype] * float(b.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("pool", [7, 14])
+def test_roialign_h16_fwd_bwd(dev, dtype, pool):
+    """mrcnn_roialign_fwd_h16 / _bwd_h16 (configs[4]: the ROI heads gather from the 16-bit pyramid) against the float32 ORACLE
+    (PyramidROIAlign, mrcnn/model.py:428-534) evaluated on the same 16-bit-rounded inputs: the interpolation runs in float32 and
+    is rounded once, so forward outputs agree to one rounding of the result (2^-10 / 2^-7 relative to the largest corner
+    value); the adjoint adds float32 atomics of (16-bit gradient x multiplier) -- equal to the oracle's gradient of the rounded
+    dout up to float32 summation order.  ROIs on all four levels, one partly outside the map, zero-padded rows."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_kernels_gpu as K
+    ops = _ops()
+    rng = np.random.default_rng(pool + (0 if dtype == torch.float16 else 100))
+    B, R, C = 2, 60, 256
+    area = 1024.0 * 1024.0
+    fm16 = [torch.tensor(K._rand(rng, B, s, s, C)).to(dtype) for s in (64, 32, 16, 8)]
+    fms = [f.float().requires_grad_(True) for f in fm16]                       # the oracle sees exactly the rounded values
+    rois = K._random_rois(rng, B, R, zero_tail=3)
+    rois[0, 0] = [0.2, 0.2, 1.2, 0.7]
+    ref = orc.pyramid_roi_align(rois, fms, pool, area)
+    got = ops.roialign_h16(torch.tensor(rois, device=dev), [f.to(dev) for f in fm16], pool, area)
+    torch.cuda.synchronize()
+    assert got.dtype == dtype and tuple(got.shape) == tuple(ref.shape)
+    eps = 2.0 ** -10 if dtype == torch.float16 else 2.0 ** -7
+    err = (got.float().cpu() - ref.detach()).abs().max().item()
+    assert err <= eps * float(max(f.abs().max() for f in fms)) * 1.01, err
+    S = 64.0
+    dout16 = (torch.tensor(K._rand(rng, *ref.shape)) * S).to(dtype)
+    dout16[1, 5] = 0                                                              # an all-zero row: skipped by the adjoint
+    ref.backward(dout16.float() / S)
+    dfm = [torch.full((B, s, s, C), 0.5, device=dev) for s in (64, 32, 16, 8)]   # accumulates onto what the maps hold
+    ops.roialign_bwd_h16(torch.tensor(rois, device=dev), dout16.to(dev), dfm, pool, area, multiplier=1.0 / S)
+    torch.cuda.synchronize()
+    for a, f in zip(dfm, fms):
+        torch.testing.assert_close(a.cpu() - 0.5, f.grad, rtol=1e-4, atol=1e-4)
