@@ -619,7 +619,8 @@ def measure_config4(args, rank, local_rank, world):
 
     out = {"workload": "BASELINE.json configs[4]: resnet101+FPN 512x512, nimg_per_gpu=4, train step, 16-bit weights/activations "
                        "on the 16-bit MFMA where built (mask head, FPN smoothing, shared RPN conv, class FCs, every bottleneck "
-                       "block), float32 elsewhere (stem, laterals, small output layers); float32 master weights and gradients, "
+                       "block; both ROIAlign gathers and the mask head's ROIAlign adjoint read / write 16-bit tensors), float32 elsewhere "
+                       "(stem, FPN laterals, the 4- to 16-column output layers, the class head's gather-form ROIAlign adjoint); float32 master weights and gradients, "
                        "loss scale 4096 + guarded optimiser step (f16)",
            "unit": "images/s"}
     steps = max(5, args.steps // 2)
