@@ -163,6 +163,7 @@ _SIGNATURES = {
     "mrcnn_winograd_output_g": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(WinoGroup), _P]),
     "mrcnn_winograd_output_bwd_g": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.POINTER(WinoGroup), _P]),
+    "mrcnn_winograd_output_bwd_zmask_g": (C.c_int, [_P] * 10 + [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(WinoGroup), _P]),
     "mrcnn_winograd_dy_g": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(WinoGroup), _P]),
     "mrcnn_winograd_dw_g": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_deconv2x2_gemm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

@@ -242,7 +242,8 @@ __global__ __launch_bounds__(256) void winograd_output_bwd_kernel(const float* _
                                                                   const float* __restrict__ scale, const float* __restrict__ mean,
                                                                   const float* __restrict__ rstd, float* dgamma, float* dbeta, float* dbias,
                                                                   int N, int H, int W, int C, long long T, long long Tp, int act,
-                                                                  long long tiles_per_block, int lg, const WinoGrp g) {
+                                                                  long long tiles_per_block, int lg, const WinoGrp g,
+                                                                  const float* __restrict__ fwd_shift) {
     typedef typename WinoVec<CV>::type vec;
     constexpr int ITH = OTH + 2, ITW = OTW + 2;
     __shared__ float sacc[3 * 4 * 256];
@@ -254,11 +255,16 @@ __global__ __launch_bounds__(256) void winograd_output_bwd_kernel(const float* _
     const long long t0 = (long long)blockIdx.x * tiles_per_block;
     long long t1 = t0 + tiles_per_block;
     if (t1 > T) t1 = T;
-    vec sc, mu = {}, rs = {};
+    vec sc, mu = {}, rs = {}, fsh = {};
 #pragma unroll
     for (int e = 0; e < CV; ++e) sc[e] = 1.f;
     if (scale) sc = *(const vec*)(scale + c);
     if (dgamma) { mu = *(const vec*)(mean + c); rs = *(const vec*)(rstd + c); }
+    // fwd_shift: the ReLU mask is taken from the stored pre-BN value -- out > 0 <=> scale * z + shift > 0, the very expression
+    // (operation for operation, no contraction) the forward epilogue fed to max(., 0) -- so the activated output of the layer
+    // below is not read at all: one of the pass's four tensor streams (0.41 of 2.25 GB per mask-head layer) gone, same bits
+    const bool zmask = fwd_shift != nullptr;
+    if (zmask) fsh = *(const vec*)(fwd_shift + c);
     vec a_db = {}, a_dg = {}, a_bias = {};
     for (long long t = t0 + rsub; t < t1; t += R) {
         const WinoTile q = wino_tile(t, g.th_n, g.tw_n);
@@ -283,17 +289,25 @@ __global__ __launch_bounds__(256) void winograd_output_bwd_kernel(const float* _
                 const int ow = g.ow0 + OTW * q.tw + b;
                 if (ow >= W) continue;
                 const long long addr = (((long long)q.n * H + oh) * W + ow) * C + c;
-                vec gg = y[b], dz;
+                vec gg = y[b], dz, zz = {};
+                if (dgamma || zmask) zz = *(const vec*)(below_z + addr);
                 if (act == MRCNN_ACT_RELU) {
-                    const vec oo = *(const vec*)(below_out + addr);
+                    if (zmask) {
 #pragma unroll
-                    for (int e = 0; e < CV; ++e) gg[e] = oo[e] > 0.f ? gg[e] : 0.f;
+                        for (int e = 0; e < CV; ++e) {
+                            const float v = sc[e] * zz[e] + fsh[e];
+                            gg[e] = v > 0.f ? gg[e] : 0.f;
+                        }
+                    } else {
+                        const vec oo = *(const vec*)(below_out + addr);
+#pragma unroll
+                        for (int e = 0; e < CV; ++e) gg[e] = oo[e] > 0.f ? gg[e] : 0.f;
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < CV; ++e) dz[e] = gg[e] * sc[e];
                 *(vec*)(dz_out + addr) = dz;
                 if (dgamma) {
-                    const vec zz = *(const vec*)(below_z + addr);
 #pragma unroll
                     for (int e = 0; e < CV; ++e) a_dg[e] += gg[e] * (zz[e] - mu[e]) * rs[e];
                 }
@@ -617,11 +631,30 @@ extern "C" int mrcnn_winograd_output_g(const float* Mt, float* out, float* z, co
     return mrcnn_launch_status();
 }
 
+static int wino_output_bwd_g(const float* Mt, float* dz_below, const float* below_out, const float* below_z, const float* scale,
+                             const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H,
+                             int W, int C, int act, const mrcnn_wino_group* g, void* stream, const float* fwd_shift);
+
 extern "C" int mrcnn_winograd_output_bwd_g(const float* Mt, float* dz_below, const float* below_out, const float* below_z, const float* scale,
                                            const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H,
                                            int W, int C, int act, const mrcnn_wino_group* g, void* stream) {
+    return wino_output_bwd_g(Mt, dz_below, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, N, H, W, C, act, g, stream, nullptr);
+}
+
+/* the same for a ReLU layer below whose forward epilogue was out = max(scale * z + shift, 0): the mask comes from z (bit for bit
+ * the forward's decision), `out` is never read */
+extern "C" int mrcnn_winograd_output_bwd_zmask_g(const float* Mt, float* dz_below, const float* below_z, const float* scale,
+                                                 const float* shift, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                                                 float* dbias, int N, int H, int W, int C, const mrcnn_wino_group* g, void* stream) {
+    if (!below_z || !scale || !shift) return MRCNN_ERR_ARG;
+    return wino_output_bwd_g(Mt, dz_below, nullptr, below_z, scale, mean, rstd, dgamma, dbeta, dbias, N, H, W, C, MRCNN_ACT_RELU, g, stream, shift);
+}
+
+static int wino_output_bwd_g(const float* Mt, float* dz_below, const float* below_out, const float* below_z, const float* scale,
+                             const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H,
+                             int W, int C, int act, const mrcnn_wino_group* g, void* stream, const float* fwd_shift) {
     if (!Mt || !dz_below || !wino_grp_ok(g, N, H, W, C)) return MRCNN_ERR_ARG;
-    if ((act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) || (act == MRCNN_ACT_RELU && !below_out)) return MRCNN_ERR_ARG;
+    if ((act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) || (act == MRCNN_ACT_RELU && !below_out && !fwd_shift)) return MRCNN_ERR_ARG;
     if (dgamma && (!below_z || !mean || !rstd)) return MRCNN_ERR_ARG;
     const int cv = wino_grp_cv(g);
     const int cn = C / cv;
@@ -635,7 +668,7 @@ extern "C" int mrcnn_winograd_output_bwd_g(const float* Mt, float* dz_below, con
     const dim3 grid((unsigned)cdiv64(T, per));
     const WinoGrp k = {g->th_n, g->tw_n, g->oh0, g->ow0};
     WINO_LAUNCH_G(winograd_output_bwd_kernel, g, grid, grid, Mt, dz_below, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, N, H, W,
-                  C, T, wino_rows(T), act, per, lg, k);
+                  C, T, wino_rows(T), act, per, lg, k, fwd_shift);
     return mrcnn_launch_status();
 }
 

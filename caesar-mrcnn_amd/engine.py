@@ -1219,7 +1219,8 @@ class MaskRCNNEngine(object):
                     if wino and self.fused_dgrad_epilogue and below.bn is not None:
                         _, bz, bout, bact = bctx
                         dz = ops.conv2d_dgrad_ep_winograd(dz, self._wino_U(op, 1, dz.shape), bout if bact != ACT_NONE else None, bz, below.scale,
-                                                          below.mean, below.rstd, below.dgamma, below.dbeta, below.db, bact)
+                                                          below.mean, below.rstd, below.dgamma, below.dbeta, below.db, bact,
+                                                          fwd_shift=below.shift)
                     elif wino:
                         dz = below.epilogue_bwd(ops.conv2d_winograd(dz, self._wino_U(op, 1, dz.shape)), bctx)[0]
                     else:

@@ -894,16 +894,27 @@ def conv2d_winograd(x, U, bias=None, scale=None, shift=None, act=ACT_NONE, out=N
     return out
 
 
-def conv2d_dgrad_ep_winograd(dz, Ut, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, act):
+_WINO_ZMASK = os.environ.get("MRCNN_WINOGRAD_ZMASK", "1") != "0"       # ReLU mask of the layer below from its stored z (its `out` is not read)
+
+
+def conv2d_dgrad_ep_winograd(dz, Ut, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, act, fwd_shift=None):
     """Data gradient of a 3 x 3 'same' convolution (Ut = winograd_weights of the flipped / transposed kernel) fused with the
-    epilogue backward of the layer below: returns dz_below, channel sums are added to dgamma / dbeta / dbias."""
-    _need_cuda(dz, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias)
+    epilogue backward of the layer below: returns dz_below, channel sums are added to dgamma / dbeta / dbias.
+    fwd_shift: the shift of the layer below's forward epilogue out = max(scale * z + shift, 0) -- with it (and z, scale) the ReLU
+    mask is recomputed from z, bit for bit the forward's decision, and below_out is not read (18 % of the pass's bytes)."""
+    _need_cuda(dz, below_out, below_z, scale, mean, rstd, dgamma, dbeta, dbias, fwd_shift)
     N, H, W, _ = dz.shape
     cout = (Ut[0] if isinstance(Ut, (list, tuple)) else Ut).shape[2]
     out = empty((N, H, W, cout), torch.float32, dz.device)
     lib = _hip.lib()
+    zmask = _WINO_ZMASK and act == ACT_RELU and fwd_shift is not None and below_z is not None and scale is not None
 
     def finish(g, Mt):
+        if zmask:
+            check(lib.mrcnn_winograd_output_bwd_zmask_g(ptr(Mt), ptr(out), ptr(below_z), ptr(scale), ptr(fwd_shift), ptr(mean), ptr(rstd),
+                                                        ptr(dgamma), ptr(dbeta), ptr(dbias), N, H, W, cout, C.byref(g), current_stream()),
+                  "mrcnn_winograd_output_bwd_zmask_g")
+            return
         check(lib.mrcnn_winograd_output_bwd_g(ptr(Mt), ptr(out), ptr(below_out), ptr(below_z), ptr(scale), ptr(mean), ptr(rstd),
                                               ptr(dgamma), ptr(dbeta), ptr(dbias), N, H, W, cout, act, C.byref(g), current_stream()),
               "mrcnn_winograd_output_bwd_g")

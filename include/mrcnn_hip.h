@@ -476,6 +476,11 @@ int mrcnn_winograd_output_g(const float* Mt, float* out, float* z_out, const flo
 int mrcnn_winograd_output_bwd_g(const float* Mt, float* dz_below, const float* below_out, const float* below_z, const float* scale,
                                 const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H, int W,
                                 int C, int act, const mrcnn_wino_group* g, void* stream);
+/* The same when the layer below is a ReLU layer with a frozen-BN affine (forward epilogue out = max(scale * z + shift, 0)): the
+ * ReLU mask is recomputed from the stored z with the forward's own expression, so the activated output is not read. */
+int mrcnn_winograd_output_bwd_zmask_g(const float* Mt, float* dz_below, const float* below_z, const float* scale, const float* shift,
+                                      const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H,
+                                      int W, int C, const mrcnn_wino_group* g, void* stream);
 int mrcnn_winograd_dy_g(const float* dy, float* dM, int N, int H, int W, int C, const mrcnn_wino_group* g, void* stream);
 int mrcnn_winograd_dw_g(const float* dU, float* dw_hwio, int Cin, int Cout, int accumulate, int oth, int otw, void* stream);
 

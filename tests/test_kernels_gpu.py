@@ -168,6 +168,22 @@ def test_conv_winograd(dev, case):
     torch.testing.assert_close(got, ref, **tol(ref))
     for a, r in zip(sums, rs):
         torch.testing.assert_close(a, r, rtol=2e-4, atol=2e-4 * float(r.abs().max()))
+    # round 3: the ReLU mask recomputed from the stored z (mrcnn_winograd_output_bwd_zmask_g) instead of read from the
+    # activated output: with (z, out) a real forward pair -- out = max(scale * z + shift, 0), including values exactly on the
+    # boundary -- dz must equal the out-reading form bit for bit, and the channel sums up to the order of their atomics
+    shift = torch.tensor(rng.uniform(-0.3, 0.3, Cin).astype(np.float32), device=dev)
+    zf = torch.tensor(_rand(rng, N, H, W, Cin), device=dev)
+    zf[0, 0, 0, :] = -shift / scale                                   # scale * z + shift == 0 (or within an ulp of it)
+    outf = torch.clamp_min(scale * zf + shift, 0.0)                   # the forward epilogue's expression (torch: mul, add, max -- no fma)
+    Ut = ops.winograd_weights(wflip, tile=tile)
+    s1 = [torch.zeros(Cin, device=dev) for _ in range(3)]
+    s2 = [torch.zeros(Cin, device=dev) for _ in range(3)]
+    a_ = ops.conv2d_dgrad_ep_winograd(dz, Ut, outf, zf, scale, mean, rstd, s1[0], s1[1], s1[2], 1)
+    b_ = ops.conv2d_dgrad_ep_winograd(dz, Ut, None, zf, scale, mean, rstd, s2[0], s2[1], s2[2], 1, fwd_shift=shift)
+    torch.cuda.synchronize()
+    assert torch.equal(a_, b_) and float(a_.abs().max()) > 0 and float((a_ == 0).float().mean()) > 0.2
+    for u, v in zip(s1, s2):
+        torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-5 * float(v.abs().max()))
 
 
 def test_winograd_gemm_tiles_agree(dev, monkeypatch):
