@@ -444,7 +444,8 @@ extern "C" int mrcnn_proposal_fwd(const mrcnn_proposal_desc* d, const float* rpn
     a.pre_ws = reinterpret_cast<unsigned*>(a.cand_ws + (size_t)d->B * SORT_CAP);
     hipStream_t s = (hipStream_t)stream;
     // pre-selection over many workgroups when one workgroup would have to walk > 32 anchors per thread four times
-    a.pre_groups = d->A >= 32 * K1_THREADS ? (int)((d->A + 4095) / 4096 < PRE_MAXG ? (d->A + 4095) / 4096 : PRE_MAXG) : 0;
+    static const long long pre_min = getenv("MRCNN_TOPK_PRE_MIN") ? atoll(getenv("MRCNN_TOPK_PRE_MIN")) : 32 * K1_THREADS;   // A/B
+    a.pre_groups = d->A >= pre_min && d->A > K ? (int)((d->A + 4095) / 4096 < PRE_MAXG ? (d->A + 4095) / 4096 : PRE_MAXG) : 0;
     if (a.pre_groups) {
         const int chunk = (d->A + a.pre_groups - 1) / a.pre_groups;
         const dim3 grid(a.pre_groups, d->B);

@@ -111,6 +111,11 @@ class RcclComm(object):
             self.handle = C.c_void_p()
 
 
+def _reraise(why):
+    from . import _hip
+    return _hip.HipPathError("gradient exchange set-up failed: %s" % why)
+
+
 class GradReducer(object):
     """Sums a flat gradient tensor over ranks, range by range, on a side stream.
 
@@ -137,14 +142,36 @@ class GradReducer(object):
         self.comm = self.scratch = None
         if self.mode in ("rccl", "direct"):
             rank = (dist.get_rank() if dist.is_initialized() else 0) if rank is None else rank
-            self.comm = RcclComm(rank, world_size, flat_grads.device)
-            self.algo = 1 if self.mode == "direct" else 0
-            if self.algo == 1:
-                longest = self.max_floats or flat_grads.numel()
-                nbytes = self.comm.lib.mrcnn_allreduce_scratch(world_size, min(longest, flat_grads.numel()), 1)
-                self.scratch = torch.empty(max(nbytes // 4, 64), dtype=torch.float32, device=flat_grads.device)
-            # neither form has run on more than one GPU of this pool: the first thing a communicator does is prove itself
-            self.comm.self_test(flat_grads.device, self.algo, self.scratch, self.stream)
+            why = None
+            try:
+                self.comm = RcclComm(rank, world_size, flat_grads.device)
+                self.algo = 1 if self.mode == "direct" else 0
+                if self.algo == 1:
+                    longest = self.max_floats or flat_grads.numel()
+                    nbytes = self.comm.lib.mrcnn_allreduce_scratch(world_size, min(longest, flat_grads.numel()), 1)
+                    self.scratch = torch.empty(max(nbytes // 4, 64), dtype=torch.float32, device=flat_grads.device)
+                # neither form has run on more than one GPU of this pool: the first thing a communicator does is prove itself
+                self.comm.self_test(flat_grads.device, self.algo, self.scratch, self.stream)
+            except Exception as e:                      # decided TOGETHER below: one rank must not leave the others in a collective
+                why = repr(e)
+            if world_size > 1 and dist.is_initialized():
+                ok = torch.tensor([0.0 if why else 1.0], device=flat_grads.device)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if float(ok.item()) == 0.0:
+                    # still RCCL over xGMI (torch.distributed's own communicator), never a host path: the step keeps its overlap
+                    if rank == 0:
+                        import sys
+                        sys.stderr.write("[mrcnn] gradient exchange through the C-ABI (%s) failed its start-up check on some rank%s; "
+                                         "every rank falls back to torch.distributed.all_reduce\n" % (self.mode, ": " + why if why else ""))
+                    if self.comm is not None:
+                        try:
+                            self.comm.close()
+                        except Exception:
+                            pass
+                    self.comm = self.scratch = None
+                    self.mode = "torch"
+            elif why:
+                raise _reraise(why)
 
     def ready(self, start, end):
         """Called by the engine when grads[start:end] are final.  Stream hand-offs go through _hip.ev_record / ev_wait and the
