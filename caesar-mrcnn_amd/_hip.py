@@ -59,6 +59,13 @@ class WinoGroup(C.Structure):
     _fields_ = [("oth", C.c_int), ("otw", C.c_int), ("th_n", C.c_int), ("tw_n", C.c_int), ("oh0", C.c_int), ("ow0", C.c_int)]
 
 
+class WinoFuse(C.Structure):
+    """mrcnn_wino_fuse (include/mrcnn_hip.h): the output transform fused into mrcnn_winograd_gemm_fused."""
+    _fields_ = [(n, C.c_int32) for n in ("mode", "N", "H", "W", "act")] + [("g", WinoGroup)] + \
+               [(n, C.c_void_p) for n in ("out", "z", "bias", "scale", "shift", "below_out", "below_z", "mean", "rstd", "dgamma", "dbeta",
+                                          "dbias", "counters")]
+
+
 class BwdEpilogue(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("out", "z", "scale", "mean", "rstd", "dgamma", "dbeta", "dbias")] + [
         ("act", C.c_int32), ("dy", C.c_void_p)]
@@ -164,6 +171,7 @@ _SIGNATURES = {
     "mrcnn_winograd_output_bwd_g": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                              C.POINTER(WinoGroup), _P]),
     "mrcnn_winograd_output_bwd_zmask_g": (C.c_int, [_P] * 10 + [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(WinoGroup), _P]),
+    "mrcnn_winograd_gemm_fused": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(WinoFuse), _P]),
     "mrcnn_winograd_dy_g": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(WinoGroup), _P]),
     "mrcnn_winograd_dw_g": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "mrcnn_deconv2x2_gemm": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

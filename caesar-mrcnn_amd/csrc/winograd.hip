@@ -10,6 +10,7 @@
 // only, and H and W must be even (mask head: 14 x 14); the 4 x 4 tile takes any extent (its last tiles hang over the edge).
 #include "common.h"
 #include <type_traits>
+#include <string.h>
 
 // ---- the 1-D transforms, m = OT outputs per tile and dimension (IT = OT + 2 inputs) -------------------------------------------
 // OT = 2: B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1], G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1], A^T = [1 1 1 0; 0 1 -1 -1].
@@ -178,18 +179,14 @@ __global__ __launch_bounds__(256) void winograd_weight_kernel(const float* __res
 }
 
 // A^T m A (OTH x OTW outputs of one tile) + epilogue: z = y + bias (stored when asked), out = act(scale z + shift)
+// wino_output_tile: tile t x CV channels from c on; shared by the stand-alone kernel and by the GEMM's fused epilogue
 template <int OTH, int OTW, int CV>
-__global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ Mt, float* __restrict__ out, float* __restrict__ z,
-                                                              const float* __restrict__ bias, const float* __restrict__ scale,
-                                                              const float* __restrict__ shift, int N, int H, int W, int C, long long T,
-                                                              long long Tp, int act, const WinoGrp g) {
+__device__ __forceinline__ void wino_output_tile(const float* __restrict__ Mt, float* __restrict__ out, float* __restrict__ z,
+                                                 const typename WinoVec<CV>::type bi, const typename WinoVec<CV>::type sc,
+                                                 const typename WinoVec<CV>::type sh, int H, int W, int C, long long Tp, int act,
+                                                 const WinoGrp& g, long long t, int c) {
     typedef typename WinoVec<CV>::type vec;
     constexpr int ITH = OTH + 2, ITW = OTW + 2;
-    const int cn = C / CV;
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (i >= T * cn) return;
-    const long long t = i / cn;
-    const int c = (int)(i - t * cn) * CV;
     const WinoTile q = wino_tile(t, g.th_n, g.tw_n);
     vec s[OTH][ITW];
 #pragma unroll
@@ -201,11 +198,6 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
 #pragma unroll
         for (int a = 0; a < OTH; ++a) s[a][k] = o[a];
     }
-    vec bi = {}, sc, sh = {};
-#pragma unroll
-    for (int e = 0; e < CV; ++e) sc[e] = 1.f;
-    if (bias) bi = *(const vec*)(bias + c);
-    if (scale) { sc = *(const vec*)(scale + c); sh = *(const vec*)(shift + c); }
 #pragma unroll
     for (int a = 0; a < OTH; ++a) {
         vec y[OTW];
@@ -231,11 +223,91 @@ __global__ __launch_bounds__(256) void winograd_output_kernel(const float* __res
     }
 }
 
+template <int OTH, int OTW, int CV>
+__global__ __launch_bounds__(256) void winograd_output_kernel(const float* __restrict__ Mt, float* __restrict__ out, float* __restrict__ z,
+                                                              const float* __restrict__ bias, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int N, int H, int W, int C, long long T,
+                                                              long long Tp, int act, const WinoGrp g) {
+    typedef typename WinoVec<CV>::type vec;
+    const int cn = C / CV;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= T * cn) return;
+    const long long t = i / cn;
+    const int c = (int)(i - t * cn) * CV;
+    vec bi = {}, sc, sh = {};
+#pragma unroll
+    for (int e = 0; e < CV; ++e) sc[e] = 1.f;
+    if (bias) bi = *(const vec*)(bias + c);
+    if (scale) { sc = *(const vec*)(scale + c); sh = *(const vec*)(shift + c); }
+    wino_output_tile<OTH, OTW, CV>(Mt, out, z, bi, sc, sh, H, W, C, Tp, act, g, t, c);
+}
+
 // The output transform of a DATA gradient fused with the epilogue backward of the layer below (what mrcnn_conv2d_dgrad_ep does
 // for the direct kernel): y = A^T m A is d(loss)/d(activated output of the layer below);
 //   g = y * act'(out_below);  dz = g * scale_below -> stored;  dbeta += sum g, dgamma += sum g (z_below - mean) rstd, dbias += sum dz.
 // A workgroup walks a range of tiles: lane = CV-channel group (C / CV of them, a power of two <= 256), 256 / (C / CV) tiles in
 // flight; channel sums stay in registers, meet in LDS and leave as one atomic per channel and workgroup.
+// one tile x CV channels of the data-gradient output transform + epilogue backward; the channel sums go to the caller's registers
+template <int OTH, int OTW, int CV>
+__device__ __forceinline__ void wino_output_bwd_tile(const float* __restrict__ Mt, float* __restrict__ dz_out, const float* __restrict__ below_out,
+                                                     const float* __restrict__ below_z, const typename WinoVec<CV>::type sc,
+                                                     const typename WinoVec<CV>::type mu, const typename WinoVec<CV>::type rs,
+                                                     const typename WinoVec<CV>::type fsh, bool zmask, bool want_dg, int H, int W, int C,
+                                                     long long Tp, int act, const WinoGrp& g, long long t, int c,
+                                                     typename WinoVec<CV>::type& a_db, typename WinoVec<CV>::type& a_dg,
+                                                     typename WinoVec<CV>::type& a_bias) {
+    typedef typename WinoVec<CV>::type vec;
+    constexpr int ITH = OTH + 2, ITW = OTW + 2;
+    const WinoTile q = wino_tile(t, g.th_n, g.tw_n);
+    vec s[OTH][ITW];
+#pragma unroll
+    for (int k = 0; k < ITW; ++k) {
+        vec col[ITH], o[OTH];
+#pragma unroll
+        for (int r = 0; r < ITH; ++r) col[r] = *(const vec*)(Mt + ((long long)(r * ITW + k) * Tp + t) * C + c);
+        wino_at<OTH>(col, o);
+#pragma unroll
+        for (int a = 0; a < OTH; ++a) s[a][k] = o[a];
+    }
+#pragma unroll
+    for (int a = 0; a < OTH; ++a) {
+        vec y[OTW];
+        wino_at<OTW>(s[a], y);
+        const int oh = g.oh0 + OTH * q.th + a;
+        if (oh >= H) continue;
+#pragma unroll
+        for (int b = 0; b < OTW; ++b) {
+            const int ow = g.ow0 + OTW * q.tw + b;
+            if (ow >= W) continue;
+            const long long addr = (((long long)q.n * H + oh) * W + ow) * C + c;
+            vec gg = y[b], dz, zz = {};
+            if (want_dg || zmask) zz = *(const vec*)(below_z + addr);
+            if (act == MRCNN_ACT_RELU) {
+                if (zmask) {
+#pragma unroll
+                    for (int e = 0; e < CV; ++e) {
+                        const float v = sc[e] * zz[e] + fsh[e];
+                        gg[e] = v > 0.f ? gg[e] : 0.f;
+                    }
+                } else {
+                    const vec oo = *(const vec*)(below_out + addr);
+#pragma unroll
+                    for (int e = 0; e < CV; ++e) gg[e] = oo[e] > 0.f ? gg[e] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < CV; ++e) dz[e] = gg[e] * sc[e];
+            *(vec*)(dz_out + addr) = dz;
+            if (want_dg) {
+#pragma unroll
+                for (int e = 0; e < CV; ++e) a_dg[e] += gg[e] * (zz[e] - mu[e]) * rs[e];
+            }
+#pragma unroll
+            for (int e = 0; e < CV; ++e) { a_db[e] += gg[e]; a_bias[e] += dz[e]; }
+        }
+    }
+}
+
 template <int OTH, int OTW, int CV>
 __global__ __launch_bounds__(256) void winograd_output_bwd_kernel(const float* __restrict__ Mt, float* __restrict__ dz_out,
                                                                   const float* __restrict__ below_out, const float* __restrict__ below_z,
@@ -266,56 +338,9 @@ __global__ __launch_bounds__(256) void winograd_output_bwd_kernel(const float* _
     const bool zmask = fwd_shift != nullptr;
     if (zmask) fsh = *(const vec*)(fwd_shift + c);
     vec a_db = {}, a_dg = {}, a_bias = {};
-    for (long long t = t0 + rsub; t < t1; t += R) {
-        const WinoTile q = wino_tile(t, g.th_n, g.tw_n);
-        vec s[OTH][ITW];
-#pragma unroll
-        for (int k = 0; k < ITW; ++k) {
-            vec col[ITH], o[OTH];
-#pragma unroll
-            for (int r = 0; r < ITH; ++r) col[r] = *(const vec*)(Mt + ((long long)(r * ITW + k) * Tp + t) * C + c);
-            wino_at<OTH>(col, o);
-#pragma unroll
-            for (int a = 0; a < OTH; ++a) s[a][k] = o[a];
-        }
-#pragma unroll
-        for (int a = 0; a < OTH; ++a) {
-            vec y[OTW];
-            wino_at<OTW>(s[a], y);
-            const int oh = g.oh0 + OTH * q.th + a;
-            if (oh >= H) continue;
-#pragma unroll
-            for (int b = 0; b < OTW; ++b) {
-                const int ow = g.ow0 + OTW * q.tw + b;
-                if (ow >= W) continue;
-                const long long addr = (((long long)q.n * H + oh) * W + ow) * C + c;
-                vec gg = y[b], dz, zz = {};
-                if (dgamma || zmask) zz = *(const vec*)(below_z + addr);
-                if (act == MRCNN_ACT_RELU) {
-                    if (zmask) {
-#pragma unroll
-                        for (int e = 0; e < CV; ++e) {
-                            const float v = sc[e] * zz[e] + fsh[e];
-                            gg[e] = v > 0.f ? gg[e] : 0.f;
-                        }
-                    } else {
-                        const vec oo = *(const vec*)(below_out + addr);
-#pragma unroll
-                        for (int e = 0; e < CV; ++e) gg[e] = oo[e] > 0.f ? gg[e] : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < CV; ++e) dz[e] = gg[e] * sc[e];
-                *(vec*)(dz_out + addr) = dz;
-                if (dgamma) {
-#pragma unroll
-                    for (int e = 0; e < CV; ++e) a_dg[e] += gg[e] * (zz[e] - mu[e]) * rs[e];
-                }
-#pragma unroll
-                for (int e = 0; e < CV; ++e) { a_db[e] += gg[e]; a_bias[e] += dz[e]; }
-            }
-        }
-    }
+    for (long long t = t0 + rsub; t < t1; t += R)
+        wino_output_bwd_tile<OTH, OTW, CV>(Mt, dz_out, below_out, below_z, sc, mu, rs, fsh, zmask, dgamma != nullptr, H, W, C, Tp, act, g, t, c,
+                                           a_db, a_dg, a_bias);
 #pragma unroll
     for (int k = 0; k < CV; ++k) {
         if (dbeta || dgamma) atomicAdd(&sacc[lane * CV + k], a_db[k]);
@@ -411,15 +436,39 @@ struct GemmDeconvEp {
     const float* bias;
     int Cd, H, W, act;
     FastDiv d_hw, d_w;
+    int nb_order;        // > 0: tiles are walked ROW-BLOCK-major (row block b = tile / nb_order outermost, the nb_order matrices
+                         // xi = tile % nb_order inside): all xi of a row block finish close together (fused output transform)
 };
 
-template <int TN, bool DECONV>      // TN 2: 128 x 128 tile (5 workgroups per CU); 4: 128 x 256 tile -- N = 256 whole: every V row block is fetched once
-__global__ __launch_bounds__(256, 2) void winograd_gemm_kernel(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ Mt,
+// FUSE (round 3): the OUTPUT transform of a 4 x 4 tile group inside the GEMM launch.  Tiles are walked row-block-major
+// (GemmDeconvEp::nb_order), so the 36 products of a 128-tile row block finish close together; every workgroup counts its
+// finished tile into the row block's counter and the one whose count completes the block -- nobody waits for anybody --
+// transforms those 128 tiles right there: A^T m A + the forward epilogue (FUSE 1) or the epilogue backward of the layer below
+// (FUSE 2), the code of the stand-alone kernels (wino_output_tile / wino_output_bwd_tile).  The separate launch disappears and
+// its memory pass runs beside the MFMAs of the two other workgroups of the CU, which a separate kernel cannot (the GEMM's
+// workgroups hold 3 x 166 of a SIMD's 512 registers: no transform wave becomes resident beside them).  Mt still goes through
+// memory (36 x 128 x 256 floats per row block do not fit a CU), freshly written and read back from L2 / Infinity Cache.
+// Cross-workgroup hand-off as MI355X_MICROARCH.md prescribes: every storing wave waits vmcnt(0), workgroup barrier, ONE lane
+// releases at agent scope, waits, adds to the counter (agent scope); the last arriver acquires at agent scope, waits,
+// workgroup barrier, then plain loads.  The counter returns to zero by the last arriver's store.
+struct WinoFuseArgs {
+    int H, W, C, act, per_block;
+    long long T, Tp;
+    WinoGrp g;
+    float* out; float* z;
+    const float* bias; const float* scale; const float* shift;
+    const float* below_out; const float* below_z; const float* mean; const float* rstd;
+    float* dgamma; float* dbeta; float* dbias;
+    int* counters;
+};
+
+template <int TN, bool DECONV, int FUSE = 0>      // TN 2: 128 x 128 tile (5 workgroups per CU); 4: 128 x 256 tile -- N = 256 whole: every V row block is fetched once
+__global__ __launch_bounds__(256, FUSE ? 3 : 2) void winograd_gemm_kernel(const float* __restrict__ V, const float* __restrict__ U, float* __restrict__ Mt,
                                                                int rows, int K, int N, int total_tiles, unsigned v_records,
-                                                               const GemmDeconvEp ep) {
+                                                               const GemmDeconvEp ep, const WinoFuseArgs fz) {   // FUSE: three workgroups per CU as the plain wide tile (168 VGPRs)
     constexpr int BM = 128, BN = 64 * TN, BK = 16, TM = 2;
     constexpr int AF = BM * BK, BF = BK * BN;
-    __shared__ __attribute__((aligned(16))) float lds[2 * (AF + BF)];
+    __shared__ __attribute__((aligned(16))) float lds[2 * (AF + BF) + 4];       // + one word: the fused transform's "this workgroup was last" flag
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -434,7 +483,12 @@ __global__ __launch_bounds__(256, 2) void winograd_gemm_kernel(const float* __re
                                                           // hipcc drop the kernel's host stub (build.py checks for that)
     int m0 = 0, n0 = 0;
     auto setup = [&](int tile) {
-        const int mtile = tile / ntiles, ntile = tile - mtile * ntiles;
+        int mtile = tile / ntiles;
+        const int ntile = tile - mtile * ntiles;
+        if (ep.nb_order > 0) {                                                 // (b, xi) -> row tile xi * (rows / BM) + b
+            const int b = mtile / ep.nb_order, xi = mtile - b * ep.nb_order;
+            mtile = xi * (rows / BM) + b;
+        }
         m0 = mtile * BM; n0 = ntile * BN;
         const unsigned wbase = (unsigned)(((long long)(m0 / rows) * K * N + n0) * 4);      // the tile's weight matrix (U [nb][K][N], < 2 GiB)
 #pragma unroll
@@ -499,7 +553,12 @@ __global__ __launch_bounds__(256, 2) void winograd_gemm_kernel(const float* __re
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    // FUSE: the zeroing must stay HERE -- rotated to the loop's end it would keep 128 dead-but-zero registers alive
+                    // across the fused transform (seen: 131 spilled VGPRs); a volatile definition is not moved
+                    if constexpr (FUSE != 0) asm volatile("v_mov_b32 %0, 0" : "=v"(acc[a][b][r]));
+                    else acc[a][b][r] = 0.f;
+                }
         __syncthreads();
         for (int ks = 0; ks < nk; ks += 2) {
             if (ks + 1 < nk) stage(lds + (AF + BF));
@@ -512,6 +571,7 @@ __global__ __launch_bounds__(256, 2) void winograd_gemm_kernel(const float* __re
             }
         }
         const int mw0 = m0 + wm * 64 + 4 * lh, nw0 = n0 + wn * (32 * TN) + li;   // the tile the accumulators belong to
+        const int m0_cur = m0;
         const int next = tile + (int)gridDim.x;
         const bool more = next < total_tiles;
         if (more) { k0 = 0; setup(next); stage(lds); }                         // its first stage travels under this tile's stores
@@ -555,9 +615,74 @@ __global__ __launch_bounds__(256, 2) void winograd_gemm_kernel(const float* __re
                     }
                 }
         }
+        if constexpr (FUSE != 0) {
+            int* flag = (int*)(lds + 2 * (AF + BF));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's stores of the tile (and the prefetched stage) are out
+            __syncthreads();
+            if (tid == 0) {
+                if (ep.act != 77) {                                            // (77: timing experiment without the release -- results may be stale)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                const int rb = (m0_cur % rows) / BM;
+                const int old = __hip_atomic_fetch_add(fz.counters + rb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int mine = -1;
+                if (old == fz.per_block - 1) {                                 // every tile of the row block has been counted in
+                    mine = rb;
+                    __hip_atomic_store(fz.counters + rb, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                *flag = mine;
+            }
+            __syncthreads();
+            const int rb = *flag;
+            if (rb >= 0) {
+                typedef typename WinoVec<2>::type vec2;
+                const int c = (tid & 127) * 2;                                  // C == 256: 128 channel pairs x 2 tiles in flight
+                const long long tb = (long long)rb * BM + (tid >> 7);
+                if constexpr (FUSE == 1) {
+                    vec2 bi = {}, sc = {1.f, 1.f}, sh = {};
+                    if (fz.bias) bi = *(const vec2*)(fz.bias + c);
+                    if (fz.scale) { sc = *(const vec2*)(fz.scale + c); sh = *(const vec2*)(fz.shift + c); }
+                    for (int it = 0; it < BM / 2; ++it) {
+                        const long long t = tb + 2 * it;
+                        if (t < fz.T) wino_output_tile<4, 4, 2>(Mt, fz.out, fz.z, bi, sc, sh, fz.H, fz.W, fz.C, fz.Tp, fz.act, fz.g, t, c);
+                    }
+                } else {
+                    vec2 sc = {1.f, 1.f}, mu = {}, rs = {}, fsh = {};
+                    if (fz.scale) sc = *(const vec2*)(fz.scale + c);
+                    if (fz.dgamma) { mu = *(const vec2*)(fz.mean + c); rs = *(const vec2*)(fz.rstd + c); }
+                    const bool zmask = fz.shift != nullptr;
+                    if (zmask) fsh = *(const vec2*)(fz.shift + c);
+                    vec2 a_db = {}, a_dg = {}, a_bias = {};
+                    for (int it = 0; it < BM / 2; ++it) {
+                        const long long t = tb + 2 * it;
+                        if (t < fz.T)
+                            wino_output_bwd_tile<4, 4, 2>(Mt, fz.out, fz.below_out, fz.below_z, sc, mu, rs, fsh, zmask, fz.dgamma != nullptr, fz.H,
+                                                          fz.W, fz.C, fz.Tp, fz.act, fz.g, t, c, a_db, a_dg, a_bias);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {                               // two threads per channel, 144 row blocks: a few hundred thousand atomics per layer
+                        if (fz.dbeta) atomicAdd(fz.dbeta + c + e, a_db[e]);
+                        if (fz.dgamma) atomicAdd(fz.dgamma + c + e, a_dg[e]);
+                        if (fz.dbias) atomicAdd(fz.dbias + c + e, a_bias[e]);
+                    }
+                }
+            }
+            __syncthreads();                                                   // the flag word is rewritten at the next tile
+        }
         if (!more) break;
         tile = next;
     }
+}
+
+// Timing experiments only (results are then wrong): MRCNN_WINO_KNOCKOUT = letters of the transform kernels NOT to launch --
+// i (input), o (output), b (output_bwd), y (dy), w (weights / dw).  What the step would cost if those passes were free is the
+// upper bound of any fusion of them into the GEMM.
+static bool wino_knocked(char which) {
+    static const char* k = getenv("MRCNN_WINO_KNOCKOUT");
+    return k && strchr(k, which) != nullptr;
 }
 
 // ---- host side: tile groups ------------------------------------------------------------------------------------------------------
@@ -606,6 +731,7 @@ extern "C" size_t mrcnn_winograd_group_floats(const mrcnn_wino_group* g, int N, 
 
 extern "C" int mrcnn_winograd_input_g(const float* x, float* V, int N, int H, int W, int C, const mrcnn_wino_group* g, void* stream) {
     if (!x || !V || !wino_grp_ok(g, N, H, W, C)) return MRCNN_ERR_ARG;
+    if (wino_knocked('i')) return MRCNN_OK;
     const long long T = wino_grp_tiles(g, N);
     const WinoGrp k = {g->th_n, g->tw_n, g->oh0, g->ow0};
     const dim3 g4((unsigned)cdiv64(T * C / 4, 256)), g2((unsigned)cdiv64(T * C / 2, 256));
@@ -624,6 +750,7 @@ extern "C" int mrcnn_winograd_output_g(const float* Mt, float* out, float* z, co
                                        int N, int H, int W, int C, int act, const mrcnn_wino_group* g, void* stream) {
     if (!Mt || !out || !wino_grp_ok(g, N, H, W, C) || (scale && !shift)) return MRCNN_ERR_ARG;
     if (act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) return MRCNN_ERR_UNSUPPORTED;
+    if (wino_knocked('o')) return MRCNN_OK;
     const long long T = wino_grp_tiles(g, N);
     const WinoGrp k = {g->th_n, g->tw_n, g->oh0, g->ow0};
     const dim3 g4((unsigned)cdiv64(T * C / 4, 256)), g2((unsigned)cdiv64(T * C / 2, 256));
@@ -656,6 +783,7 @@ static int wino_output_bwd_g(const float* Mt, float* dz_below, const float* belo
     if (!Mt || !dz_below || !wino_grp_ok(g, N, H, W, C)) return MRCNN_ERR_ARG;
     if ((act != MRCNN_ACT_NONE && act != MRCNN_ACT_RELU) || (act == MRCNN_ACT_RELU && !below_out && !fwd_shift)) return MRCNN_ERR_ARG;
     if (dgamma && (!below_z || !mean || !rstd)) return MRCNN_ERR_ARG;
+    if (wino_knocked('b')) return MRCNN_OK;
     const int cv = wino_grp_cv(g);
     const int cn = C / cv;
     if (cn > 256 || (cn & (cn - 1))) return MRCNN_ERR_UNSUPPORTED;
@@ -674,6 +802,7 @@ static int wino_output_bwd_g(const float* Mt, float* dz_below, const float* belo
 
 extern "C" int mrcnn_winograd_dy_g(const float* dy, float* dM, int N, int H, int W, int C, const mrcnn_wino_group* g, void* stream) {
     if (!dy || !dM || !wino_grp_ok(g, N, H, W, C)) return MRCNN_ERR_ARG;
+    if (wino_knocked('y')) return MRCNN_OK;
     const long long T = wino_grp_tiles(g, N);
     const WinoGrp k = {g->th_n, g->tw_n, g->oh0, g->ow0};
     const dim3 g4((unsigned)cdiv64(T * C / 4, 256)), g2((unsigned)cdiv64(T * C / 2, 256));
@@ -744,20 +873,62 @@ extern "C" int mrcnn_winograd_gemm(const float* V, const float* U, float* Mt, in
     const char* wenv = getenv("MRCNN_WINOGRAD_GEMM_WIDE_MIN");                  // read per call (tests compare the two tiles)
     const long long wide_min = wenv ? atoll(wenv) : 4096;
     const bool wide = wide_min >= 0 && N % 256 == 0 && (M / 128) * (N / 256) >= wide_min;
-    const GemmDeconvEp none = {};
+    GemmDeconvEp none = {};
+    { const char* oe = getenv("MRCNN_WINOGRAD_GEMM_ORDER"); if (oe && oe[0] == 'b') none.nb_order = nb; }   // A/B: row-block-major tile order
     if (wide) {                                                 // 128 x 256 tiles: 48 KiB LDS, 3 workgroups per CU
         const long long tiles = (M / 128) * (N / 256);
         const long long slots = 3LL * mrcnn_num_cus();
         const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
         hipLaunchKernelGGL((winograd_gemm_kernel<4, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, V, U, Mt, rows, K, N, (int)tiles,
-                           (unsigned)(M * K * 4), none);
+                           (unsigned)(M * K * 4), none, WinoFuseArgs{});
         return mrcnn_launch_status();
     }
     const long long tiles = (M / 128) * (N / 128);
     const long long slots = 5LL * mrcnn_num_cus();
     const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
     hipLaunchKernelGGL((winograd_gemm_kernel<2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, V, U, Mt, rows, K, N, (int)tiles,
-                       (unsigned)(M * K * 4), none);
+                       (unsigned)(M * K * 4), none, WinoFuseArgs{});
+    return mrcnn_launch_status();
+}
+
+/* The 36 transform-domain GEMMs of a 4 x 4 tile group with the group's OUTPUT transform fused into the launch (see
+ * winograd_gemm_kernel, FUSE).  mode 1: forward (A^T m A + bias, frozen-BN affine, activation, optional z); mode 2: data gradient
+ * (epilogue backward of the layer below: ReLU mask from below_out -- or, shift given, from below_z --, BN scale, channel sums).
+ * Needs the wide tile: Cout == 256 (one column tile: a row block is complete after nb tiles), K % 16 == 0, a 4 x 4 group;
+ * MRCNN_ERR_UNSUPPORTED otherwise (the caller runs mrcnn_winograd_gemm + mrcnn_winograd_output*_g).  counters: one int per
+ * 128-row block of a matrix (rows / 128), zero on entry, zero again on exit. */
+extern "C" int mrcnn_winograd_gemm_fused(const float* V, const float* U, float* Mt, int nb, int rows, int K, int N, const mrcnn_wino_fuse* f,
+                                         void* stream) {
+    if (!V || !U || !Mt || !f || nb <= 0 || rows <= 0 || rows % 128 || K <= 0 || K % 16 || N <= 0) return MRCNN_ERR_ARG;
+    if ((f->mode != 1 && f->mode != 2) || !f->out || !f->counters || !wino_grp_ok(&f->g, f->N, f->H, f->W, N)) return MRCNN_ERR_ARG;
+    if (N != 256 || f->g.oth != 4 || f->g.otw != 4 || nb != 36) return MRCNN_ERR_UNSUPPORTED;
+    if (f->act != MRCNN_ACT_NONE && f->act != MRCNN_ACT_RELU) return MRCNN_ERR_UNSUPPORTED;
+    const long long T = wino_grp_tiles(&f->g, f->N);
+    if (wino_rows(T) != rows) return MRCNN_ERR_ARG;
+    if (f->mode == 1 && f->scale && !f->shift) return MRCNN_ERR_ARG;
+    if (f->mode == 2 && ((f->act == MRCNN_ACT_RELU && !f->below_out && !(f->shift && f->below_z && f->scale)) ||
+                         (f->dgamma && (!f->below_z || !f->mean || !f->rstd))))
+        return MRCNN_ERR_ARG;
+    const long long M = (long long)nb * rows;
+    if (M * K * 4 >= 0x7FFFFFF0LL || (long long)nb * K * N * 4 >= 0x7FFFFFF0LL || M * N >= (1LL << 40)) return MRCNN_ERR_UNSUPPORTED;
+    WinoFuseArgs z = {};
+    z.H = f->H; z.W = f->W; z.C = N; z.act = f->act; z.per_block = nb; z.T = T; z.Tp = rows;
+    z.g = {f->g.th_n, f->g.tw_n, f->g.oh0, f->g.ow0};
+    z.out = f->out; z.z = f->z; z.bias = f->bias; z.scale = f->scale; z.shift = f->shift;
+    z.below_out = f->below_out; z.below_z = f->below_z; z.mean = f->mean; z.rstd = f->rstd;
+    z.dgamma = f->dgamma; z.dbeta = f->dbeta; z.dbias = f->dbias; z.counters = f->counters;
+    GemmDeconvEp ep = {};
+    ep.nb_order = nb;
+    if (getenv("MRCNN_WINOGRAD_FUSE_NORELEASE")) ep.act = 77;                  // timing experiments only
+    const long long tiles = M / 128;
+    const long long slots = 3LL * mrcnn_num_cus();
+    const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+    if (f->mode == 1)
+        hipLaunchKernelGGL((winograd_gemm_kernel<4, false, 1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, V, U, Mt, rows, K, N, (int)tiles,
+                           (unsigned)(M * K * 4), ep, z);
+    else
+        hipLaunchKernelGGL((winograd_gemm_kernel<4, false, 2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, V, U, Mt, rows, K, N, (int)tiles,
+                           (unsigned)(M * K * 4), ep, z);
     return mrcnn_launch_status();
 }
 
@@ -780,6 +951,6 @@ extern "C" int mrcnn_deconv2x2_gemm(const float* x, const float* w_gemm, const f
     const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
     const int rows = (int)((M + 127) / 128 * 128);              // one matrix: every tile uses weight matrix 0
     hipLaunchKernelGGL((winograd_gemm_kernel<2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w_gemm, out, rows, Cin, Nn, (int)tiles,
-                       (unsigned)(M * Cin * 4), ep);
+                       (unsigned)(M * Cin * 4), ep, WinoFuseArgs{});
     return mrcnn_launch_status();
 }

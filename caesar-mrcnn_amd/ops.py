@@ -841,7 +841,7 @@ def winograd_weights(w, out=None, tile=2):
     return out
 
 
-def _winograd_run(x, U, finish, keep_v=None, after_input=None):
+def _winograd_run(x, U, finish, keep_v=None, after_input=None, fuse=None):
     """Per tile group: input transform, the group's transform-domain GEMMs, then finish(group, Mt) -- the output transform the caller
     wants.  V of all groups lives in one flat buffer (keep_v: kept for the weight gradient), Mt is a per-stream scratch buffer
     reused group after group (stream order)."""
@@ -866,8 +866,39 @@ def _winograd_run(x, U, finish, keep_v=None, after_input=None):
         if gi == 0 and after_input is not None:
             after_input()                # e.g. an event: a second chain on another stream starts one transform behind this one
         nb = _wino_nb(g)
-        check(gemm(ptr(Vg), ptr(u), ptr(Mt), nb, nvs[gi] // (nb * Cin), Cin, cout, current_stream()), "mrcnn_winograd_gemm")
+        rows = nvs[gi] // (nb * Cin)
+        if fuse is not None and _WINO_FUSE and _WINO_PERSISTENT_GEMM and g.oth == 4 and g.otw == 4 and cout == 256 and \
+                (nb * rows // 128) >= _WINO_FUSE_MIN_TILES:
+            # the group's output transform inside the GEMM launch (mrcnn_winograd_gemm_fused): no second launch, its memory pass runs
+            # beside the other workgroups' MFMAs
+            f = fuse(g)
+            f.counters = ptr(_wino_counters(x.device, rows // 128))
+            rc = lib.mrcnn_winograd_gemm_fused(ptr(Vg), ptr(u), ptr(Mt), nb, rows, Cin, cout, C.byref(f), current_stream())
+            if rc != ERR_UNSUPPORTED:
+                check(rc, "mrcnn_winograd_gemm_fused")
+                continue
+        check(gemm(ptr(Vg), ptr(u), ptr(Mt), nb, rows, Cin, cout, current_stream()), "mrcnn_winograd_gemm")
         finish(g, Mt)
+
+
+# output transform of the 4 x 4 group fused into its GEMM launch (mrcnn_winograd_gemm_fused).  Built, bit-identical to the separate
+# launches (test_winograd_fused_output_equals_unfused) -- and OFF: measured 1.74 -> 5.3 ms per forward layer, 1.88 -> 12 ms per data
+# gradient at 2048 ROIs (tools/wino_fuse_probe.py; 5.15 / 11.1 ms even without the per-tile release fence).  One workgroup
+# transforming a 128-tile row block is a chain of 64 dependent load rounds from the memory side (~0.5 ms), it holds up that
+# workgroup's next tiles and with them the 35 other row blocks they belong to -- DESIGN.md 4.1e
+_WINO_FUSE = os.environ.get("MRCNN_WINOGRAD_FUSE", "0") != "0"
+_WINO_FUSE_MIN_TILES = int(os.environ.get("MRCNN_WINOGRAD_FUSE_MIN_TILES", "1536"))   # GEMM tiles (two rounds of 768 workgroups) from which it pays
+_wino_counter_cache = {}
+
+
+def _wino_counters(device, n):
+    """Row-block counters of mrcnn_winograd_gemm_fused: zero on entry, left zero by the kernel -- one buffer per stream."""
+    key = (str(device), current_stream())
+    t = _wino_counter_cache.get(key)
+    if t is None or t.numel() < n:
+        t = torch.zeros(max(n, 1024), dtype=torch.int32, device=device)
+        _wino_counter_cache[key] = t
+    return t
 
 
 def winograd_v_floats(xshape, tile=None):
@@ -890,7 +921,13 @@ def conv2d_winograd(x, U, bias=None, scale=None, shift=None, act=ACT_NONE, out=N
     def finish(g, Mt):
         check(lib.mrcnn_winograd_output_g(ptr(Mt), ptr(out), ptr(z_out), ptr(bias), ptr(scale), ptr(shift), N, H, W, cout, act, C.byref(g),
                                           current_stream()), "mrcnn_winograd_output_g")
-    _winograd_run(x, U, finish, keep_v, after_input)
+
+    def fuse(g):
+        f = _hip.WinoFuse()
+        f.mode, f.N, f.H, f.W, f.act, f.g = 1, N, H, W, act, g
+        f.out, f.z, f.bias, f.scale, f.shift = ptr(out), ptr(z_out), ptr(bias), ptr(scale), ptr(shift)
+        return f
+    _winograd_run(x, U, finish, keep_v, after_input, fuse if act in (ACT_NONE, ACT_RELU) else None)
     return out
 
 
@@ -918,7 +955,15 @@ def conv2d_dgrad_ep_winograd(dz, Ut, below_out, below_z, scale, mean, rstd, dgam
         check(lib.mrcnn_winograd_output_bwd_g(ptr(Mt), ptr(out), ptr(below_out), ptr(below_z), ptr(scale), ptr(mean), ptr(rstd),
                                               ptr(dgamma), ptr(dbeta), ptr(dbias), N, H, W, cout, act, C.byref(g), current_stream()),
               "mrcnn_winograd_output_bwd_g")
-    _winograd_run(dz, Ut, finish)
+
+    def fuse(g):
+        f = _hip.WinoFuse()
+        f.mode, f.N, f.H, f.W, f.act, f.g = 2, N, H, W, act, g
+        f.out, f.scale, f.shift = ptr(out), ptr(scale), (ptr(fwd_shift) if zmask else None)
+        f.below_out, f.below_z, f.mean, f.rstd = (None if zmask else ptr(below_out)), ptr(below_z), ptr(mean), ptr(rstd)
+        f.dgamma, f.dbeta, f.dbias = ptr(dgamma), ptr(dbeta), ptr(dbias)
+        return f
+    _winograd_run(dz, Ut, finish, fuse=fuse)
     return out
 
 

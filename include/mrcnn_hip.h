@@ -481,6 +481,25 @@ int mrcnn_winograd_output_bwd_g(const float* Mt, float* dz_below, const float* b
 int mrcnn_winograd_output_bwd_zmask_g(const float* Mt, float* dz_below, const float* below_z, const float* scale, const float* shift,
                                       const float* mean, const float* rstd, float* dgamma, float* dbeta, float* dbias, int N, int H,
                                       int W, int C, const mrcnn_wino_group* g, void* stream);
+
+/* The transform-domain GEMMs of a 4 x 4 tile group WITH the group's output transform in the same launch (round 3): tiles are
+ * walked row-block-major, every workgroup counts its finished tile into its row block's counter and the workgroup that completes
+ * a row block transforms its 128 tiles on the spot -- no waiting, no second launch; the transform's memory pass runs beside the
+ * other workgroups' MFMAs.  mode 1 = mrcnn_winograd_gemm + mrcnn_winograd_output_g, mode 2 = mrcnn_winograd_gemm +
+ * mrcnn_winograd_output_bwd_g / _zmask_g (shift != NULL), same results up to the order of the channel-sum atomics.  Cout = 256,
+ * a 4 x 4 group (36 matrices); else MRCNN_ERR_UNSUPPORTED.  counters: rows / 128 ints, zero on entry (left zero).           */
+typedef struct mrcnn_wino_fuse {
+    int32_t mode, N, H, W, act;
+    mrcnn_wino_group g;
+    float* out;              /* mode 1: out [N,H,W,256]; mode 2: dz of the layer below */
+    float* z;                /* mode 1: pre-BN output or NULL */
+    const float* bias; const float* scale; const float* shift;
+    const float* below_out; const float* below_z; const float* mean; const float* rstd;
+    float* dgamma; float* dbeta; float* dbias;
+    int32_t* counters;
+} mrcnn_wino_fuse;
+int mrcnn_winograd_gemm_fused(const float* V, const float* U, float* Mt, int nb, int rows, int K, int N, const mrcnn_wino_fuse* f,
+                              void* stream);
 int mrcnn_winograd_dy_g(const float* dy, float* dM, int N, int H, int W, int C, const mrcnn_wino_group* g, void* stream);
 int mrcnn_winograd_dw_g(const float* dU, float* dw_hwio, int Cin, int Cout, int accumulate, int oth, int otw, void* stream);
 

@@ -186,6 +186,52 @@ def test_conv_winograd(dev, case):
         torch.testing.assert_close(u, v, rtol=1e-5, atol=1e-5 * float(v.abs().max()))
 
 
+@pytest.mark.parametrize("tile", [4, 6])
+def test_winograd_fused_output_equals_unfused(dev, monkeypatch, tile):
+    """mrcnn_winograd_gemm_fused (round 3): the 4 x 4 group's output transform inside the GEMM launch -- row-block-major tile
+    order, per-row-block arrival counters, the last arriver transforms -- against the separate launches on a training-sized layer
+    (640 ROIs of 14 x 14 x 256: 5760 GEMM tiles, 160 row blocks of which the last is ragged for the uniform tiling).  The
+    transform code and the per-tile arithmetic are the same, so: forward out and z BIT-identical; data gradient dz of the layer
+    below bit-identical (ReLU mask from `out` and from z), channel sums equal up to the order of their float atomics.  Run
+    three times over: the counters must come back to zero and a stale Mt of the previous call must never be read."""
+    ops = _ops()
+    rng = np.random.default_rng(5 + tile)
+    N, H, W, C_ = 640, 14, 14, 256
+    x = torch.tensor(_rand(rng, N, H, W, C_), device=dev)
+    w = torch.tensor(_rand(rng, 3, 3, C_, C_, scale=0.03), device=dev)
+    b = torch.tensor(_rand(rng, C_, scale=0.1), device=dev)
+    sc = torch.tensor(rng.uniform(.5, 1.5, C_).astype(np.float32), device=dev)
+    sh = torch.tensor(rng.uniform(-.2, .2, C_).astype(np.float32), device=dev)
+    mean, rstd = (torch.tensor(rng.uniform(0.5, 1.5, C_).astype(np.float32), device=dev) for _ in range(2))
+    U = ops.winograd_weights(w, tile=tile)
+    wflip = torch.empty((3, 3, C_, C_), device=dev)
+    ops.weight_flip_transpose(w, wflip)
+    Ut = ops.winograd_weights(wflip, tile=tile)
+    dz = torch.tensor(_rand(rng, N, H, W, C_), device=dev)
+    monkeypatch.setattr(ops, "_WINO_FUSE_MIN_TILES", 1)
+
+    def run(fused, rep):
+        monkeypatch.setattr(ops, "_WINO_FUSE", fused)
+        xin = x * (1.0 + 0.25 * rep)                                  # a different problem every repetition
+        z = torch.empty((N, H, W, C_), device=dev)
+        y = ops.conv2d_winograd(xin, U, b, sc, sh, 1, z_out=z)
+        sums = [torch.zeros(C_, device=dev) for _ in range(6)]
+        d1 = ops.conv2d_dgrad_ep_winograd(dz, Ut, y, z, sc, mean, rstd, sums[0], sums[1], sums[2], 1)                  # mask from out
+        d2 = ops.conv2d_dgrad_ep_winograd(dz, Ut, None, z, sc, mean, rstd, sums[3], sums[4], sums[5], 1, fwd_shift=sh)  # mask from z
+        torch.cuda.synchronize()
+        return y, z, d1, d2, sums
+    for rep in range(3):
+        want = run(False, rep)
+        got = run(True, rep)
+        for k in range(4):
+            assert torch.equal(got[k], want[k]), (rep, k, float((got[k] - want[k]).abs().max()))
+        assert torch.equal(got[2], got[3]) and float(got[2].abs().max()) > 0
+        for u, v in zip(got[4], want[4]):
+            torch.testing.assert_close(u, v, rtol=2e-5, atol=2e-5 * float(v.abs().max()))
+    for t in ops._wino_counter_cache.values():
+        assert int(t.abs().sum()) == 0                                 # every row-block counter is back at zero
+
+
 def test_winograd_gemm_tiles_agree(dev, monkeypatch):
     """mrcnn_winograd_gemm: the 128 x 256 tile (taken for large products) and the 128 x 128 tile walk K in the same order, so the
     36 products of an F(4x4) layer must agree bit for bit; both against a float64 matmul of three of the matrices."""
