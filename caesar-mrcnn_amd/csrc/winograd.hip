@@ -645,7 +645,8 @@ __global__ __launch_bounds__(256, FUSE ? 3 : 2) void winograd_gemm_kernel(const 
                     vec2 bi = {}, sc = {1.f, 1.f}, sh = {};
                     if (fz.bias) bi = *(const vec2*)(fz.bias + c);
                     if (fz.scale) { sc = *(const vec2*)(fz.scale + c); sh = *(const vec2*)(fz.shift + c); }
-                    for (int it = 0; it < BM / 2; ++it) {
+                    const int itn = ep.Cd > 0 ? ep.Cd - 1 : BM / 2;             // (timing experiments: MRCNN_WINOGRAD_FUSE_ITERS caps the loop)
+                    for (int it = 0; it < itn; ++it) {
                         const long long t = tb + 2 * it;
                         if (t < fz.T) wino_output_tile<4, 4, 2>(Mt, fz.out, fz.z, bi, sc, sh, fz.H, fz.W, fz.C, fz.Tp, fz.act, fz.g, t, c);
                     }
@@ -920,6 +921,7 @@ extern "C" int mrcnn_winograd_gemm_fused(const float* V, const float* U, float* 
     GemmDeconvEp ep = {};
     ep.nb_order = nb;
     if (getenv("MRCNN_WINOGRAD_FUSE_NORELEASE")) ep.act = 77;                  // timing experiments only
+    if (getenv("MRCNN_WINOGRAD_FUSE_ITERS")) ep.Cd = atoi(getenv("MRCNN_WINOGRAD_FUSE_ITERS")) + 1;   // timing experiments only (forward form)
     const long long tiles = M / 128;
     const long long slots = 3LL * mrcnn_num_cus();
     const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
