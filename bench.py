@@ -208,8 +208,8 @@ def _train_loop_leg(args, res, model, cfg, nimg, world, rank, loader_threads=Non
 TRAFFIC_PER_LAUNCH = {1024: None, 2048: 1.810e9}   # mask-head conv, PMC passes: profiles/r01_pmc_conv_traffic.md
 TRAFFIC_WGRAD_PER_LAUNCH = {1024: None, 2048: 4.55e9}   # its weight gradient (same file)
 # (ROIs, tiling) -> HBM-side bytes per launch of the roofline leg's GEMM: 2 x FETCH_SIZE (gfx950 reports half of wide reads, guide) +
-# WRITE_SIZE, separate --pmc passes (profiles/r02_pmc_winograd_gemm.txt); measured for the default tiling only
-TRAFFIC_WINOGRAD_GEMM = {(2048, 6): 1.597e9}
+# WRITE_SIZE, separate --pmc passes (profiles/r03_pmc_winograd_gemm.txt; round 2: 1.597e9); measured for the default tiling only
+TRAFFIC_WINOGRAD_GEMM = {(2048, 6): 1.594e9}
 
 
 def measure(args, backbone, nimg, rank, local_rank, world, full):
