@@ -1188,3 +1188,36 @@ def test_mold_inputs_device_equals_host(dev):
     res_host = model._detect_results(out, [cut.shape], [molded[0].shape], windows)[0]
     for k in ("rois", "class_ids", "scores", "masks"):
         assert np.array_equal(res_dev[k], res_host[k]), k
+
+
+def test_detect_batch_of_two_equals_single_images(dev):
+    """detect() on a batch of two images of different original sizes (both molded to the 256 x 256 canvas on the device) returns,
+    image by image, what two batch-1 calls return: same boxes, class ids, scores and full-size masks -- the per-slot pinned
+    staging buffers, the per-image mrcnn_mask rows and the windows must not mix."""
+    from caesar_mrcnn_amd.config import run_py_config
+    from caesar_mrcnn_amd.model import MaskRCNN
+    from caesar_mrcnn_amd.params import ParamLayout, init_weights
+    rng = np.random.default_rng(41)
+    imgs = [rng.integers(0, 256, (132, 132, 3), dtype=np.uint8), rng.integers(0, 256, (200, 256, 3), dtype=np.uint8)]
+    for im in imgs:                                         # a few bright blobs so that the random network finds something
+        for _ in range(4):
+            y, x = rng.integers(10, im.shape[0] - 30), rng.integers(10, im.shape[1] - 30)
+            im[y:y + 18, x:x + 22] = 250
+    cfg1 = run_py_config(backbone="custom", imgsize=256, mode="inference")
+    cfg1.POST_NMS_ROIS_INFERENCE = 200; cfg1.DETECTION_MAX_INSTANCES = 30
+    w = init_weights(ParamLayout(cfg1), seed=13)
+    m1 = MaskRCNN("inference", cfg1, "/tmp/mrcnn_logs", device=dev, weights=w)
+    singles = [m1.detect([im])[0] for im in imgs]
+    cfg2 = run_py_config(backbone="custom", imgsize=256, mode="inference")
+    cfg2.IMAGES_PER_GPU = 2                                 # (run.py's InferenceConfig pins 1; BATCH_SIZE follows the attribute)
+    cfg2.POST_NMS_ROIS_INFERENCE = 200; cfg2.DETECTION_MAX_INSTANCES = 30
+    assert cfg2.BATCH_SIZE == 2
+    m2 = MaskRCNN("inference", cfg2, "/tmp/mrcnn_logs", device=dev, weights=w)
+    for rep in range(2):                                    # second call: replayed graph, reused staging buffers
+        both = m2.detect(imgs)
+        assert len(both) == 2
+        for got, want, im in zip(both, singles, imgs):
+            assert got["masks"].shape[:2] == im.shape[:2] and got["masks"].dtype == np.bool_
+            for k in ("rois", "class_ids", "scores", "masks"):
+                assert np.array_equal(got[k], want[k]), (rep, k)
+    assert sum(r["rois"].shape[0] for r in singles) > 0
