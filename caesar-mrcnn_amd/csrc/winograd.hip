@@ -875,7 +875,7 @@ extern "C" int mrcnn_winograd_gemm(const float* V, const float* U, float* Mt, in
     const long long wide_min = wenv ? atoll(wenv) : 4096;
     const bool wide = wide_min >= 0 && N % 256 == 0 && (M / 128) * (N / 256) >= wide_min;
     GemmDeconvEp none = {};
-    { const char* oe = getenv("MRCNN_WINOGRAD_GEMM_ORDER"); if (oe && oe[0] == 'b') none.nb_order = nb; }   // A/B: row-block-major tile order
+    { static const char* oe = getenv("MRCNN_WINOGRAD_GEMM_ORDER"); if (oe && oe[0] == 'b') none.nb_order = nb; }   // A/B (once per process): row-block-major tile order
     if (wide) {                                                 // 128 x 256 tiles: 48 KiB LDS, 3 workgroups per CU
         const long long tiles = (M / 128) * (N / 256);
         const long long slots = 3LL * mrcnn_num_cus();
@@ -920,8 +920,11 @@ extern "C" int mrcnn_winograd_gemm_fused(const float* V, const float* U, float* 
     z.dgamma = f->dgamma; z.dbeta = f->dbeta; z.dbias = f->dbias; z.counters = f->counters;
     GemmDeconvEp ep = {};
     ep.nb_order = nb;
-    if (getenv("MRCNN_WINOGRAD_FUSE_NORELEASE")) ep.act = 77;                  // timing experiments only
-    if (getenv("MRCNN_WINOGRAD_FUSE_ITERS")) ep.Cd = atoi(getenv("MRCNN_WINOGRAD_FUSE_ITERS")) + 1;   // timing experiments only (forward form)
+    // timing experiments only (read once per process; the fused path itself is opt-in): no release fence / a capped transform loop
+    static const bool no_release = getenv("MRCNN_WINOGRAD_FUSE_NORELEASE") != nullptr;
+    static const int iters = getenv("MRCNN_WINOGRAD_FUSE_ITERS") ? atoi(getenv("MRCNN_WINOGRAD_FUSE_ITERS")) + 1 : 0;
+    if (no_release) ep.act = 77;
+    if (iters > 0) ep.Cd = iters;
     const long long tiles = M / 128;
     const long long slots = 3LL * mrcnn_num_cus();
     const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
