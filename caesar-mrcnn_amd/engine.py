@@ -231,6 +231,9 @@ class MaskRCNNEngine(object):
         # matrix-core flops through three launches per layer; MRCNN_WINOGRAD=0 keeps the direct kernels
         self.winograd = os.environ.get("MRCNN_WINOGRAD", "1") != "0"
         self.winograd_wgrad = os.environ.get("MRCNN_WINOGRAD_WGRAD", "1") != "0"    # weight gradients through the same domain
+        # the trunk's large 3x3 layers (FPN smoothing, RPN shared convolution on levels of >= 16 384 pixels) through F(2x2, 3x3)
+        # in the forward pass (A/B switch, see DESIGN 4.1e for the measurement)
+        self.trunk_winograd = os.environ.get("MRCNN_WINOGRAD_TRUNK", "1") != "0"
         # forward as two half-batch chains on two streams: +0.7 ms with the F(2x2) layers, level with the uniform F(4x4) tiling, a loss with
         # the mixed tiling (its small tile groups halve again: ResNet-101 / 4 images 37.6 -> 37.4 ms, ResNet-50 / 2 images 20.8 -> 20.0) -> off
         self.winograd_split = os.environ.get("MRCNN_WINOGRAD_SPLIT", "0") != "0"
@@ -539,7 +542,30 @@ class MaskRCNNEngine(object):
 
     # ---- independent small convolutions in one launch (mrcnn_conv2d_fwd_multi) ------------------------
     def _forward_multi(self, layers, xs, act=ACT_NONE, train=False):
-        """[ConvOp.forward(x, act) for layer, x in zip(layers, xs)] as one launch; falls back to the loop."""
+        """[ConvOp.forward(x, act) for layer, x in zip(layers, xs)] as one launch; falls back to the loop.  With trunk_winograd the
+        3 x 3 layers large enough for the Winograd path (FPN smoothing / RPN shared convolution on P2, P3 of big inputs) leave the
+        group and run F(2x2, 3x3) on their own; their training contexts are the direct kernels' (the backward pass is unchanged)."""
+        if self.trunk_winograd and any(self._wino_ok(op, x.shape) for op, x in zip(layers, xs)):
+            res = [None] * len(layers)
+            rest = []
+            for i, (op, x) in enumerate(zip(layers, xs)):
+                if self._wino_ok(op, x.shape):
+                    out = ops.empty(tuple(x.shape[:3]) + (op.wshape[3],), torch.float32, x.device)
+                    z = ops.empty_like(out) if (train and op.bn) else None
+                    V = None
+                    if train and self.winograd_wgrad:       # the input transform is kept: the weight gradient contracts it with A dz A^T
+                        V = ops.empty((ops.winograd_v_floats(tuple(x.shape)),), torch.float32, x.device)
+                        self._wino_V[(op.name, tuple(x.shape))] = V
+                    ops.conv2d_winograd(x, self._wino_U(op, 0, x.shape, train), op.b, op.scale, op.shift, act, out=out, z_out=z, keep_v=V)
+                    res[i] = (out, (x, z, out, act) if train else None)
+                else:
+                    rest.append(i)
+            if rest:
+                sub = self._forward_multi([layers[i] for i in rest], [xs[i] for i in rest], act, train) if len(rest) > 1 else \
+                    [layers[rest[0]].forward(xs[rest[0]], act, train=train)]
+                for i, r in zip(rest, sub):
+                    res[i] = r
+            return res
         if self.multi_launch and 1 < len(layers) <= 5:
             probs, zs = [], []
             for op, x in zip(layers, xs):
@@ -573,6 +599,41 @@ class MaskRCNNEngine(object):
             if ops.conv2d_multi(probs) is not None:
                 return outs
         return [op.dgrad(dz, ctx, out=o, accumulate=a) for op, dz, ctx, o, a in zip(layers, dzs, ctxs, outs, accs)]
+
+    def _bwd_group(self, layers, dzs, ctxs, outs=None, accumulate=False, wgrad_acc=None):
+        """Weight gradients (weight-gradient stream) and data gradients of a group of stride-1 convolutions from their dz.  Layers
+        whose forward went through the Winograd path (trunk_winograd: a kept input transform under (name, input shape)) take it
+        here too -- weight gradient from V, data gradient F(2x2, 3x3) and, where the destination accumulates, one add pass --,
+        the others share the multi-problem launches as before.  wgrad_acc[i]: the layer's weight gradient adds to dw (shared
+        weights: the RPN convolution over the pyramid levels)."""
+        n = len(layers)
+        outs = list(outs) if outs is not None else [None] * n
+        accs = list(accumulate) if isinstance(accumulate, (list, tuple)) else [accumulate] * n
+        wacc = list(wgrad_acc) if wgrad_acc is not None else [False] * n
+        Vs = [self._wino_V.pop((op.name, tuple(c[0].shape)), None) for op, c in zip(layers, ctxs)]
+        rest = [i for i in range(n) if Vs[i] is None]
+        if rest and not any(wacc):                          # independent weights: the direct ones of the group share a launch as before
+            self.wgrad_group([layers[i].wgrad_item(dzs[i], ctxs[i]) for i in rest])
+        for i in range(n):                                  # (shared weights: in layer order, each adding to the one before)
+            if Vs[i] is not None:
+                self._mask_wgrad("wino", Vs[i], tuple(ctxs[i][0].shape), dzs[i], layers[i].dw, wacc[i])
+            elif any(wacc):
+                self.wgrad_async(*layers[i].wgrad_item(dzs[i], ctxs[i], accumulate=wacc[i]))
+        if rest:
+            sub = self._dgrad_multi([layers[i] for i in rest], [dzs[i] for i in rest], [ctxs[i] for i in rest],
+                                    outs=[outs[i] for i in rest], accumulate=[accs[i] for i in rest])
+            for i, o in zip(rest, sub):
+                outs[i] = o
+        for i in range(n):
+            if Vs[i] is None:
+                continue
+            op = layers[i]
+            d = ops.conv2d_winograd(dzs[i], self._wino_U(op, 1, dzs[i].shape))
+            if accs[i]:
+                ops.add_inplace(outs[i], d)
+            else:
+                outs[i] = d
+        return outs
 
     def join_wgrad(self):
         if self.wgrad_stream is not None:
@@ -799,7 +860,10 @@ class MaskRCNNEngine(object):
         if self.multi_launch and len(pyramid) <= 5:
             # the levels are independent and P3..P6 are a handful of workgroups each: one launch per layer for all levels
             if not h16:
-                ss = ops.conv2d_multi([dict(x=p, w=shared.w, bias=shared.b, act=ACT_RELU) for p in pyramid])
+                if self.trunk_winograd and any(self._wino_ok(shared, p.shape) for p in pyramid):
+                    ss = [r[0] for r in self._forward_multi([shared] * len(pyramid), pyramid, ACT_RELU, train)]
+                else:
+                    ss = ops.conv2d_multi([dict(x=p, w=shared.w, bias=shared.b, act=ACT_RELU) for p in pyramid])
             assert ss is not None                       # one weight tensor: the levels always share a launch shape
             offs = []
             for p in pyramid:
@@ -1326,10 +1390,15 @@ class MaskRCNNEngine(object):
                         dP6 = ops.cast_from_h16(dx16, 1.0 / S)
                 return dP6
             dzs, ctxs = [], []
+            wino = any((shared.name, tuple(t[0][0].shape)) in self._wino_V for t in rpn_tape)
             for lvl, (cs, chead, off, H, W) in enumerate(rpn_tape):
                 dz, _ = shared.epilogue_bwd(d_s[lvl], cs)
-                shared.wgrad(dz, cs, accumulate=lvl > 0)
+                if not wino:
+                    shared.wgrad(dz, cs, accumulate=lvl > 0)
                 dzs.append(dz); ctxs.append(cs)
+            if wino:                                        # some level's forward took the Winograd path (trunk_winograd)
+                return self._bwd_group([shared] * n, dzs, ctxs, outs=list(dP[:4]) + [None], accumulate=[True] * 4 + [False],
+                                       wgrad_acc=[lvl > 0 for lvl in range(n)])[4]
             return self._dgrad_multi([shared] * n, dzs, ctxs, outs=list(dP[:4]) + [None], accumulate=[True] * 4 + [False])[4]
         for lvl, (cs, chead, off, H, W) in enumerate(rpn_tape):
             gl = ops.empty((B, H, W, 2 * na), torch.float32, self.dev)
@@ -1366,8 +1435,11 @@ class MaskRCNNEngine(object):
                 op, c = self.op(name), tape[name]
                 dz, _ = op.epilogue_bwd(g, c)
                 layers.append(op); dzs.append(dz); cs.append(c)
-            self.wgrad_group([op.wgrad_item(dz, c) for op, dz, c in zip(layers, dzs, cs)])
-            d5s, d4s, d3s, d2s = self._dgrad_multi(layers, dzs, cs)    # four independent 3x3 data gradients: one launch
+            if any((op.name, tuple(c[0].shape)) in self._wino_V for op, c in zip(layers, cs)):
+                d5s, d4s, d3s, d2s = self._bwd_group(layers, dzs, cs)
+            else:
+                self.wgrad_group([op.wgrad_item(dz, c) for op, dz, c in zip(layers, dzs, cs)])
+                d5s, d4s, d3s, d2s = self._dgrad_multi(layers, dzs, cs)    # four independent 3x3 data gradients: one launch
         ops.upsample2_bwd(d2s, d3s, True)
         ops.upsample2_bwd(d3s, d4s, True)
         ops.upsample2_bwd(d4s, d5s, True)
@@ -1480,7 +1552,7 @@ class MaskRCNNEngine(object):
     # =========================================================================================
     _MODE_ATTRS = ("sparse_mask_bwd", "h16_wide", "h16_blocks", "h16_all_blocks", "h16_fused_bwd", "h16_phase_bwd", "winograd",
                    "winograd_wgrad", "winograd_split", "fused_mask_out_bwd", "fused_dgrad_epilogue", "defer_mask_wgrad",
-                   "gather_roialign_bwd", "multi_launch", "h16_roialign")
+                   "gather_roialign_bwd", "multi_launch", "h16_roialign", "trunk_winograd")
 
     def _mode_key(self):
         """Every engine switch a captured graph / recorded launch tape bakes in besides the tensors: a replay is only valid for the
