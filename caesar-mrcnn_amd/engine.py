@@ -10,6 +10,8 @@ Gradient plumbing conventions
     convolution can add an existing buffer in its epilogue (res_mode SAME, in place);
   * the ROIAlign adjoints scatter-add into zero-initialised pyramid gradients first.
 """
+import contextlib
+import gc
 import os
 import numpy as np
 import torch
@@ -27,6 +29,23 @@ H16_WIDE_LAYERS = ("fpn_p2", "fpn_p3", "fpn_p4", "fpn_p5", "rpn_conv_shared", "m
 
 LOSS_NAMES = ("rpn_class_loss", "rpn_bbox_loss", "mrcnn_class_loss", "mrcnn_bbox_loss", "mrcnn_mask_loss")
 
+
+
+@contextlib.contextmanager
+def _capture(graph):
+    """torch.cuda.graph(graph) with the garbage collector out of the way: this torch no longer collects before a capture
+    (torch.compiler.config.force_cudagraph_gc), and a dead cycle that owns a CUDAGraph, a stream or device memory (an earlier
+    engine) freed by a collection that happens to run INSIDE the capture makes hipGraphExecDestroy / hipFree fail under the global
+    capture mode -- thrown from a destructor, which aborts the process.  Collect before, keep the collector off while capturing."""
+    gc.collect()
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(graph):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 class ConvOp(object):
     """One named Conv2D/Dense(+BatchNorm) layer: views into the flat buffers + fwd/bwd launches."""
@@ -234,6 +253,7 @@ class MaskRCNNEngine(object):
         # the trunk's large 3x3 layers (FPN smoothing, RPN shared convolution on levels of >= 16 384 pixels) through F(2x2, 3x3)
         # in the forward pass (A/B switch, see DESIGN 4.1e for the measurement)
         self.trunk_winograd = os.environ.get("MRCNN_WINOGRAD_TRUNK", "1") != "0"
+        self.trunk_winograd_min_rows = int(os.environ.get("MRCNN_WINOGRAD_TRUNK_MIN_ROWS", "4096"))
         # forward as two half-batch chains on two streams: +0.7 ms with the F(2x2) layers, level with the uniform F(4x4) tiling, a loss with
         # the mixed tiling (its small tile groups halve again: ResNet-101 / 4 images 37.6 -> 37.4 ms, ResNet-50 / 2 images 20.8 -> 20.0) -> off
         self.winograd_split = os.environ.get("MRCNN_WINOGRAD_SPLIT", "0") != "0"
@@ -343,9 +363,15 @@ class MaskRCNNEngine(object):
             ok[which] = True
         return ent[which]
 
-    def _wino_ok(self, op, xshape):
+    def _wino_ok(self, op, xshape, min_rows=None):
         return (self.winograd and self.head_dtype is None and
-                ops.winograd_ok(tuple(xshape), op.wshape, op.stride, op.padding))
+                ops.winograd_ok(tuple(xshape), op.wshape, op.stride, op.padding, min_rows))
+
+    def _wino_trunk_ok(self, op, xshape):
+        """Trunk layers (FPN smoothing, RPN shared convolution) take the F(2x2, 3x3) path from 4 096 pixels on (P3 at 256 x 256
+        x 4 images, P2 at batch-1 detect): measured product default 20.22 -> 20.03 ms, detect 3.14 -> 3.10 ms, ResNet-50 step
+        19.67 -> 19.50 ms, headline level; the mask head keeps its own threshold (ops._WINO_MIN_ROWS)."""
+        return self.trunk_winograd and self._wino_ok(op, xshape, self.trunk_winograd_min_rows)
 
     def _ensure_h16(self):
         """16-bit operand images (W^T and the rotated data-gradient image) of the mask-head convolutions."""
@@ -545,11 +571,11 @@ class MaskRCNNEngine(object):
         """[ConvOp.forward(x, act) for layer, x in zip(layers, xs)] as one launch; falls back to the loop.  With trunk_winograd the
         3 x 3 layers large enough for the Winograd path (FPN smoothing / RPN shared convolution on P2, P3 of big inputs) leave the
         group and run F(2x2, 3x3) on their own; their training contexts are the direct kernels' (the backward pass is unchanged)."""
-        if self.trunk_winograd and any(self._wino_ok(op, x.shape) for op, x in zip(layers, xs)):
+        if self.trunk_winograd and any(self._wino_trunk_ok(op, x.shape) for op, x in zip(layers, xs)):
             res = [None] * len(layers)
             rest = []
             for i, (op, x) in enumerate(zip(layers, xs)):
-                if self._wino_ok(op, x.shape):
+                if self._wino_trunk_ok(op, x.shape):
                     out = ops.empty(tuple(x.shape[:3]) + (op.wshape[3],), torch.float32, x.device)
                     z = ops.empty_like(out) if (train and op.bn) else None
                     V = None
@@ -616,7 +642,7 @@ class MaskRCNNEngine(object):
             self.wgrad_group([layers[i].wgrad_item(dzs[i], ctxs[i]) for i in rest])
         for i in range(n):                                  # (shared weights: in layer order, each adding to the one before)
             if Vs[i] is not None:
-                self._mask_wgrad("wino", Vs[i], tuple(ctxs[i][0].shape), dzs[i], layers[i].dw, wacc[i])
+                self._wino_wgrad_async(Vs[i], tuple(ctxs[i][0].shape), dzs[i], layers[i].dw, wacc[i])   # never deferred: trunk
             elif any(wacc):
                 self.wgrad_async(*layers[i].wgrad_item(dzs[i], ctxs[i], accumulate=wacc[i]))
         if rest:
@@ -649,19 +675,22 @@ class MaskRCNNEngine(object):
         elif kind == "f32":
             self.wgrad_async(*args)
         elif kind == "wino":
-            V, xshape, dz, dw, acc = args
-            ws = self.wgrad_stream
-            if ws is None:
-                ops.conv2d_wgrad_winograd(V, xshape, dz, dw, accumulate=acc)
-                return
-            ev = _hip_mod.ev_record(torch.cuda.current_stream(self.dev))
-            with torch.cuda.stream(ws):
-                _hip_mod.ev_wait(ws, ev)
-                ops.conv2d_wgrad_winograd(V, xshape, dz, dw, accumulate=acc)
-            dz.record_stream(ws)
-            V.record_stream(ws)
+            self._wino_wgrad_async(*args)
         else:
             self.wgrad_h16_async(*args)
+
+    def _wino_wgrad_async(self, V, xshape, dz, dw, acc):
+        """Weight gradient from a kept Winograd input transform, on the weight-gradient stream behind the current one."""
+        ws = self.wgrad_stream
+        if ws is None:
+            ops.conv2d_wgrad_winograd(V, xshape, dz, dw, accumulate=acc)
+            return
+        ev = _hip_mod.ev_record(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(ws):
+            _hip_mod.ev_wait(ws, ev)
+            ops.conv2d_wgrad_winograd(V, xshape, dz, dw, accumulate=acc)
+        dz.record_stream(ws)
+        V.record_stream(ws)
 
     def _flush_deferred(self):
         """Issue the deferred weight gradients on the auxiliary stream, behind everything the main stream has done so far."""
@@ -860,7 +889,7 @@ class MaskRCNNEngine(object):
         if self.multi_launch and len(pyramid) <= 5:
             # the levels are independent and P3..P6 are a handful of workgroups each: one launch per layer for all levels
             if not h16:
-                if self.trunk_winograd and any(self._wino_ok(shared, p.shape) for p in pyramid):
+                if self.trunk_winograd and any(self._wino_trunk_ok(shared, p.shape) for p in pyramid):
                     ss = [r[0] for r in self._forward_multi([shared] * len(pyramid), pyramid, ACT_RELU, train)]
                 else:
                     ss = ops.conv2d_multi([dict(x=p, w=shared.w, bias=shared.b, act=ACT_RELU) for p in pyramid])
@@ -1054,7 +1083,7 @@ class MaskRCNNEngine(object):
                     self.infer(sx, sw)
             _hip_mod.stream_wait(torch.cuda.current_stream(self.dev), side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with _capture(graph):
                 out = self.infer(sx, sw)
             entry = (graph, sx, sw, out)
             self._infer_graphs[key] = entry
@@ -1552,7 +1581,7 @@ class MaskRCNNEngine(object):
     # =========================================================================================
     _MODE_ATTRS = ("sparse_mask_bwd", "h16_wide", "h16_blocks", "h16_all_blocks", "h16_fused_bwd", "h16_phase_bwd", "winograd",
                    "winograd_wgrad", "winograd_split", "fused_mask_out_bwd", "fused_dgrad_epilogue", "defer_mask_wgrad",
-                   "gather_roialign_bwd", "multi_launch", "h16_roialign", "trunk_winograd")
+                   "gather_roialign_bwd", "multi_launch", "h16_roialign", "trunk_winograd", "trunk_winograd_min_rows")
 
     def _mode_key(self):
         """Every engine switch a captured graph / recorded launch tape bakes in besides the tensors: a replay is only valid for the
@@ -1596,7 +1625,7 @@ class MaskRCNNEngine(object):
             _hip_mod.stream_wait(main, side)
             del keep
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with _capture(graph):
                 losses = self.forward_backward(*static)
                 self.apply_gradients(learning_rate, momentum, 1)
             entry = (graph, static, losses)
