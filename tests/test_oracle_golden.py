@@ -268,3 +268,90 @@ def test_oracle_crop_and_resize_matches_scipy_sampler():
             for c in range(C):
                 want = ndimage.map_coordinates(img[bi, :, :, c].astype(np.float64), coords, order=1, mode="constant", cval=0.0)
                 np.testing.assert_allclose(got[n, :, :, c], want, rtol=0, atol=2e-5, err_msg="box %d crop %dx%d" % (n, ch, cw))
+
+
+def test_oracle_sgd_clipnorm_matches_torch_optim():
+    """keras.optimizers.SGD(lr, momentum, clipnorm) (mrcnn/model.py:2260-2262) is restated in oracle.sgd_step [3P, Keras 2.2.4 not
+    installable here].  Second source for its arithmetic: torch.nn.utils.clip_grad_norm_ (one norm over all tensors, every tensor
+    scaled by clipnorm / norm) + torch.optim.SGD(momentum) -- Keras keeps v = m v - lr g, torch buf = m buf + g; with a constant
+    learning rate v = -lr buf, the same trajectory.  Five steps, two with the clip active, one with the norm below the threshold."""
+    import torch
+    rng = np.random.default_rng(11)
+    shapes = {"a/kernel": (3, 3, 8, 16), "a/bias": (16,), "b/gamma": (16,), "c/kernel": (64, 5)}
+    p0 = {k: rng.standard_normal(s).astype(np.float32) for k, s in shapes.items()}
+    params = {k: v.copy() for k, v in p0.items()}
+    vel = {k: np.zeros_like(v) for k, v in p0.items()}
+    tp = {k: torch.nn.Parameter(torch.from_numpy(v.copy())) for k, v in p0.items()}
+    opt = torch.optim.SGD(list(tp.values()), lr=0.01, momentum=0.9)
+    for step, gscale in enumerate((3.0, 0.02, 1.5, 0.05, 4.0)):        # 1 504 elements: norm ~ 38.8 gscale
+        grads = {k: (gscale * rng.standard_normal(s)).astype(np.float32) for k, s in shapes.items()}
+        norm = orc.sgd_step(params, grads, vel, 0.01, 0.9, 5.0)
+        for k in tp:
+            tp[k].grad = torch.from_numpy(grads[k].copy())
+        tnorm = float(torch.nn.utils.clip_grad_norm_(list(tp.values()), 5.0))
+        opt.step()
+        assert abs(norm - tnorm) <= 1e-5 * tnorm
+        assert (norm >= 5.0) == (gscale >= 1.0)                              # steps 0, 2, 4 clip; 1, 3 (norm ~ 0.8, 1.9) do not
+        for k in tp:
+            np.testing.assert_allclose(params[k], tp[k].detach().numpy(), rtol=2e-5, atol=2e-6, err_msg="%s step %d" % (k, step))
+
+
+def test_oracle_loss_primitives_match_torch_functional():
+    """smooth_l1 (mrcnn/model.py:1098-1105) and K.binary_crossentropy (:1259, Keras 2.2.4's clip to [1e-7, 1 - 1e-7] -> logit ->
+    sigmoid cross entropy [3P]) against torch.nn.functional's own statements of the same losses."""
+    import torch
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(5)
+    a, b = torch.randn(4096, generator=g) * 2, torch.randn(4096, generator=g) * 2
+    b[:8] = a[:8] + torch.tensor([1.0, -1.0, 0.0, 0.999999, 1.000001, -0.5, 2.0, -2.0])      # both branches and the |d| = 1 seam
+    np.testing.assert_allclose(orc.smooth_l1(a, b).numpy(), F.smooth_l1_loss(b, a, reduction="none", beta=1.0).numpy(), rtol=1e-6, atol=1e-7)
+    t = (torch.rand(4096, generator=g) > 0.6).float()
+    o = torch.rand(4096, generator=g).double()
+    o[:4] = torch.tensor([0.0, 1.0, 1e-9, 1 - 1e-9], dtype=torch.float64)    # Keras clips these to eps / 1 - eps before the logarithm
+    want = F.binary_cross_entropy(torch.clamp(o, 1e-7, 1 - 1e-7), t.double(), reduction="none")
+    np.testing.assert_allclose(orc.keras_binary_crossentropy(t.double(), o).numpy(), want.numpy(), rtol=1e-9, atol=1e-12)
+    o32 = o.float()
+    got32 = orc.keras_binary_crossentropy(t, o32).numpy()
+    np.testing.assert_allclose(got32[4:], want.numpy()[4:], rtol=2e-5, atol=1e-6)
+
+
+def test_oracle_same_padding_conv_and_pool_match_scipy():
+    """Conv2D / MaxPooling2D padding='same' (mrcnn/model.py:99-210) are TF kernels [3P].  The padding rule is pinned by the worked
+    example of TensorFlow's own documentation of SAME (width 13, filter 6, stride 5 -> 3 outputs, 1 column before, 2 after) and by
+    the backbone's own cases; the arithmetic by scipy: correlate with explicit zero padding, maximum_filter with -inf padding,
+    sampled at the window positions the rule gives."""
+    import torch
+    from scipy import ndimage, signal
+    assert orc.same_pad(13, 6, 5) == (3, 1, 2)
+    assert orc.same_pad(64, 3, 2) == (32, 0, 1) and orc.same_pad(63, 3, 2) == (32, 1, 1) and orc.same_pad(14, 3, 1) == (14, 1, 1)
+    rng = np.random.default_rng(3)
+    for H, W, k, s in ((14, 14, 3, 1), (16, 12, 3, 2), (15, 9, 3, 2), (8, 8, 1, 2)):
+        x = rng.standard_normal((H, W)).astype(np.float64)
+        w = rng.standard_normal((k, k)).astype(np.float64)
+        got = orc.conv2d_nhwc(torch.from_numpy(x)[None, :, :, None], torch.from_numpy(w)[:, :, None, None], None, s, "same")[0, :, :, 0].numpy()
+        oh, pt, pb = orc.same_pad(H, k, s)
+        ow, pl, pr = orc.same_pad(W, k, s)
+        full = signal.correlate2d(np.pad(x, ((pt, pb), (pl, pr))), w, mode="valid")
+        np.testing.assert_allclose(got, full[::s, ::s][:oh, :ow], rtol=1e-12, atol=1e-12)
+    for H, W in ((16, 12), (15, 9)):
+        x = rng.standard_normal((H, W)).astype(np.float32)
+        got = orc.maxpool3x3s2_same(torch.from_numpy(x)[None, :, :, None])[0, :, :, 0].numpy()
+        oh, pt, _ = orc.same_pad(H, 3, 2)
+        ow, pl, _ = orc.same_pad(W, 3, 2)
+        filt = ndimage.maximum_filter(x, size=3, mode="constant", cval=-np.inf)          # window centred on every pixel
+        want = filt[1 - pt::2, 1 - pl::2][:oh, :ow]                                       # window i starts at 2 i - pad_before: centre 2 i + 1 - pad_before
+        np.testing.assert_array_equal(got, want)
+
+
+def test_oracle_transposed_convolution_layout():
+    """KL.Conv2DTranspose(256, (2, 2), strides=2) (mrcnn/model.py:1084): Keras stores the kernel as (kh, kw, out, in); with a 2 x 2
+    kernel and stride 2 no two taps overlap, so out[n, 2i + a, 2j + b, co] = sum_ci x[n, i, j, ci] k[a, b, co, ci] + bias[co] --
+    stated here as one einsum, against the oracle's torch.conv_transpose2d call."""
+    import torch
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((2, 5, 4, 6))
+    k = rng.standard_normal((2, 2, 3, 6))
+    b = rng.standard_normal(3)
+    got = orc.conv2d_transpose_2x2(torch.from_numpy(x), torch.from_numpy(k), torch.from_numpy(b)).numpy()
+    want = np.einsum("nijc,aboc->niajbo", x, k).reshape(2, 10, 8, 3) + b
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-12)
