@@ -27,82 +27,100 @@ __device__ __forceinline__ int roi_level(float y1, float x1, float y2, float x2,
     return l < 2 ? 2 : (l > 5 ? 5 : l);
 }
 
+// Round 3: a wave owns one ROW of bins (roi, py) and walks px: the ROI's level (logf / sqrtf), the row's y sample and every
+// integer division are done once per P bins instead of once per bin -- with one wave per bin those ~300 instructions were
+// what a 1 KiB bin cost (1 300 SIMD cycles per bin in the isolated launch), not its five memory instructions.  The float
+// expressions are the ones of the per-bin form (same operands, same order): results are bit-identical.
 template <bool BWD>
 __global__ __launch_bounds__(256) void roialign_kernel(const RoiArgs p) {
     const int lane = threadIdx.x & 63;
-    const int64_t bin = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nbins = (int64_t)p.B * p.R * p.P * p.P;
-    if (bin >= nbins) return;
-    const int px = (int)(bin % p.P);
-    const int py = (int)((bin / p.P) % p.P);
-    const int64_t roi = bin / (p.P * p.P);       // b*R + r
-    const int b = (int)(roi / p.R);
-    const float* bx = p.boxes + roi * 4;
+    const unsigned row = blockIdx.x * 4u + (threadIdx.x >> 6);               // (roi, py); the host checks B * R * P * P * C < 2^40, rows < 2^31
+    const unsigned nrows = (unsigned)p.B * (unsigned)p.R * (unsigned)p.P;
+    if (row >= nrows) return;
+    const unsigned roi = row / (unsigned)p.P;                                // b * R + r
+    const int py = (int)(row - roi * (unsigned)p.P);
+    const int b = (int)(roi / (unsigned)p.R);
+    const float* bx = p.boxes + (int64_t)roi * 4;
     const float y1 = bx[0], x1 = bx[1], y2 = bx[2], x2 = bx[3];
     const int lvl = roi_level(y1, x1, y2, x2, p.image_area);
     const int li = lvl - 2;
     const int H = p.H[li], W = p.W[li];
-    if (!BWD && p.level_out && py == 0 && px == 0 && lane == 0) p.level_out[roi] = lvl;
+    if (!BWD && p.level_out && py == 0 && lane == 0) p.level_out[roi] = lvl;
 
-    float in_y, in_x;
+    float in_y, ws = 0.f, x0;
     if (p.P > 1) {
         const float hs = (y2 - y1) * (float)(H - 1) / (float)(p.P - 1);
-        const float ws = (x2 - x1) * (float)(W - 1) / (float)(p.P - 1);
+        ws = (x2 - x1) * (float)(W - 1) / (float)(p.P - 1);
         in_y = y1 * (float)(H - 1) + (float)py * hs;
-        in_x = x1 * (float)(W - 1) + (float)px * ws;
+        x0 = x1 * (float)(W - 1);
     } else {
         in_y = 0.5f * (y1 + y2) * (float)(H - 1);
-        in_x = 0.5f * (x1 + x2) * (float)(W - 1);
+        x0 = 0.5f * (x1 + x2) * (float)(W - 1);
     }
-    const bool inside = !(in_y < 0.f || in_y > (float)(H - 1) || in_x < 0.f || in_x > (float)(W - 1));
+    const bool y_inside = !(in_y < 0.f || in_y > (float)(H - 1));
+    const int top = (int)floorf(in_y), bot = (int)ceilf(in_y);
+    const float yl = in_y - (float)top;
     const int c4n = p.C >> 2;
+    const int64_t bin0 = (int64_t)row * p.P;
     if (!BWD) {
-        f32x4* o = (f32x4*)(p.out + bin * p.C);
-        if (!inside) {
-            for (int c = lane; c < c4n; c += 64) o[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            return;
-        }
-        const int top = (int)floorf(in_y), bot = (int)ceilf(in_y);
-        const int lef = (int)floorf(in_x), rig = (int)ceilf(in_x);
-        const float yl = in_y - (float)top, xl = in_x - (float)lef;
-        const float* base = p.fm[li] + (int64_t)b * H * W * p.C;
-        const f32x4* tl = (const f32x4*)(base + ((int64_t)top * W + lef) * p.C);
-        const f32x4* tr = (const f32x4*)(base + ((int64_t)top * W + rig) * p.C);
-        const f32x4* bl = (const f32x4*)(base + ((int64_t)bot * W + lef) * p.C);
-        const f32x4* br = (const f32x4*)(base + ((int64_t)bot * W + rig) * p.C);
-        for (int c = lane; c < c4n; c += 64) {
-            f32x4 a = tl[c], bq = tr[c], cq = bl[c], dq = br[c], r;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = a[e] + (bq[e] - a[e]) * xl;
-                float u = cq[e] + (dq[e] - cq[e]) * xl;
-                r[e] = t + (u - t) * yl;
+        const float* __restrict__ base = p.fm[li] + (int64_t)b * H * W * p.C;
+        const float* __restrict__ rtop = base + (int64_t)top * W * p.C;
+        const float* __restrict__ rbot = base + (int64_t)bot * W * p.C;
+        float* __restrict__ orow = p.out + bin0 * p.C;
+#pragma unroll 2
+        for (int px = 0; px < p.P; ++px) {
+            const float in_x = p.P > 1 ? x0 + (float)px * ws : x0;
+            f32x4* o = (f32x4*)(orow + (int64_t)px * p.C);
+            if (!y_inside || in_x < 0.f || in_x > (float)(W - 1)) {
+                for (int c = lane; c < c4n; c += 64) o[c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                continue;
             }
-            o[c] = r;
+            const int lef = (int)floorf(in_x), rig = (int)ceilf(in_x);
+            const float xl = in_x - (float)lef;
+            const f32x4* tl = (const f32x4*)(rtop + (int64_t)lef * p.C);
+            const f32x4* tr = (const f32x4*)(rtop + (int64_t)rig * p.C);
+            const f32x4* bl = (const f32x4*)(rbot + (int64_t)lef * p.C);
+            const f32x4* br = (const f32x4*)(rbot + (int64_t)rig * p.C);
+            for (int c = lane; c < c4n; c += 64) {
+                f32x4 a = tl[c], bq = tr[c], cq = bl[c], dq = br[c], r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = a[e] + (bq[e] - a[e]) * xl;
+                    float u = cq[e] + (dq[e] - cq[e]) * xl;
+                    r[e] = t + (u - t) * yl;
+                }
+                o[c] = r;
+            }
         }
     } else {
-        if (!inside) return;
-        const int top = (int)floorf(in_y), bot = (int)ceilf(in_y);
-        const int lef = (int)floorf(in_x), rig = (int)ceilf(in_x);
-        const float yl = in_y - (float)top, xl = in_x - (float)lef;
+        if (!y_inside) return;
         float* base = p.dfm[li] + (int64_t)b * H * W * p.C;
-        float* tl = base + ((int64_t)top * W + lef) * p.C;
-        float* tr = base + ((int64_t)top * W + rig) * p.C;
-        float* bl = base + ((int64_t)bot * W + lef) * p.C;
-        float* br = base + ((int64_t)bot * W + rig) * p.C;
-        const float* g = p.dout + bin * p.C;
-        const float wtl = (1.f - yl) * (1.f - xl), wtr = (1.f - yl) * xl, wbl = yl * (1.f - xl), wbr = yl * xl;
-        // one dword per lane per atomic instruction: 256 contiguous bytes per wave-instruction
-        // exact zeros are skipped: ROIs that carry no gradient (zero-padded / non-positive rows of the
-        // mask head) and integer-aligned samples (weight 0 corners) would only add 0.0f -- and the
-        // padded ROIs all hit pixel (0,0) of P2, which serialises the atomics on one row
-        for (int c = lane; c < p.C; c += 64) {
-            float gv = g[c];
-            if (gv == 0.f) continue;
-            if (wtl != 0.f) atomicAdd(tl + c, gv * wtl);
-            if (wtr != 0.f) atomicAdd(tr + c, gv * wtr);
-            if (wbl != 0.f) atomicAdd(bl + c, gv * wbl);
-            if (wbr != 0.f) atomicAdd(br + c, gv * wbr);
+        float* rtop = base + (int64_t)top * W * p.C;
+        float* rbot = base + (int64_t)bot * W * p.C;
+        const float* grow = p.dout + bin0 * p.C;
+        for (int px = 0; px < p.P; ++px) {
+            const float in_x = p.P > 1 ? x0 + (float)px * ws : x0;
+            if (in_x < 0.f || in_x > (float)(W - 1)) continue;
+            const int lef = (int)floorf(in_x), rig = (int)ceilf(in_x);
+            const float xl = in_x - (float)lef;
+            float* tl = rtop + (int64_t)lef * p.C;
+            float* tr = rtop + (int64_t)rig * p.C;
+            float* bl = rbot + (int64_t)lef * p.C;
+            float* br = rbot + (int64_t)rig * p.C;
+            const float* g = grow + (int64_t)px * p.C;
+            const float wtl = (1.f - yl) * (1.f - xl), wtr = (1.f - yl) * xl, wbl = yl * (1.f - xl), wbr = yl * xl;
+            // one dword per lane per atomic instruction: 256 contiguous bytes per wave-instruction
+            // exact zeros are skipped: ROIs that carry no gradient (zero-padded / non-positive rows of the
+            // mask head) and integer-aligned samples (weight 0 corners) would only add 0.0f -- and the
+            // padded ROIs all hit pixel (0,0) of P2, which serialises the atomics on one row
+            for (int c = lane; c < p.C; c += 64) {
+                float gv = g[c];
+                if (gv == 0.f) continue;
+                if (wtl != 0.f) atomicAdd(tl + c, gv * wtl);
+                if (wtr != 0.f) atomicAdd(tr + c, gv * wtr);
+                if (wbl != 0.f) atomicAdd(bl + c, gv * wbl);
+                if (wbr != 0.f) atomicAdd(br + c, gv * wbr);
+            }
         }
     }
 }
@@ -125,8 +143,9 @@ extern "C" int mrcnn_roialign_fwd(const mrcnn_roialign_desc* d, const float* box
     if (rc) return rc;
     if (!boxes || !fm2 || !fm3 || !fm4 || !fm5 || !out) return MRCNN_ERR_ARG;
     a.boxes = boxes; a.fm[0] = fm2; a.fm[1] = fm3; a.fm[2] = fm4; a.fm[3] = fm5; a.out = out; a.level_out = level_out;
-    int64_t nbins = (int64_t)a.B * a.R * a.P * a.P;
-    hipLaunchKernelGGL(roialign_kernel<false>, dim3((unsigned)cdiv64(nbins, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    const int64_t nrows = (int64_t)a.B * a.R * a.P;
+    if (nrows >= (1LL << 31)) return MRCNN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(roialign_kernel<false>, dim3((unsigned)cdiv64(nrows, 4)), dim3(256), 0, (hipStream_t)stream, a);
     return mrcnn_launch_status();
 }
 
@@ -137,8 +156,9 @@ extern "C" int mrcnn_roialign_bwd(const mrcnn_roialign_desc* d, const float* box
     if (rc) return rc;
     if (!boxes || !dout || !dfm2 || !dfm3 || !dfm4 || !dfm5) return MRCNN_ERR_ARG;
     a.boxes = boxes; a.dout = dout; a.dfm[0] = dfm2; a.dfm[1] = dfm3; a.dfm[2] = dfm4; a.dfm[3] = dfm5;
-    int64_t nbins = (int64_t)a.B * a.R * a.P * a.P;
-    hipLaunchKernelGGL(roialign_kernel<true>, dim3((unsigned)cdiv64(nbins, 4)), dim3(256), 0, (hipStream_t)stream, a);
+    const int64_t nrows = (int64_t)a.B * a.R * a.P;
+    if (nrows >= (1LL << 31)) return MRCNN_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(roialign_kernel<true>, dim3((unsigned)cdiv64(nrows, 4)), dim3(256), 0, (hipStream_t)stream, a);
     return mrcnn_launch_status();
 }
 
@@ -158,74 +178,91 @@ struct RoiH16Args {
 };
 
 template <typename T, bool BWD>
-__global__ __launch_bounds__(256) void roialign_h16_kernel(const RoiH16Args p) {
+__global__ __launch_bounds__(256) void roialign_h16_kernel(const RoiH16Args p) {      // a wave per row of bins, as roialign_kernel
     typedef T t4 __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
-    const int64_t bin = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int64_t nbins = (int64_t)p.B * p.R * p.P * p.P;
-    if (bin >= nbins) return;
-    const int px = (int)(bin % p.P);
-    const int py = (int)((bin / p.P) % p.P);
-    const int64_t roi = bin / (p.P * p.P);
-    const int b = (int)(roi / p.R);
-    const float* bx = p.boxes + roi * 4;
+    const unsigned row = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const unsigned nrows = (unsigned)p.B * (unsigned)p.R * (unsigned)p.P;
+    if (row >= nrows) return;
+    const unsigned roi = row / (unsigned)p.P;
+    const int py = (int)(row - roi * (unsigned)p.P);
+    const int b = (int)(roi / (unsigned)p.R);
+    const float* bx = p.boxes + (int64_t)roi * 4;
     const float y1 = bx[0], x1 = bx[1], y2 = bx[2], x2 = bx[3];
     const int li = roi_level(y1, x1, y2, x2, p.image_area) - 2;
     const int H = p.H[li], W = p.W[li];
-    float in_y, in_x;
+    float in_y, ws = 0.f, x0;
     if (p.P > 1) {
         const float hs = (y2 - y1) * (float)(H - 1) / (float)(p.P - 1);
-        const float ws = (x2 - x1) * (float)(W - 1) / (float)(p.P - 1);
+        ws = (x2 - x1) * (float)(W - 1) / (float)(p.P - 1);
         in_y = y1 * (float)(H - 1) + (float)py * hs;
-        in_x = x1 * (float)(W - 1) + (float)px * ws;
+        x0 = x1 * (float)(W - 1);
     } else {
         in_y = 0.5f * (y1 + y2) * (float)(H - 1);
-        in_x = 0.5f * (x1 + x2) * (float)(W - 1);
+        x0 = 0.5f * (x1 + x2) * (float)(W - 1);
     }
-    const bool inside = !(in_y < 0.f || in_y > (float)(H - 1) || in_x < 0.f || in_x > (float)(W - 1));
+    const bool y_inside = !(in_y < 0.f || in_y > (float)(H - 1));
+    const int top = y_inside ? (int)floorf(in_y) : 0, bot = y_inside ? (int)ceilf(in_y) : 0;
+    const float yl = in_y - (float)top;
     const int c4n = p.C >> 2;
-    const int top = inside ? (int)floorf(in_y) : 0, bot = inside ? (int)ceilf(in_y) : 0;
-    const int lef = inside ? (int)floorf(in_x) : 0, rig = inside ? (int)ceilf(in_x) : 0;
-    const float yl = in_y - (float)top, xl = in_x - (float)lef;
+    const int64_t bin0 = (int64_t)row * p.P;
     if (!BWD) {
-        t4* o = (t4*)((T*)p.out + bin * p.C);
-        if (!inside) {
-            for (int c = lane; c < c4n; c += 64) o[c] = (t4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
-            return;
-        }
-        const T* base = (const T*)p.fm[li] + (int64_t)b * H * W * p.C;
-        const t4* tl = (const t4*)(base + ((int64_t)top * W + lef) * p.C);
-        const t4* tr = (const t4*)(base + ((int64_t)top * W + rig) * p.C);
-        const t4* bl = (const t4*)(base + ((int64_t)bot * W + lef) * p.C);
-        const t4* br = (const t4*)(base + ((int64_t)bot * W + rig) * p.C);
-        for (int c = lane; c < c4n; c += 64) {
-            const t4 a = tl[c], bq = tr[c], cq = bl[c], dq = br[c];
-            t4 r;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float av = (float)a[e], cv = (float)cq[e];
-                const float t = av + ((float)bq[e] - av) * xl;
-                const float u = cv + ((float)dq[e] - cv) * xl;
-                r[e] = (T)(t + (u - t) * yl);
+        const T* __restrict__ base = (const T*)p.fm[li] + (int64_t)b * H * W * p.C;
+        const T* __restrict__ rtop = base + (int64_t)top * W * p.C;
+        const T* __restrict__ rbot = base + (int64_t)bot * W * p.C;
+        T* __restrict__ orow = (T*)p.out + bin0 * p.C;
+#pragma unroll 2
+        for (int px = 0; px < p.P; ++px) {
+            const float in_x = p.P > 1 ? x0 + (float)px * ws : x0;
+            t4* o = (t4*)(orow + (int64_t)px * p.C);
+            if (!y_inside || in_x < 0.f || in_x > (float)(W - 1)) {
+                for (int c = lane; c < c4n; c += 64) o[c] = (t4){(T)0.f, (T)0.f, (T)0.f, (T)0.f};
+                continue;
             }
-            o[c] = r;
+            const int lef = (int)floorf(in_x), rig = (int)ceilf(in_x);
+            const float xl = in_x - (float)lef;
+            const t4* tl = (const t4*)(rtop + (int64_t)lef * p.C);
+            const t4* tr = (const t4*)(rtop + (int64_t)rig * p.C);
+            const t4* bl = (const t4*)(rbot + (int64_t)lef * p.C);
+            const t4* br = (const t4*)(rbot + (int64_t)rig * p.C);
+            for (int c = lane; c < c4n; c += 64) {
+                const t4 a = tl[c], bq = tr[c], cq = bl[c], dq = br[c];
+                t4 r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float av = (float)a[e], cv = (float)cq[e];
+                    const float t = av + ((float)bq[e] - av) * xl;
+                    const float u = cv + ((float)dq[e] - cv) * xl;
+                    r[e] = (T)(t + (u - t) * yl);
+                }
+                o[c] = r;
+            }
         }
     } else {
-        if (!inside) return;
+        if (!y_inside) return;
         float* base = p.dfm[li] + (int64_t)b * H * W * p.C;
-        float* tl = base + ((int64_t)top * W + lef) * p.C;
-        float* tr = base + ((int64_t)top * W + rig) * p.C;
-        float* bl = base + ((int64_t)bot * W + lef) * p.C;
-        float* br = base + ((int64_t)bot * W + rig) * p.C;
-        const T* g = (const T*)p.dout + bin * p.C;
-        const float wtl = (1.f - yl) * (1.f - xl), wtr = (1.f - yl) * xl, wbl = yl * (1.f - xl), wbr = yl * xl;
-        for (int c = lane; c < p.C; c += 64) {
-            const float gv = (float)g[c] * p.mul;
-            if (gv == 0.f) continue;
-            if (wtl != 0.f) atomicAdd(tl + c, gv * wtl);
-            if (wtr != 0.f) atomicAdd(tr + c, gv * wtr);
-            if (wbl != 0.f) atomicAdd(bl + c, gv * wbl);
-            if (wbr != 0.f) atomicAdd(br + c, gv * wbr);
+        float* rtop = base + (int64_t)top * W * p.C;
+        float* rbot = base + (int64_t)bot * W * p.C;
+        const T* grow = (const T*)p.dout + bin0 * p.C;
+        for (int px = 0; px < p.P; ++px) {
+            const float in_x = p.P > 1 ? x0 + (float)px * ws : x0;
+            if (in_x < 0.f || in_x > (float)(W - 1)) continue;
+            const int lef = (int)floorf(in_x), rig = (int)ceilf(in_x);
+            const float xl = in_x - (float)lef;
+            float* tl = rtop + (int64_t)lef * p.C;
+            float* tr = rtop + (int64_t)rig * p.C;
+            float* bl = rbot + (int64_t)lef * p.C;
+            float* br = rbot + (int64_t)rig * p.C;
+            const T* g = grow + (int64_t)px * p.C;
+            const float wtl = (1.f - yl) * (1.f - xl), wtr = (1.f - yl) * xl, wbl = yl * (1.f - xl), wbr = yl * xl;
+            for (int c = lane; c < p.C; c += 64) {
+                const float gv = (float)g[c] * p.mul;
+                if (gv == 0.f) continue;
+                if (wtl != 0.f) atomicAdd(tl + c, gv * wtl);
+                if (wtr != 0.f) atomicAdd(tr + c, gv * wtr);
+                if (wbl != 0.f) atomicAdd(bl + c, gv * wbl);
+                if (wbr != 0.f) atomicAdd(br + c, gv * wbr);
+            }
         }
     }
 }
@@ -247,7 +284,8 @@ extern "C" int mrcnn_roialign_fwd_h16(const mrcnn_roialign_desc* d, int dtype, c
     if (rc) return rc;
     if (!boxes || !fm2 || !fm3 || !fm4 || !fm5 || !out || (dtype != MRCNN_DTYPE_F16 && dtype != MRCNN_DTYPE_BF16)) return MRCNN_ERR_ARG;
     a.boxes = boxes; a.fm[0] = fm2; a.fm[1] = fm3; a.fm[2] = fm4; a.fm[3] = fm5; a.out = out;
-    const int64_t nbins = (int64_t)a.B * a.R * a.P * a.P;
+    const int64_t nbins = (int64_t)a.B * a.R * a.P;          // rows of bins: a wave each
+    if (nbins >= (1LL << 31)) return MRCNN_ERR_UNSUPPORTED;
     if (dtype == MRCNN_DTYPE_F16)
         hipLaunchKernelGGL((roialign_h16_kernel<_Float16, false>), dim3((unsigned)cdiv64(nbins, 4)), dim3(256), 0, (hipStream_t)stream, a);
     else
@@ -262,7 +300,8 @@ extern "C" int mrcnn_roialign_bwd_h16(const mrcnn_roialign_desc* d, int dtype, c
     if (rc) return rc;
     if (!boxes || !dout || !dfm2 || !dfm3 || !dfm4 || !dfm5 || (dtype != MRCNN_DTYPE_F16 && dtype != MRCNN_DTYPE_BF16)) return MRCNN_ERR_ARG;
     a.boxes = boxes; a.dout = dout; a.mul = multiplier; a.dfm[0] = dfm2; a.dfm[1] = dfm3; a.dfm[2] = dfm4; a.dfm[3] = dfm5;
-    const int64_t nbins = (int64_t)a.B * a.R * a.P * a.P;
+    const int64_t nbins = (int64_t)a.B * a.R * a.P;          // rows of bins: a wave each
+    if (nbins >= (1LL << 31)) return MRCNN_ERR_UNSUPPORTED;
     if (dtype == MRCNN_DTYPE_F16)
         hipLaunchKernelGGL((roialign_h16_kernel<_Float16, true>), dim3((unsigned)cdiv64(nbins, 4)), dim3(256), 0, (hipStream_t)stream, a);
     else
