@@ -3,7 +3,7 @@
 // concatenates and re-sorts; here every output bin picks its level in registers and the result is
 // written straight in the original ROI order.
 //
-// Work mapping: one wave per output bin (roi, py, px).  The C channels of a bin are contiguous in
+// Work mapping: one wave per ROW of output bins (roi, py), walking px (round 3; one wave per bin before).  The C channels of a bin are contiguous in
 // NHWC, so the four bilinear corners are four fully coalesced row reads (C=256: 1 KiB = 64 lanes x
 // float4) and the bin is one coalesced 1 KiB store.  crop_and_resize semantics ([3P] TF 1.13
 // CropAndResize CPU functor): in = lo*(D-1) + i*(hi-lo)*(D-1)/(P-1) (P>1) or 0.5*(lo+hi)*(D-1);
