@@ -20,6 +20,7 @@ extern int g_mrcnn_wgrad_lds_pad;
 //   workgroup of it fills a CU's LDS, so beside another stream's big kernels (the mask head's weight gradients run next to
 //   its data gradients) the statically assigned tiles start late on the CUs the other kernel held.
 extern int g_mrcnn_h16_phase;
+extern int g_mrcnn_h16_slab;
 //   proposal_skip_zero: tests only (fault injection): 1 suppresses the reset of the multi-workgroup top-k's counters.
 extern int g_mrcnn_proposal_skip_zero;
 

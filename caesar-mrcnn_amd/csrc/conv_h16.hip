@@ -389,7 +389,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, NBUF <= 3 ? 2 : (WAVES_M * 
 // slots.  (The stores stay compiler builtins: as inline asm the recogniser no longer sees their SGPR operands, and the
 // "vector write of an SGPR, then a memory instruction reads it" wait states go missing -- measured: wrong addresses.)
 template <int N> __device__ __forceinline__ void h16p_wait() {        // s_waitcnt vmcnt(min(N, 63)): the field has 6 bits
-    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if constexpr (N == 36) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -737,6 +741,331 @@ __global__ __launch_bounds__(512) void conv_fwd_h16p_kernel(const ConvH16Args p)
     if (p.dbg && blockIdx.x == 0 && (wave & 3) == 0 && lane == 0)
         for (int i = 0; i < NTRC; ++i)
             p.dbg[wr * NTRC + i] = i < ntrc ? ((unsigned long long*)(lds + TRC))[wr * NTRC + i] : 0ull;
+}
+
+// ---- slab form of the phased kernel (round 3; 3 x 3, stride 1, pad 1 on maps with W <= 14: the mask head) --------------------
+// MEASURED SLOWER than conv_fwd_h16p_kernel and therefore opt-in (MRCNN_H16_SLAB=1 / mrcnn_tuning_set("h16_slab", 1)); kept with its
+// tests as the evidence that the number of LDS-DMA pieces is NOT what bounds the phased kernel.
+// The phased kernel re-stages the pixels of a channel chunk for each of the nine taps: 1 152 of a tile's 2 304 LDS-DMA pieces,
+// and what bounds it is the issue cost of those pieces.  Here a channel chunk's pixels are staged ONCE, as a slab
+// of the tile's 256 pixel rows with a halo of 15 rows on either side (288 rows of 128 bytes, rows in the flat pixel order of the
+// [M] tensor), and the nine taps are SHIFTED READS of it: tap (th, tw) reads row 15 + t + (th - 1) W + (tw - 1) for pixel t.  A
+// pixel whose tap leaves its map (border of the 14 x 14 map, tile tail) reads a zero row instead: per lane a 9-bit mask for each of
+// its eight 16-row operand tiles, made once per tile.  Rows are chunk-swizzled as before, c ^ ((row >> 1) & 7); a shift changes
+// the row and with it the swizzle, but the term is the same for all eight tiles of a lane (they are 16 rows apart), so a tap costs
+// one address per k half plus one select per tile.  Per K-step a wave issues 4 weight pieces + on average 0.5 slab pieces
+// instead of 8; the weight stages, the two staggered wave groups, the barriers, the MFMA quadrants and the epilogue are the
+// phased kernel's.  Two slabs (the next chunk's is staged five K-steps ahead, while this chunk's taps are computed), two 32 KiB
+// weight stages, parameters, store staging and the zero row: 161 920 bytes of LDS.
+//   waits     only weight quarters are counted: the quarter a phase reads next was issued 5 phases earlier and two quarters
+//             (4 pieces) have been issued since -- s_waitcnt vmcnt(4) (+ the epilogue's stores while they are in that window); a
+//             slab piece in the window only makes the wait stricter by one, and a chunk's slab is >= 20 pieces old at its first read
+template <typename T, bool ZOUT>
+__global__ __launch_bounds__(512) void conv_fwd_h16q_kernel(const ConvH16Args p) {
+    typedef typename H16Traits<T>::v8 v8;
+    constexpr int HALO = 15, SROWS = 288, SLAB = SROWS * 128, NPIECE = SROWS / 8;
+    constexpr int BST = 2 * SLAB, BSZ = 32768, PRM = BST + 2 * BSZ, MAXC = 512;
+    constexpr int STG = PRM + 3 * MAXC * 4, ZROW = STG + 8 * 2048;
+    __shared__ __attribute__((aligned(16))) char lds[ZROW + 128];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int ntiles = p.Cout >> 8;
+    const int total = p.ptiles;
+    {
+        float* prm = (float*)(lds + PRM);
+        for (int c = tid; c < p.Cout; c += 512) {
+            const float bi = p.bias ? p.bias[c] : 0.f, sc = p.scale ? p.scale[c] : 1.f, sh = p.scale ? p.shift[c] : 0.f;
+            prm[c] = sc;
+            prm[MAXC + c] = sc * bi + sh;
+            prm[2 * MAXC + c] = bi;
+        }
+        if (tid < 32) ((float*)(lds + ZROW))[tid] = 0.f;
+        __syncthreads();
+    }
+    const int ohw = p.OH * p.OW;
+    const int nk = p.Ktot >> 6;                                 // 9 taps x Cin / 64 chunks; the host checks Cin % 128 == 0: nk is even
+
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.x - p.x_shift), 0, p.x_records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)p.wt, 0, p.w_records, 0x00020000);
+
+    // ---- staging bookkeeping ----------------------------------------------------------------------------------------------
+    unsigned b_voff[2][2];
+    int b_lds[2][2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int qr0 = (wave + 8 * j) * 8;
+            b_lds[q][j] = ((qr0 >> 5) * 64 + q * 32 + (qr0 & 31)) * 128;
+        }
+    const int lane_ = lane;
+    auto setup_b = [&](int tile) {
+        const int mtile = tile / ntiles, ntile = tile - mtile * ntiles;
+        const bool live = tile < total;
+        int lane = lane_;
+        asm volatile("" : "+v"(lane));
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = b_lds[q][j] / 128 + (lane >> 3);
+                const int cl = (lane & 7) ^ ((r >> 1) & 7);
+                b_voff[q][j] = live ? (unsigned)((((long long)(ntile * 256 + r)) * p.Ktot + cl * 8) * 2) : H16_OOB_OFFSET;
+            }
+    };
+    // slab pieces: piece pi covers slab rows 8 pi .. 8 pi + 7 = flat pixels mtile * 256 - 15 + 8 pi ..; lane (l >> 3, l & 7) fetches
+    // logical chunk (l & 7) ^ ((row >> 1) & 7) of its row.  Nothing per piece is kept in registers: the offset is the lane's
+    // constant part plus a wave-uniform pixel base, made when the piece is issued (one piece per K-step).
+    auto slab_piece = [&](const int j, const int buf, const unsigned soff, const int mtile, const bool live) {
+        const int pi = wave + 8 * j;                            // wave-uniform: pieces 36 .. 39 do not exist
+        if (pi < NPIECE) {
+            int ln = lane_;
+            asm volatile("" : "+v"(ln));                        // recomputed per piece: a register kept across the K loop would spill (ZOUT form)
+            const int g = mtile * 256 - HALO + pi * 8 + (ln >> 3);
+            const bool ok = live && g >= 0 && g < p.M;
+            const unsigned cl = (unsigned)((ln & 7) ^ (((ln >> 4) + 4 * (wave & 1)) & 7));
+            const unsigned vo = ok ? p.x_shift + cl * 16u + (unsigned)g * (unsigned)(p.Cin * 2) : H16_OOB_OFFSET;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (h16_lds_ptr)(lds + buf * SLAB + pi * 1024), 16, vo, soff, 0, 0);
+        }
+    };
+
+    int it_tile = blockIdx.x, it_tap = 0, it_ci0 = 0, it_kt = 0;
+    auto issue_b = [&](auto qc, auto bufc) {
+        constexpr int q = decltype(qc)::value;
+        char* base = lds + BST + decltype(bufc)::value * BSZ;
+        const unsigned soff = it_kt < nk ? (unsigned)((it_tap * p.Cin + it_ci0) * 2) : 0u;
+        const unsigned dead = it_kt < nk ? 0u : H16_OOB_OFFSET;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const unsigned vo = b_voff[q][j] | dead;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (h16_lds_ptr)(base + b_lds[q][j]), 16, vo, soff, 0, 0);
+        }
+    };
+    int it_mtile = (int)blockIdx.x / ntiles, nx_mtile = ((int)blockIdx.x + (int)gridDim.x) / ntiles;      // row tile of the issue side's tile / of the next one
+    auto issue_slab = [&]() {                                   // during taps 2 .. 6 of a chunk: one piece of the NEXT chunk's slab
+        if (it_kt < nk && it_tap >= 2 && it_tap <= 6) {
+            const bool wrap = it_ci0 + 64 == p.Cin;                 // the next chunk is chunk 0 of this workgroup's next tile
+            const unsigned soff = wrap ? 0u : (unsigned)((it_ci0 + 64) * 2);
+            slab_piece(it_tap - 2, ((it_ci0 >> 6) & 1) ^ 1, soff, wrap ? nx_mtile : it_mtile,
+                       wrap ? it_tile + (int)gridDim.x < total : it_tile < total);
+        }
+    };
+    auto advance = [&]() {
+        if (++it_kt == nk) {
+            it_kt = it_tap = it_ci0 = 0;
+            it_tile += gridDim.x;
+            it_mtile = nx_mtile;
+            nx_mtile = (it_tile + (int)gridDim.x) / ntiles;
+            setup_b(it_tile);
+        } else if (++it_tap == 9) {
+            it_tap = 0;
+            it_ci0 += 64;
+        }
+    };
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 1> I1;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int l15 = lane & 15, fq = lane >> 4;
+    const int wrd = BST + (wc * 64 + l15) * 128 + ((fq ^ ((l15 >> 1) & 7)) << 4);
+    v8 xf[4][2], w0[2][2], w1[2][2];
+    unsigned vm0 = 0u, vm1 = 0u, vm2 = 0u;                      // tap masks of this lane's pixel in operand tiles 0-2, 3-5, 6-7 (9 bits each)
+
+    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_records, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_z = __builtin_amdgcn_make_buffer_rsrc(p.z, 0, ZOUT ? p.out_records : 0u, 0x00020000);
+    const float act_floor = p.act == MRCNN_ACT_RELU ? 0.f : -INFINITY;
+    constexpr int ES = ZOUT ? 16 : 8;
+    typedef T t4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto epilogue = [&](auto halfc, const int tile) {           // conv_fwd_h16p_kernel's, dense NHWC only
+        constexpr int PB = decltype(halfc)::value * 4;
+        const int mtile = tile / ntiles, ntile = tile - mtile * ntiles;
+        const int nb = ntile * 256 + wc * 64;
+        char* stg = lds + STG + wave * 2048;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int l15 = ln & 15, fq = ln >> 4;
+        const int wbase = l15 * 128 + (fq & 1) * 8, wsw = l15 & 7;
+        const int r8 = ln >> 3;
+        const int rbase = r8 * 128 + (((ln & 7) ^ (r8 & 7)) << 4);
+        const unsigned voff = (unsigned)(((mtile * 256 + wr * 128 + r8) * p.Cout + nb) * 2 + (ln & 7) * 16);
+        f32x4 p0[4], p1[4], p2[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int n = nb + c * 16 + fq * 4;
+            p0[c] = *(const f32x4*)(lds + PRM + n * 4);
+            p1[c] = *(const f32x4*)(lds + PRM + (MAXC + n) * 4);
+            if constexpr (ZOUT) p2[c] = *(const f32x4*)(lds + PRM + (2 * MAXC + n) * 4);
+        }
+        u32x4 o0[4], o1[4], z0[4], z1[4];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            if (i < 4) {
+                t4 yv[4], zv4[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) yv[c][j] = (T)fmaxf(acc[PB + i][c][j] * p0[c][j] + p1[c][j], act_floor);
+                    if constexpr (ZOUT) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) zv4[c][j] = (T)(acc[PB + i][c][j] + p2[c][j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[PB + i][c][j] = 0.f;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) *(t4*)(stg + wbase + (((c * 2 + (fq >> 1)) ^ wsw) << 4)) = yv[c];
+                o0[i] = *(const u32x4*)(stg + rbase); o1[i] = *(const u32x4*)(stg + rbase + 1024);
+                if constexpr (ZOUT) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) *(t4*)(stg + wbase + (((c * 2 + (fq >> 1)) ^ wsw) << 4)) = zv4[c];
+                    z0[i] = *(const u32x4*)(stg + rbase); z1[i] = *(const u32x4*)(stg + rbase + 1024);
+                }
+            }
+            if (i > 0) {
+                const unsigned soff = (unsigned)(((PB + i - 1) * 16 * p.Cout) * 2), soff8 = soff + (unsigned)(8 * p.Cout * 2);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_raw_buffer_store_b128(o0[i - 1], rsrc_o, voff, soff, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o1[i - 1], rsrc_o, voff, soff8, 0);
+                if constexpr (ZOUT) {
+                    __builtin_amdgcn_raw_buffer_store_b128(z0[i - 1], rsrc_z, voff, soff, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(z1[i - 1], rsrc_z, voff, soff8, 0);
+                }
+                asm volatile("s_nop 2");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    // tap masks of the compute side's tile: bit t = th * 3 + tw set when pixel (oh, ow)'s tap stays inside the map and the row is < M
+    auto tile_masks = [&](const int tile) {
+        const int mtile = tile / ntiles;
+        int ln = lane_;
+        asm volatile("" : "+v"(ln));
+        auto one = [&](const int gi) -> unsigned {
+            const int m = mtile * 256 + wr * 128 + 16 * gi + (ln & 15);
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int n = p.mg_ohw ? (int)(__umulhi((unsigned)mm, p.mg_ohw) >> p.sh_ohw) : mm, rem = mm - n * ohw;
+            const int oh = p.mg_ow ? (int)(__umulhi((unsigned)rem, p.mg_ow) >> p.sh_ow) : rem, ow = rem - oh * p.OW;
+            const unsigned rows = (oh > 0 ? 0x007u : 0u) | 0x038u | (oh < p.H - 1 ? 0x1C0u : 0u);     // tap rows th = 0 / 1 / 2
+            const unsigned cols = (ow > 0 ? 0x049u : 0u) | 0x092u | (ow < p.W - 1 ? 0x124u : 0u);     // tap columns tw = 0 / 1 / 2
+            return ok ? (rows & cols) : 0u;
+        };
+        vm0 = one(0) | (one(1) << 9) | (one(2) << 18);
+        vm1 = one(3) | (one(4) << 9) | (one(5) << 18);
+        vm2 = one(6) | (one(7) << 9);
+    };
+
+    auto phase = [&](auto phc, const int t, const int tile) {
+        constexpr int PH = decltype(phc)::value;                // 0..7
+        constexpr int BUF = PH >> 2, Q = PH & 3;
+        const char* sb = lds + BUF * BSZ;                        // weight stage (wrd carries BST)
+        const bool last = t + 2 >= nk, after = t == 0 && tile != (int)blockIdx.x;
+        if constexpr (PH == 6) { if (last) epilogue(I0{}, tile); }
+        if constexpr (PH == 0) { if (after) epilogue(I1{}, tile - (int)gridDim.x); }
+        if constexpr (PH == 0) { if (t == 0) tile_masks(tile); }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (Q == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) w0[i][ks] = *(const v8*)(sb + (wrd ^ (ks << 6)) + i * 2048);
+        }
+        if constexpr (Q == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) w1[i][ks] = *(const v8*)(sb + (wrd ^ (ks << 6)) + 4096 + i * 2048);
+        }
+        if constexpr (Q == 0 || Q == 2) {
+            if constexpr (Q == 0) __builtin_amdgcn_sched_barrier(0);
+            // this K-step's tap as a shifted read of the chunk's slab
+            const int kstep = t + BUF;
+            const int chunk = kstep / 9, tap = kstep - chunk * 9;
+            const int th = tap / 3, tw = tap - th * 3;
+            const int shift = (th - 1) * p.W + (tw - 1);
+            int ln = lane_;
+            asm volatile("" : "+v"(ln));
+            const int r0 = HALO + wr * 128 + (ln & 15) + shift;                       // slab row of operand tile 0's pixel (tiles: + 16 i)
+            const int a0 = (chunk & 1) * SLAB + r0 * 128 + ((((ln >> 4)) ^ ((r0 >> 1) & 7)) << 4) + (Q == 2 ? 8192 : 0);
+            const int a1 = a0 ^ 64;
+            const int zr = ZROW + ((ln >> 4) << 4);
+            if (p.dbg) {                                        // TIMING EXPERIMENT ONLY (MRCNN_H16P_TRACE set): no border masks -- wrong at map borders
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xf[i][0] = *(const v8*)(lds + a0 + i * 2048);
+                    xf[i][1] = *(const v8*)(lds + a1 + i * 2048);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    constexpr int GI0 = (Q == 2 ? 4 : 0);
+                    const int gi = GI0 + i;
+                    const unsigned word = gi < 3 ? vm0 : (gi < 6 ? vm1 : vm2);
+                    const bool ok = ((word >> (9 * (gi % 3) + tap)) & 1u) != 0u;
+                    xf[i][0] = *(const v8*)(lds + (ok ? a0 + i * 2048 : zr));
+                    xf[i][1] = *(const v8*)(lds + (ok ? a1 + i * 2048 : zr));
+                }
+            }
+        }
+        // staging: weight quarters as in the phased kernel; where that kernel staged pixel quarters, at most one slab piece
+        if constexpr (PH == 0) issue_b(I1{}, I1{});
+        if constexpr (PH == 1) advance();
+        if constexpr (PH == 2) issue_slab();
+        if constexpr (PH == 3) issue_b(I0{}, I0{});
+        if constexpr (PH == 4) issue_b(I1{}, I0{});
+        if constexpr (PH == 5) advance();
+        if constexpr (PH == 6) issue_slab();
+        if constexpr (PH == 7) issue_b(I0{}, I1{});
+        if constexpr (PH == 7) { if (last) h16p_wait<4 + ES>(); else h16p_wait<4>(); }
+        else if constexpr (PH == 0) { if (after) h16p_wait<4 + 2 * ES>(); else h16p_wait<4>(); }
+        else if constexpr (PH == 3) { if (after) h16p_wait<4 + ES>(); else h16p_wait<4>(); }
+        else if constexpr (PH == 4) h16p_wait<4>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        constexpr int PB = (Q >= 2) ? 4 : 0;
+        constexpr int CB = (Q == 1 || Q == 2) ? 2 : 0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    acc[PB + i][CB + c] = H16Traits<T>::mfma16((CB ? w1 : w0)[c][ks], xf[i][ks], acc[PB + i][CB + c]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    };
+
+    // prologue: the first chunk's slab whole, K-step 0's weight quarters, K-step 1's first; group 1 drops one barrier behind
+    setup_b(it_tile);
+#pragma unroll
+    for (int j = 0; j < 5; ++j) slab_piece(j, 0, 0u, it_mtile, it_tile < total);
+    issue_b(I0{}, I0{}); issue_b(I1{}, I0{}); advance();
+    issue_b(I0{}, I1{});
+    if (wr == 1) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+
+    int tile = blockIdx.x;
+    for (; tile < total; tile += gridDim.x)
+        for (int t = 0; t < nk; t += 2)
+            h16_static_for([&](auto phc) { phase(phc, t, tile); }, std::make_integer_sequence<int, 8>{});
+    epilogue(I1{}, tile - (int)gridDim.x);
+    if (wr == 0) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // Small-tile variant for the layers of the trunk (feature maps of 1 024 .. 16 384 pixels, Cin / Cout multiples of 64):
@@ -2084,7 +2413,24 @@ extern "C" int mrcnn_conv2d_fwd_h16_res(const mrcnn_conv_desc* d, int dtype, con
         a.ptiles = (int)own;
         unsigned blocks = (unsigned)std::min<long long>(own, cus);   // one workgroup per CU (LDS)
         if (const char* g = getenv("MRCNN_H16P_GRID")) blocks = (unsigned)std::min<long long>(own, atoi(g));   // experiments
-        if (deconv_p) {
+        // slab form (conv_fwd_h16q_kernel): 3 x 3 / stride 1 / pad 1 on maps no wider than 14 pixels (halo of W + 1 <= 15 rows), an
+        // even number of 64-channel chunks (the two slab buffers alternate by chunk parity across tiles): the mask head's layers
+        // OFF by default: correct (test_conv_fwd_h16_slab) and 8-12 % SLOWER than the per-tap staging on the mask-head layer (0.419 ->
+        // 0.474 ms; with the border masks knocked out 0.422-0.431 ms: halving the pixel pieces buys nothing, the masks cost) --
+        // tools/h16_slab_probe.py, DESIGN 4.1c
+        static const bool slab_env = getenv("MRCNN_H16_SLAB") && getenv("MRCNN_H16_SLAB")[0] == '1';
+        const bool slab_on = g_mrcnn_h16_slab < 0 ? slab_env : g_mrcnn_h16_slab != 0;
+        const bool slab = slab_on && !deconv_p && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad_t == 1 && d->pad_l == 1 &&
+                          d->OH == d->H && d->OW == d->W && d->W <= 14 && d->Cin % 128 == 0 && a.dense && d->Cout <= 512;
+        if (slab) {
+            if (dtype == MRCNN_DTYPE_F16) {
+                if (z_out) hipLaunchKernelGGL((conv_fwd_h16q_kernel<_Float16, true>), dim3(blocks), dim3(512), 0, s, a);
+                else hipLaunchKernelGGL((conv_fwd_h16q_kernel<_Float16, false>), dim3(blocks), dim3(512), 0, s, a);
+            } else {
+                if (z_out) hipLaunchKernelGGL((conv_fwd_h16q_kernel<__bf16, true>), dim3(blocks), dim3(512), 0, s, a);
+                else hipLaunchKernelGGL((conv_fwd_h16q_kernel<__bf16, false>), dim3(blocks), dim3(512), 0, s, a);
+            }
+        } else if (deconv_p) {
             if (dtype == MRCNN_DTYPE_F16) hipLaunchKernelGGL((conv_fwd_h16p_kernel<_Float16, false, true>), dim3(blocks), dim3(512), 0, s, a);
             else hipLaunchKernelGGL((conv_fwd_h16p_kernel<__bf16, false, true>), dim3(blocks), dim3(512), 0, s, a);
         } else if (dtype == MRCNN_DTYPE_F16) {

@@ -41,14 +41,18 @@ H16_CASES = [
 ]
 
 
-@pytest.fixture(params=["small", "big", "phase", "wave128"])
+@pytest.fixture(params=["small", "big", "phase", "slab", "wave128"])
 def h16_tile(request):
     """The forward tilings on every eligible shape: MRCNN_H16_TILE is read per call (256 x 128 / 4 waves / double
     buffered; 256 x 256 / 8 waves / 4-stage ring with counted waits; 256 x 256 / 8 waves in two staggered groups, phased
     K-steps; 256 x 256 / 4 waves of 128 x 128 with software-pipelined operand reads and the epilogue through LDS -- the last
     three need Cout % 256 == 0, the phased one also Cin % 64 == 0, else the call takes the default)."""
-    os.environ["MRCNN_H16_TILE"] = request.param
+    # "slab": the phased tile with the pixels of a channel chunk staged once and the taps as shifted reads (conv_fwd_h16q_kernel,
+    # what eligible shapes take by default); "phase" keeps the per-tap staging on those shapes too
+    os.environ["MRCNN_H16_TILE"] = "phase" if request.param == "slab" else request.param
+    _ops().tuning_set("h16_slab", 1 if request.param == "slab" else 0)
     yield request.param
+    _ops().tuning_set("h16_slab", -1)
     del os.environ["MRCNN_H16_TILE"]
 
 
@@ -57,8 +61,10 @@ def h16_tile(request):
 def test_conv_fwd_h16(dev, case, dtype, h16_tile):
     ops = _ops()
     N, H, W, Cin, Cout, k, padding, act, bn = case
-    if h16_tile in ("big", "phase", "wave128") and (Cout % 256 or (h16_tile == "phase" and Cin % 64)):
+    if h16_tile in ("big", "phase", "slab", "wave128") and (Cout % 256 or (h16_tile in ("phase", "slab") and Cin % 64)):
         pytest.skip("256 x 256 tile needs Cout % 256 == 0")
+    if h16_tile == "slab" and not (k == 3 and padding == "same" and W <= 14 and Cin % 128 == 0):
+        pytest.skip("slab staging: 3 x 3 on maps no wider than 14 pixels, an even number of 64-channel chunks")
     rng = np.random.default_rng(sum(case[:6]))
     x = torch.tensor(rng.standard_normal((N, H, W, Cin)).astype(np.float32)).to(dtype)
     w = torch.tensor((rng.standard_normal((k, k, Cin, Cout)) / np.sqrt(k * k * Cin)).astype(np.float32)).to(dtype)
@@ -83,7 +89,7 @@ def test_conv_fwd_h16(dev, case, dtype, h16_tile):
         err = float((got.float().cpu() - ref).abs().max()) / float(ref.abs().max())
         assert err <= TOL[dtype], "%s: max error %.3g of max |ref| (allowed %.3g)" % (name, err, TOL[dtype])
     # data gradient: the same kernel on dz with the rotated weight image
-    if (padding == "same" or k == 1) and Cin % 128 == 0 and not (h16_tile in ("big", "phase") and Cin % 256):
+    if (padding == "same" or k == 1) and Cin % 128 == 0 and not (h16_tile in ("big", "phase", "slab") and Cin % 256):
         xg = x.float().clone().requires_grad_(True)
         yy = orc.conv2d_nhwc(xg, w.float(), None, 1, padding)
         dz = torch.tensor(rng.standard_normal(tuple(yy.shape)).astype(np.float32)).to(dtype)
@@ -93,6 +99,67 @@ def test_conv_fwd_h16(dev, case, dtype, h16_tile):
         torch.cuda.synchronize()
         err = float((dx.float().cpu() - xg.grad).abs().max()) / float(xg.grad.abs().max())
         assert err <= TOL[dtype], "dgrad: max error %.3g (allowed %.3g)" % (err, TOL[dtype])
+
+
+SLAB_CASES = [
+    # N, H, W, Cin, Cout, act, bn, grid (MRCNN_H16P_GRID: workgroups; few of them make every workgroup walk several tiles)
+    (400, 14, 14, 256, 256, 1, True, 0),        # 306.25 tiles on 256 workgroups: a second, partial round (its remainder goes to the small-tile kernel)
+    (64, 14, 14, 256, 256, 1, True, 5),         # 49 tiles on 5 workgroups: ten tile borders per workgroup, slab of the next tile staged across them
+    (37, 14, 14, 128, 512, 0, False, 3),        # two chunks (the minimum), two column tiles per row tile, ragged M (7252), no BN / activation
+    (50, 9, 13, 512, 256, 1, True, 4),          # 8 chunks, map 9 x 13 (halo 14 rows), ragged
+    (3, 5, 3, 128, 256, 1, False, 0),           # one partial tile (45 rows): every row near a border, tile tail masked
+    (30, 2, 14, 256, 256, 0, True, 2),          # maps of two rows: the taps above and below leave the map for every pixel
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("case", SLAB_CASES)
+def test_conv_fwd_h16_slab(dev, case, dtype):
+    """conv_fwd_h16q_kernel (the phased 256 x 256 tile with slab-plus-halo staging: a chunk's pixels once, nine taps as shifted
+    LDS reads, border taps redirected to a zero row) against the float32 oracle on the same 16-bit-rounded operands: forward
+    with the pre-BN output, and the data gradient where its shape is eligible too."""
+    ops = _ops()
+    N, H, W, Cin, Cout, act, bn, grid = case
+    rng = np.random.default_rng(N * 1000 + H * 100 + W * 10 + Cin + Cout)
+    x = torch.tensor(rng.standard_normal((N, H, W, Cin)).astype(np.float32)).to(dtype)
+    w = torch.tensor((rng.standard_normal((3, 3, Cin, Cout)) / np.sqrt(9 * Cin)).astype(np.float32)).to(dtype)
+    b = torch.tensor(rng.standard_normal(Cout).astype(np.float32) * 0.1)
+    z_ref = orc.conv2d_nhwc(x.float(), w.float(), b, 1, "same")
+    y_ref = z_ref
+    scale = shift = None
+    if bn:
+        scale = torch.tensor(rng.uniform(0.5, 1.5, Cout).astype(np.float32))
+        shift = torch.tensor(rng.uniform(-0.2, 0.2, Cout).astype(np.float32))
+        y_ref = z_ref * scale + shift
+    if act == 1:
+        y_ref = torch.relu(y_ref)
+    os.environ["MRCNN_H16_TILE"] = "phase"
+    if grid:
+        os.environ["MRCNN_H16P_GRID"] = str(grid)
+    ops.tuning_set("h16_slab", 1)
+    try:
+        wf, wd = ops.weights_to_h16(w.float().to(dev), dtype)
+        z = torch.full((N, H, W, Cout), float("nan"), dtype=dtype, device=dev)
+        y = torch.full((N, H, W, Cout), float("nan"), dtype=dtype, device=dev)
+        ops.conv2d_h16(x.to(dev), wf, (3, 3, Cin, Cout), b.to(dev), None if scale is None else scale.to(dev),
+                       None if shift is None else shift.to(dev), 1, "same", act, z_out=z, out=y)
+        torch.cuda.synchronize()
+        for got, ref, name in ((y, y_ref, "out"), (z, z_ref, "z")):
+            err = float((got.float().cpu() - ref).abs().max()) / float(ref.abs().max())
+            assert err <= TOL[dtype], "%s: max error %.3g of max |ref| (allowed %.3g)" % (name, err, TOL[dtype])
+        if Cin % 256 == 0 and Cout % 128 == 0:
+            xg = x.float().clone().requires_grad_(True)
+            yy = orc.conv2d_nhwc(xg, w.float(), None, 1, "same")
+            dz = torch.tensor(rng.standard_normal(tuple(yy.shape)).astype(np.float32)).to(dtype)
+            yy.backward(dz.float())
+            dx = ops.conv2d_h16(dz.to(dev), wd, (3, 3, Cout, Cin), None, None, None, 1, (1, 1), 0)
+            torch.cuda.synchronize()
+            err = float((dx.float().cpu() - xg.grad).abs().max()) / float(xg.grad.abs().max())
+            assert err <= TOL[dtype], "dgrad: max error %.3g (allowed %.3g)" % (err, TOL[dtype])
+    finally:
+        ops.tuning_set("h16_slab", -1)
+        del os.environ["MRCNN_H16_TILE"]
+        os.environ.pop("MRCNN_H16P_GRID", None)
 
 
 def test_float16_overflow_skips_the_step_and_lowers_the_loss_scale(dev):

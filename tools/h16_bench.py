@@ -27,8 +27,9 @@ for dtype in (torch.float16, torch.bfloat16):
     wf, wd = ops.weights_to_h16(w, dtype)
     b = torch.zeros(256, device=dev); sc = torch.ones(256, device=dev)
     out = torch.empty(N, 14, 14, 256, device=dev, dtype=dtype)
-    for tile in ("small", "big", "phase", "phase-nosplit") * 2:       # interleaved rounds in one process
+    for tile in ("small", "big", "phase", "phase-noslab", "phase-nosplit") * 2:       # interleaved rounds in one process
         os.environ["MRCNN_H16_TILE"] = tile.split("-")[0]
+        ops.tuning_set("h16_slab", 0 if "noslab" in tile else 1)        # slab-plus-halo staging (conv_fwd_h16q_kernel) vs per-tap staging
         os.environ.pop("MRCNN_H16P_NO_SPLIT", None)
         os.environ.pop("MRCNN_H16P_GRID", None)
         if "nosplit" in tile:
@@ -38,6 +39,7 @@ for dtype in (torch.float16, torch.bfloat16):
         ms = timed(lambda: ops.conv2d_h16(x, wf, (3, 3, 256, 256), b, sc, b, 1, "same", 1, out=out))
         print("%s fwd tile=%-22s N=%d: %.3f ms  %.1f TFLOP/s" % (dtype, tile, N, ms, fl / ms / 1e9), flush=True)
     del os.environ["MRCNN_H16_TILE"]
+    ops.tuning_set("h16_slab", -1)
     dy = torch.randn(N, 14, 14, 256, device=dev).to(dtype)
     dw = torch.empty(3, 3, 256, 256, device=dev)
     ms = timed(lambda: ops.conv2d_wgrad_h16(x, dy, (3, 3, 256, 256), 1, "same", dw=dw))
