@@ -4,7 +4,8 @@
 //  K1 select_sort_decode (one 1024-thread workgroup per image)
 //       4-pass MSB-first radix select of the k-th largest score over the A anchors (LDS histograms),
 //       compaction of the k winners (ties at the threshold taken in ascending anchor index, which is
-//       tf.nn.top_k's order), bitonic sort of 64-bit (score desc, index asc) keys in LDS, then
+//       tf.nn.top_k's order), bitonic sort of 64-bit (score desc, index asc) keys -- 8 keys per thread in registers,
+//       wave-level exchanges by shuffle, LDS only for the strides that cross waves -- then
 //       apply_box_deltas_graph + clip_boxes_graph on the sorted winners.
 //  K2 nms_mask: 64x64 tiles of the upper-triangular suppression bit matrix (IoU > threshold).
 //  K3 nms_scan (one wave per image): chunked greedy scan over the bit matrix, gather + zero pad.
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(PRE_THREADS) void topk_collect_kernel(const PropArg
 
 __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const PropArgs p) {
     __shared__ unsigned long long keys[SORT_CAP];
+    __shared__ unsigned long long xkeys[SORT_CAP];            // second exchange buffer of the sort's cross-wave stages
     __shared__ unsigned hist[256];
     __shared__ unsigned s_prefix, s_need, s_count, s_wsum[16], s_base;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -195,15 +197,35 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
     if (tid == 0) { s_prefix = 0; s_need = (unsigned)K; }
     __syncthreads();
     unsigned cnt_eq = 0;
+    // round 3: the scores of a 256 x 256 image (A = 16 368) are read ONCE -- a thread's 16 keys stay in registers for the four
+    // passes and the compaction (five strided walks over the scores before; larger A without a pre-selection keeps those)
+    constexpr int KC = 16;
+    const bool cached = !preselected && A <= KC * K1_THREADS;
+    unsigned uk[KC];
+    if (cached) {
+#pragma unroll
+        for (int i = 0; i < KC; ++i) {
+            const int a = i * K1_THREADS + tid;
+            uk[i] = a < A ? f2key(sc[(int64_t)a * 2]) : 0u;      // key 0 is below every real key (f2key sets or flips the top bit)
+        }
+    }
     for (int pass = 0; pass < 4 && !preselected; ++pass) {
         const int shift = 24 - 8 * pass;
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
         const unsigned prefix = s_prefix;
         const unsigned himask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        for (int a = tid; a < A; a += K1_THREADS) {
-            unsigned u = f2key(sc[(int64_t)a * 2]);
-            if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        if (cached) {
+#pragma unroll
+            for (int i = 0; i < KC; ++i) {
+                const unsigned u = uk[i];
+                if (i * K1_THREADS + tid < A && (u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+            }
+        } else {
+            for (int a = tid; a < A; a += K1_THREADS) {
+                unsigned u = f2key(sc[(int64_t)a * 2]);
+                if ((u & himask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+            }
         }
         __syncthreads();
         if (tid == 0) {
@@ -233,12 +255,18 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
         const unsigned long long* cand = p.cand_ws + (int64_t)b * SORT_CAP;
         for (int i = tid; i < (int)ncand; i += K1_THREADS) keys[i] = cand[i];
     }
-    for (int a0 = 0; a0 < A && !preselected; a0 += K1_THREADS) {
+    for (int a0 = 0, it = 0; a0 < A && !preselected; a0 += K1_THREADS, ++it) {
         const int a = a0 + tid;
         unsigned u = 0;
         bool gt = false, eq = false;
         if (a < A) {
-            u = f2key(sc[(int64_t)a * 2]);
+            if (cached) {
+                u = uk[0];
+#pragma unroll
+                for (int i = 1; i < KC; ++i) u = it == i ? uk[i] : u;      // (a select chain: a run-time index would put uk[] in scratch)
+            } else {
+                u = f2key(sc[(int64_t)a * 2]);
+            }
             gt = u > T;
             eq = u == T;
         }
@@ -270,25 +298,73 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
     __syncthreads();
 
     // ---- bitonic sort (ascending 64-bit keys == score descending, index ascending) ----------------
+    // round 3: a thread holds 8 consecutive keys in registers (e = 8 tid + j).  Strides 1 / 2 / 4 are exchanges inside the thread,
+    // strides 8 .. 256 lane exchanges inside the wave (__shfl_xor), only strides >= 512 cross waves and go through LDS (two
+    // buffers in turn: one barrier per such stage): 10 barrier stages for 8 192 keys instead of 91.  The network and its
+    // comparisons are the ones of the LDS form (same keys, same order: the result is a sort either way).
     int n = 1;
     const int nsort = preselected && (int)ncand > K ? (int)ncand : K;
     while (n < nsort) n <<= 1;
-    for (int size = 2; size <= n; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < (n >> 1); t += K1_THREADS) {
-                int lo = ((t / stride) * stride * 2) + (t % stride);
-                int hi = lo + stride;
-                bool up = ((lo & size) == 0);
-                unsigned long long x = keys[lo], y = keys[hi];
-                if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+    if (n < 8) n = 8;
+    unsigned long long k8[8];
+    const bool mine = tid * 8 < n;                             // threads past n hold padding only
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k8[j] = mine ? keys[tid * 8 + j] : ~0ull;
+    __syncthreads();                                           // keys[] is free: it becomes the first exchange buffer
+    auto cs = [](unsigned long long& lo, unsigned long long& hi, const bool up) {
+        const bool sw = (lo > hi) == up;
+        const unsigned long long x = sw ? hi : lo, y = sw ? lo : hi;
+        lo = x; hi = y;
+    };
+    auto intra = [&](const int stride, const bool up0, const int size) {       // stride 1, 2 or 4; `up` per element when size < 8
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if ((j & stride) == 0) {
+                const bool up = size >= 8 ? up0 : ((j & size) == 0);
+                cs(k8[j], k8[j | stride], up);
             }
-            __syncthreads();
         }
+    };
+    const int lane = tid & 63;
+    int xbuf = 0;
+    for (int size = 2; size <= n; size <<= 1) {
+        const bool up0 = ((tid * 8) & size) == 0;              // direction of this thread's elements for size >= 8
+        for (int stride = size >> 1; stride >= 512; stride >>= 1) {      // partner thread in another wave: through LDS
+            unsigned long long* buf = xbuf ? xkeys : keys;
+            xbuf ^= 1;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) buf[tid * 8 + j] = k8[j];
+            __syncthreads();
+            const int pt = tid ^ (stride >> 3);
+            const bool is_lo = (tid & (stride >> 3)) == 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned long long o = buf[pt * 8 + j];
+                const bool take_min = is_lo == up0;
+                k8[j] = take_min ? (o < k8[j] ? o : k8[j]) : (o > k8[j] ? o : k8[j]);
+            }
+        }
+        for (int stride = (size >> 1) < 256 ? (size >> 1) : 256; stride >= 8; stride >>= 1) {   // partner lane in this wave
+            const int lm = stride >> 3;
+            const bool is_lo = (lane & lm) == 0;
+            const bool take_min = is_lo == up0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned long long o = __shfl_xor(k8[j], lm, 64);
+                k8[j] = take_min ? (o < k8[j] ? o : k8[j]) : (o > k8[j] ? o : k8[j]);
+            }
+        }
+        if (size >= 8) { intra(4, up0, size); intra(2, up0, size); intra(1, up0, size); }
+        else if (size == 4) { intra(2, up0, 4); intra(1, up0, 4); }
+        else intra(1, up0, 2);
     }
 
     // ---- decode + clip (apply_box_deltas_graph, clip_boxes_graph with window [0,0,1,1]) ------------
-    for (int i = tid; i < K; i += K1_THREADS) {
-        const unsigned a = (unsigned)(keys[i] & 0xFFFFFFFFull);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int i = tid * 8 + j;
+        if (i >= K) continue;
+        const unsigned a = (unsigned)(k8[j] & 0xFFFFFFFFull);
         if (p.top_idx) p.top_idx[(int64_t)b * K + i] = (int)a;
         const float* an = p.anchors + (int64_t)a * 4;
         const float* dl = p.deltas + ((int64_t)b * A + a) * 4;
