@@ -16,6 +16,11 @@
 #include "common.h"
 
 #define SORT_CAP 8192           // bitonic capacity (pre_nms_limit <= SORT_CAP)
+#ifdef MRCNN_PROP_STAMPS        // debug build (build(extra_flags=["-DMRCNN_PROP_STAMPS"])): section times of select_sort_decode, image 0
+#define PROP_STAMP(i) do { if (tid == 0 && blockIdx.x == 0) st_[i] = wall_clock64(); } while (0)
+#else
+#define PROP_STAMP(i) do { } while (0)
+#endif
 #define K1_THREADS 1024
 
 __device__ __forceinline__ unsigned f2key(float f) {
@@ -186,6 +191,10 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* sc = p.probs + (int64_t)b * p.A * 2 + 1;     // foreground probability, stride 2
     const int A = p.A, K = p.K;
+#ifdef MRCNN_PROP_STAMPS
+    unsigned long long st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    PROP_STAMP(0);
 
     // the pre-selection must have delivered exactly the K keys it announced; anything else (counter not reset, refused
     // stores) is discarded and this workgroup selects for itself -- slower, never wrong and never out of bounds
@@ -242,6 +251,7 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
         __syncthreads();
         cnt_eq = s_count;
     }
+    PROP_STAMP(1);
     const unsigned T = s_prefix;       // k-th largest key
     const unsigned need_eq = s_need;   // how many keys == T belong to the top K (>= 1)
 
@@ -297,6 +307,7 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
     }
     __syncthreads();
 
+    PROP_STAMP(2);
     // ---- bitonic sort (ascending 64-bit keys == score descending, index ascending) ----------------
     // round 3: a thread holds 8 consecutive keys in registers (e = 8 tid + j).  Strides 1 / 2 / 4 are exchanges inside the thread,
     // strides 8 .. 256 lane exchanges inside the wave (__shfl_xor), only strides >= 512 cross waves and go through LDS (two
@@ -359,6 +370,7 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
         else intra(1, up0, 2);
     }
 
+    PROP_STAMP(3);
     // ---- decode + clip (apply_box_deltas_graph, clip_boxes_graph with window [0,0,1,1]) ------------
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -371,6 +383,12 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
         float d0 = dl[0] * p.s0, d1 = dl[1] * p.s1, d2 = dl[2] * p.s2, d3 = dl[3] * p.s3;
         decode_clip_box(an, d0, d1, d2, d3, 0.f, 0.f, 1.f, 1.f, p.boxes_ws + ((int64_t)b * K + i) * 4);
     }
+    PROP_STAMP(4);
+#ifdef MRCNN_PROP_STAMPS
+    if (tid == 0 && blockIdx.x == 0)
+        printf("select_sort_decode (10 ns units): select %llu  compaction %llu  sort %llu  decode %llu\n", st_[1] - st_[0], st_[2] - st_[1],
+               st_[3] - st_[2], st_[4] - st_[3]);
+#endif
 }
 
 // grid (nwords, nwords, B); workgroup = 64 threads: row i = 64*blockIdx.y + lane against 64 columns
