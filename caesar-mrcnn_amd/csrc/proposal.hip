@@ -186,7 +186,7 @@ __global__ __launch_bounds__(PRE_THREADS) void topk_collect_kernel(const PropArg
 __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const PropArgs p) {
     __shared__ unsigned long long keys[SORT_CAP];
     __shared__ unsigned long long xkeys[SORT_CAP];            // second exchange buffer of the sort's cross-wave stages
-    __shared__ unsigned hist[256];
+    __shared__ unsigned hist[256], s_suf[256];
     __shared__ unsigned s_prefix, s_need, s_count, s_wsum[16], s_base;
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* sc = p.probs + (int64_t)b * p.A * 2 + 1;     // foreground probability, stride 2
@@ -237,16 +237,35 @@ __global__ __launch_bounds__(K1_THREADS) void select_sort_decode_kernel(const Pr
             }
         }
         __syncthreads();
-        if (tid == 0) {
-            unsigned need = s_need, cum = 0;
-            int d = 255;
-            for (; d > 0; --d) {
-                if (cum + hist[d] >= need) break;
-                cum += hist[d];
+        // the digit d with count(digits > d) < need <= count(digits >= d): suffix sums of the 256 bins by the first four waves
+        // (shuffle scan inside a wave, wave totals through LDS) -- one thread walking the bins took ~8 us per pass
+        {
+            const unsigned need = s_need;
+            unsigned suf = 0;
+            if (tid < 256) {
+                suf = hist[tid];
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const unsigned v = __shfl_down(suf, o, 64);
+                    if ((tid & 63) + o < 64) suf += v;
+                }
+                if ((tid & 63) == 0) s_wsum[tid >> 6] = suf;           // total of this wave's 64 bins
             }
-            s_prefix = prefix | ((unsigned)d << shift);
-            s_need = need - cum;
-            s_count = hist[d];
+            __syncthreads();
+            if (tid < 256) {
+                for (int w = (tid >> 6) + 1; w < 4; ++w) suf += s_wsum[w];
+                s_suf[tid] = suf;                                       // count(digits >= tid)
+            }
+            __syncthreads();
+            if (tid < 256) {
+                const unsigned above = tid < 255 ? s_suf[tid + 1] : 0u;    // count(digits > tid)
+                // suffix sums fall with the digit: exactly one digit has above < need <= suf (digit 0 takes the rest, as the walk did)
+                if ((suf >= need || tid == 0) && above < need) {
+                    s_prefix = prefix | ((unsigned)tid << shift);
+                    s_need = need - above;
+                    s_count = hist[tid];
+                }
+            }
         }
         __syncthreads();
         cnt_eq = s_count;
