@@ -628,7 +628,9 @@ def measure_config4(args, rank, local_rank, world):
     out = {"workload": "BASELINE.json configs[4]: resnet101+FPN 512x512, nimg_per_gpu=4, train step, 16-bit weights/activations "
                        "on the 16-bit MFMA where built (mask head, FPN smoothing, shared RPN conv, class FCs, every bottleneck "
                        "block; both ROIAlign gathers and the mask head's ROIAlign adjoint read / write 16-bit tensors), float32 elsewhere "
-                       "(stem, FPN laterals, the 4- to 16-column output layers, the class head's gather-form ROIAlign adjoint); float32 master weights and gradients, "
+                       "(what each costs in the profiled f16 step, profiles/r03_step_kernels_512_f16.txt: stem 0.19 ms forward + ~0.3 ms weight gradient, FPN laterals 0.28 ms + ~0.5 ms of "
+                       "weight gradients on the side stream, the 4- to 16-column output layers < 0.2 ms, the class head's gather-form ROIAlign adjoint 1.0 ms on the auxiliary stream, "
+                       "casts at the 16-bit / float32 seams 1.1 ms over 58 launches); float32 master weights and gradients, "
                        "loss scale 4096 + guarded optimiser step (f16)",
            "unit": "images/s"}
     steps = max(5, args.steps // 2)
