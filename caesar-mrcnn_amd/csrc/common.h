@@ -21,6 +21,7 @@ extern int g_mrcnn_wgrad_lds_pad;
 //   its data gradients) the statically assigned tiles start late on the CUs the other kernel held.
 extern int g_mrcnn_h16_phase;
 extern int g_mrcnn_h16_slab;
+extern int g_mrcnn_sk16;
 //   proposal_skip_zero: tests only (fault injection): 1 suppresses the reset of the multi-workgroup top-k's counters.
 extern int g_mrcnn_proposal_skip_zero;
 

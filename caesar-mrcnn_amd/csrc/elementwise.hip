@@ -620,6 +620,7 @@ int g_mrcnn_wgrad_lds_pad = 0;
 int g_mrcnn_h16_phase = 1;
 int g_mrcnn_h16_slab = -1;               // -1: MRCNN_H16_SLAB decides (default off: measured slower); 0 / 1: set by mrcnn_tuning_set (tests, A/B)
 int g_mrcnn_proposal_skip_zero = 0;
+int g_mrcnn_sk16 = 0;                    // 1 while the inference graph is issued (engine.infer): the 16 x 16-tile small-layer kernel may be picked
 
 extern "C" int mrcnn_tuning_set(const char* key, long long value) {
     if (!key) return MRCNN_ERR_ARG;
@@ -636,6 +637,11 @@ extern "C" int mrcnn_tuning_set(const char* key, long long value) {
     if (!strcmp(key, "h16_slab")) {
         if (value < -1 || value > 1) return MRCNN_ERR_ARG;
         g_mrcnn_h16_slab = (int)value;
+        return MRCNN_OK;
+    }
+    if (!strcmp(key, "sk16")) {
+        if (value < 0 || value > 1) return MRCNN_ERR_ARG;
+        g_mrcnn_sk16 = (int)value;
         return MRCNN_OK;
     }
     if (!strcmp(key, "proposal_skip_zero")) {

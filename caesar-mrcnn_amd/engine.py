@@ -252,6 +252,7 @@ class MaskRCNNEngine(object):
         self.winograd_wgrad = os.environ.get("MRCNN_WINOGRAD_WGRAD", "1") != "0"    # weight gradients through the same domain
         # the trunk's large 3x3 layers (FPN smoothing, RPN shared convolution on levels of >= 16 384 pixels) through F(2x2, 3x3)
         # in the forward pass (A/B switch, see DESIGN 4.1e for the measurement)
+        self.sk16_infer = os.environ.get("MRCNN_SK16_INFER", "1") != "0"
         self.trunk_winograd = os.environ.get("MRCNN_WINOGRAD_TRUNK", "1") != "0"
         self.trunk_winograd_min_rows = int(os.environ.get("MRCNN_WINOGRAD_TRUNK_MIN_ROWS", "4096"))
         # forward as two half-batch chains on two streams: +0.7 ms with the F(2x2) layers, level with the uniform F(4x4) tiling, a loss with
@@ -1048,8 +1049,14 @@ class MaskRCNNEngine(object):
         cfg = self.cfg
         B, H, W = images.shape[0], images.shape[1], images.shape[2]
         area = float(H * W)
-        pyr, _ = self._trunk_fwd(images, False)
-        _, rpn_probs, rpn_bbox, _ = self._rpn_fwd(pyr, False)
+        # layers of a few hundred pixels (res4 / res5 / P5 / P6 at batch 1) take the 16 x 16-tile single-launch kernel while the
+        # inference trunk is issued: detect graph 3.01 -> 2.73 ms (ResNet-101), 2.35 -> 2.23 (ResNet-50).  Training keeps its kernels.
+        ops.tuning_set("sk16", 1 if self.sk16_infer else 0)
+        try:
+            pyr, _ = self._trunk_fwd(images, False)
+            _, rpn_probs, rpn_bbox, _ = self._rpn_fwd(pyr, False)
+        finally:
+            ops.tuning_set("sk16", 0)
         anchors = self.anchors((H, W, images.shape[3]))
         rois = ops.proposals(rpn_probs, rpn_bbox, anchors, cfg.PRE_NMS_LIMIT, cfg.POST_NMS_ROIS_INFERENCE,
                              cfg.RPN_NMS_THRESHOLD, np.asarray(cfg.RPN_BBOX_STD_DEV, np.float32))

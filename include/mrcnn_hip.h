@@ -552,7 +552,8 @@ const char* mrcnn_allreduce_last_error(void);
 /* Process-wide tuning values, read by the host side of later launches.  Keys: "wgrad_lds_pad" (0..32768 bytes of extra
  * LDS per workgroup of the large weight-gradient kernel: 8192 caps it at four workgroups per CU so that kernels of another
  * stream find a free slot on every CU); "h16_phase" (0 / 1); "h16_slab" (-1 = MRCNN_H16_SLAB decides, default off; 0 / 1: the slab form of the phased 16-bit kernel off /
- * on -- tests and A/B timing); "proposal_skip_zero" (tests only, fault injection: 1 suppresses
+ * on -- tests and A/B timing); "sk16" (0 / 1: the 16 x 16-tile single-launch kernel for layers of a few hundred pixels may be
+ * picked -- the engine sets it while it issues the inference graph); "proposal_skip_zero" (tests only, fault injection: 1 suppresses
  * the counter reset of mrcnn_proposal_fwd's multi-workgroup selection).  MRCNN_ERR_UNSUPPORTED for an unknown key.   */
 int mrcnn_tuning_set(const char* key, long long value);
 

@@ -50,6 +50,13 @@ CONV_CASES = [
     (3, 64, 64, 256, 128, 1, 1, "valid", 0, False, 0),   # LDS-DMA kernel, 1x1, one N tile
     (457, 14, 14, 64, 256, 3, 1, "same", 1, True, 1),    # LDS-DMA kernel with the TAIL SPLIT: 700 x 2 tiles = 1.09 rounds of 1280 slots ->
                                                          # 640 row tiles unsplit, 60 (ragged M = 89572) as 4 K slices + slab reduction; BN, residual, z
+    # conv_fwd_sk16_kernel (16 x 16 tiles, four waves split K): the batch-1 detect shapes, too small for the 32 x 32 single-launch kernel
+    (1, 16, 16, 1024, 256, 1, 1, "valid", 1, True, 0),   # res4 2a at batch 1: 256 tiles, 8 K-steps per wave
+    (1, 16, 16, 256, 256, 3, 1, "same", 1, True, 0),     # res4 2b: padded taps, 18 K-steps per wave
+    (1, 16, 16, 256, 1024, 1, 1, "valid", 1, True, 1),   # res4 2c: K = 256 (2 K-steps per wave), shortcut added before the ReLU
+    (1, 8, 8, 2048, 512, 1, 1, "valid", 1, True, 0),     # res5 2a: 128 tiles
+    (1, 7, 9, 256, 128, 3, 1, "same", 0, False, 1),      # ragged M (63 = 3 x 16 + 15), odd map, residual, no BN
+    (1, 16, 16, 512, 256, 1, 2, "valid", 1, True, 0),    # stride-2 1 x 1 (first block of a stage): 64 pixels out
 ]
 
 
@@ -94,7 +101,11 @@ def test_conv_fwd(dev, case, tail_split_env):
     elif act == 2:
         y = torch.sigmoid(y)
     z = torch.empty(tuple(y.shape), device=dev)
-    out = ops.conv2d(xt, wt, bt, scale, shift, rt, stride, padding, act, res, z_out=z)
+    ops.tuning_set("sk16", 1)           # what engine.infer sets: the 16 x 16-tile kernel may take the shapes written for it below
+    try:
+        out = ops.conv2d(xt, wt, bt, scale, shift, rt, stride, padding, act, res, z_out=z)
+    finally:
+        ops.tuning_set("sk16", 0)
     torch.cuda.synchronize()
     torch.testing.assert_close(out.cpu(), y, **F32)
     torch.testing.assert_close(z.cpu(), z_ref, **F32)
