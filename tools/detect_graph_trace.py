@@ -62,7 +62,7 @@ def report():
         wall = part[-1][1] - part[0][0]
         print("  %-28s %4d launches  wall %.3f ms  kernel time %.3f ms  idle %.3f ms  (%.1f us per launch)" % (
             name, len(part), wall / 1e6, busy / 1e6, (wall - busy) / 1e6, wall / 1e3 / len(part)))
-    for name, lo, hi in cuts[1:]:
+    for name, lo, hi in (cuts if len(sys.argv) > 4 and sys.argv[4] == "all" else cuts[1:]):      # report <trace> <replay> all: the trunk's launches too
         print("  %s kernels in start order:" % name)
         for s_, e_, n_, wg_ in seg[lo:hi]:
             print("    +%8.1f us  %7.1f us  wgs=%-6d %s" % ((s_ - t0) / 1e3, (e_ - s_) / 1e3, wg_, n_[:60]))
