@@ -253,6 +253,10 @@ class MaskRCNNEngine(object):
         # the trunk's large 3x3 layers (FPN smoothing, RPN shared convolution on levels of >= 16 384 pixels) through F(2x2, 3x3)
         # in the forward pass (A/B switch, see DESIGN 4.1e for the measurement)
         self.sk16_infer = os.environ.get("MRCNN_SK16_INFER", "1") != "0"
+        # the mask head of the inference graph: 4 = uniform F(4x4, 3x3) tiles (16 overhanging tiles per 14 x 14 map: 36 x 1600 GEMM rows
+        # for 100 detections where F(2x2) has 16 x 4900; 1.3e-5 of the result's range instead of 1.6e-6, on probabilities that are
+        # thresholded at 0.5) -- detect graph 2.73 -> 2.60 ms; 2 = F(2x2) as in rounds 1-2
+        self.infer_mask_tile = int(os.environ.get("MRCNN_WINOGRAD_INFER_MASK_TILE", "4"))
         self.trunk_winograd = os.environ.get("MRCNN_WINOGRAD_TRUNK", "1") != "0"
         self.trunk_winograd_min_rows = int(os.environ.get("MRCNN_WINOGRAD_TRUNK_MIN_ROWS", "4096"))
         # forward as two half-batch chains on two streams: +0.7 ms with the F(2x2) layers, level with the uniform F(4x4) tiling, a loss with
@@ -350,11 +354,12 @@ class MaskRCNNEngine(object):
         if not v:
             self._wino_valid = {}
 
-    def _wino_U(self, op, which, xshape, train=True):
+    def _wino_U(self, op, which, xshape, train=True, infer_tile=2):
         """Winograd-domain kernel of layer `op` for an input of shape xshape (in training the shape picks the tile size; inference
-        always takes F(2x2, 3x3), whatever the batch): which = 0 forward (from op.w), 1 data gradient (from the flipped /
-        transposed op.wt, which must be current).  Refreshed lazily after every weight update, in place."""
-        tile = ops.winograd_tile(tuple(xshape)) if train else 2
+        takes `infer_tile`, whatever the batch: F(2x2, 3x3) for the trunk -- the RPN scores feed index-exact proposal selection --,
+        the uniform F(4x4, 3x3) tiling for the mask head, whose output is thresholded at 0.5): which = 0 forward (from op.w), 1 data
+        gradient (from the flipped / transposed op.wt, which must be current).  Refreshed lazily after every weight update, in place."""
+        tile = ops.winograd_tile(tuple(xshape)) if train else infer_tile
         key = (op.name, tile)
         ent = self._wino.setdefault(key, [None, None])
         ok = self._wino_valid.setdefault(key, [False, False])
@@ -971,7 +976,7 @@ class MaskRCNNEngine(object):
                     V = ops.empty((ops.winograd_v_floats(tuple(x.shape)),), torch.float32, self.dev) if (train and self.winograd_wgrad) else None
                     if V is not None:
                         self._wino_V[op.name] = [(V, 0, x.shape[0])]
-                    ops.conv2d_winograd(x, self._wino_U(op, 0, x.shape, train), op.b, op.scale, op.shift, ACT_RELU, out=out, z_out=z, keep_v=V)
+                    ops.conv2d_winograd(x, self._wino_U(op, 0, x.shape, train, self.infer_mask_tile), op.b, op.scale, op.shift, ACT_RELU, out=out, z_out=z, keep_v=V)
                     x, c = out, ((x, z, out, ACT_RELU) if train else None)
                 else:
                     x, c = op.forward(x, ACT_RELU, train=train)
@@ -1014,7 +1019,7 @@ class MaskRCNNEngine(object):
         halves = ((0, cut, main), (cut, N, side))
         ops_ = [self.op("mrcnn_mask_conv%d" % i) for i in range(1, 5)]
         hshape = lambda op, a, b: (b - a,) + tuple(x.shape[1:3]) + (op.wshape[2],)
-        Us = [[self._wino_U(op, 0, hshape(op, a, b), train) for a, b, _ in halves] for op in ops_]   # weight transforms on the main stream, before the fork
+        Us = [[self._wino_U(op, 0, hshape(op, a, b), train, self.infer_mask_tile) for a, b, _ in halves] for op in ops_]   # weight transforms on the main stream, before the fork
         outs, zs, ctxs = [], [], []
         cur = x
         for op in ops_:
